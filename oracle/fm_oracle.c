@@ -1,0 +1,340 @@
+/*
+ * fm_oracle.c -- CPU ORACLE (TEST INFRASTRUCTURE, NOT PRODUCT CODE).  See fm_oracle.h.
+ *
+ * Pass-by-pass restatement of examples/simple_fm.rs (ccostes/rtl-sdr-rs v0.3.1); every
+ * function cites the lines it follows.  Build: gcc -O2 -fwrapv (see oracle/Makefile).
+ */
+#include "fm_oracle.h"
+
+#include <math.h>
+#include <pthread.h>
+#include <stdlib.h>
+#include <string.h>
+#include <time.h>
+
+/* std::f64::consts::PI (simple_fm.rs:17,373) */
+static const double FMO_PI = 3.14159265358979323846264338327950288;
+
+/* ---- optimal_settings, simple_fm.rs:189-214 ------------------------------------------ */
+int fmo_optimal_settings(uint32_t freq, uint32_t rate, uint32_t rate_resample,
+                         fmo_radio_config *radio, fmo_demod_config *demod)
+{
+    if (rate == 0) return -1;                           /* :190 would divide by zero */
+    uint32_t downsample = (1000000u / rate) + 1;        /* :190 */
+    uint32_t capture_rate = downsample * rate;          /* :192 */
+    uint32_t capture_freq = freq + capture_rate / 4;    /* :195 offset tuning */
+    uint32_t output_scale = (1u << 15) / (128u * downsample); /* :197 */
+    if (output_scale < 1) output_scale = 1;             /* :198-200 */
+    if (radio) {
+        radio->capture_freq = capture_freq;             /* :203 */
+        radio->capture_rate = capture_rate;             /* :204 */
+    }
+    if (demod) {
+        demod->rate_in = rate;                          /* :207 (SAMPLE_RATE) */
+        demod->rate_out = rate;                         /* :208 (SAMPLE_RATE) */
+        demod->rate_resample = rate_resample;           /* :209 (RATE_RESAMPLE) */
+        demod->downsample = downsample;                 /* :210 */
+        demod->output_scale = output_scale;             /* :211 */
+    }
+    return 0;
+}
+
+/* ---- Demod::new, simple_fm.rs:243-252 ------------------------------------------------- */
+void fmo_demod_new(fmo_demod *d, const fmo_demod_config *config)
+{
+    d->config = *config;
+    d->prev_index = 0;
+    d->now_lpr = 0;
+    d->prev_lpr_index = 0;
+    d->lp_now.re = 0; d->lp_now.im = 0;
+    d->demod_pre.re = 0; d->demod_pre.im = 0;
+}
+
+/* ---- Demod::rotate_90 (scalar cfg branch), simple_fm.rs:282-298 ------------------------ */
+int fmo_rotate_90(uint8_t *buf, size_t len)
+{
+    if (len % 8 != 0) return -1;
+    uint8_t tmp;
+    for (size_t i = 0; i < len; i += 8) {               /* :284 */
+        /* uint8_t negation = 255 - x */
+        tmp = (uint8_t)(255 - buf[i + 3]);              /* :286 */
+        buf[i + 3] = buf[i + 2];                        /* :287 */
+        buf[i + 2] = tmp;                               /* :288 */
+
+        buf[i + 4] = (uint8_t)(255 - buf[i + 4]);       /* :290 */
+        buf[i + 5] = (uint8_t)(255 - buf[i + 5]);       /* :291 */
+
+        tmp = (uint8_t)(255 - buf[i + 6]);              /* :293 */
+        buf[i + 6] = buf[i + 7];                        /* :294 */
+        buf[i + 7] = tmp;                               /* :295 */
+    }
+    return 0;
+}
+
+/* ---- `*val as i16 - 127`, simple_fm.rs:258 --------------------------------------------- */
+void fmo_center(const uint8_t *buf, size_t len, int16_t *out)
+{
+    for (size_t i = 0; i < len; i++) out[i] = (int16_t)((int16_t)buf[i] - 127);
+}
+
+/* ---- buf_to_complex, simple_fm.rs:441-450: windows(2).step_by(2) ------------------------ */
+size_t fmo_buf_to_complex(const int16_t *buf, size_t len, fmo_cplx *out)
+{
+    size_t n = 0;
+    for (size_t i = 0; i + 1 < len; i += 2) {           /* an odd trailing element is dropped */
+        out[n].re = (int32_t)buf[i];
+        out[n].im = (int32_t)buf[i + 1];
+        n++;
+    }
+    return n;
+}
+
+/* ---- Demod::low_pass_complex, simple_fm.rs:337-352 -------------------------------------- */
+size_t fmo_low_pass_complex(fmo_demod *d, const fmo_cplx *buf, size_t len, fmo_cplx *out)
+{
+    size_t n = 0;
+    for (size_t orig = 0; orig < len; orig++) {
+        d->lp_now.re += buf[orig].re;                   /* :340 */
+        d->lp_now.im += buf[orig].im;
+
+        d->prev_index += 1;                             /* :342 */
+        if (d->prev_index < (size_t)d->config.downsample) continue; /* :343 */
+
+        out[n++] = d->lp_now;                           /* :347 */
+        d->lp_now.re = 0; d->lp_now.im = 0;             /* :348 */
+        d->prev_index = 0;                              /* :349 */
+    }
+    return n;
+}
+
+/* num_complex 0.4 `a * b.conj()` on Complex<i32>: (ar*br - ai*(-bi), ar*(-bi) + ai*br),
+ * plain (wrapping in release) i32 arithmetic. */
+static fmo_cplx mul_conj(fmo_cplx a, fmo_cplx b)
+{
+    fmo_cplx c;
+    int32_t cbi = -b.im;
+    c.re = a.re * b.re - a.im * cbi;
+    c.im = a.re * cbi + a.im * b.re;
+    return c;
+}
+
+/* ---- Demod::polar_discriminant, simple_fm.rs:370-374 ------------------------------------ */
+int32_t fmo_polar_discriminant(fmo_cplx a, fmo_cplx b)
+{
+    fmo_cplx c = mul_conj(a, b);                        /* :371 */
+    double angle = atan2((double)c.im, (double)c.re);   /* :372 f64::atan2 -> libm */
+    double v = angle / FMO_PI * (double)(1 << 14);      /* :373 */
+    /* Rust `as i32`: truncate toward zero, saturate, NaN -> 0.  |v| <= 16384 here. */
+    if (v != v) return 0;
+    if (v >= 2147483647.0) return INT32_MAX;
+    if (v <= -2147483648.0) return INT32_MIN;
+    return (int32_t)v;
+}
+
+/* ---- Demod::fast_atan2, simple_fm.rs:383-405 -------------------------------------------- */
+int32_t fmo_fast_atan2(int32_t y, int32_t x)
+{
+    /* Pre-scaled for i16: pi = 1 << 14 */
+    const int32_t pi4 = 1 << 12;                        /* :386 */
+    const int32_t pi34 = 3 * (1 << 12);                 /* :387 */
+    if (x == 0 && y == 0) return 0;                     /* :388-390 */
+    int32_t yabs = y;
+    if (yabs < 0) yabs = -yabs;                         /* :391-394 */
+    int32_t angle;
+    if (x >= 0) {
+        /* :397  (pi4 as i64 * (x - yabs) as i64) as i32 / (x + yabs):
+         * i32 subtract, widen, i64 multiply, TRUNCATE to i32, then i32 divide. */
+        int32_t num = (int32_t)(uint32_t)((int64_t)pi4 * (int64_t)(int32_t)(x - yabs));
+        angle = pi4 - num / (x + yabs);
+    } else {
+        int32_t num = (int32_t)(uint32_t)((int64_t)pi4 * (int64_t)(int32_t)(x + yabs));
+        angle = pi34 - num / (yabs - x);                /* :399 */
+    }
+    if (y < 0) return -angle;                           /* :401-403 */
+    return angle;
+}
+
+/* ---- Demod::polar_discriminant_fast, simple_fm.rs:377-380 ------------------------------- */
+int32_t fmo_polar_discriminant_fast(fmo_cplx a, fmo_cplx b)
+{
+    fmo_cplx c = mul_conj(a, b);
+    return fmo_fast_atan2(c.im, c.re);
+}
+
+/* ---- Demod::fm_demod, simple_fm.rs:355-367 ---------------------------------------------- */
+long fmo_fm_demod(fmo_demod *d, const fmo_cplx *buf, size_t len, int16_t *out)
+{
+    if (!(len > 1)) return -1;                          /* :356 assert */
+    int32_t pcm = fmo_polar_discriminant(buf[0], d->demod_pre); /* :359 */
+    out[0] = (int16_t)(uint16_t)(uint32_t)pcm;          /* :360 `as i16` wraps */
+    for (size_t i = 1; i < len; i++) {
+        pcm = fmo_polar_discriminant_fast(buf[i], buf[i - 1]);  /* :362 */
+        out[i] = (int16_t)(uint16_t)(uint32_t)pcm;      /* :363 */
+    }
+    d->demod_pre = buf[len - 1];                        /* :365 */
+    return (long)len;
+}
+
+/* ---- Demod::low_pass_real, simple_fm.rs:408-426 ----------------------------------------- */
+long fmo_low_pass_real(fmo_demod *d, const int16_t *buf, size_t len, int16_t *out)
+{
+    long n = 0;
+    /* Simple square-window FIR */
+    uint32_t slow = d->config.rate_resample;            /* :411 */
+    uint32_t fast = d->config.rate_out;                 /* :412 */
+    size_t i = 0;
+    while (i < len) {
+        d->now_lpr += (int32_t)buf[i];                  /* :415 */
+        i += 1;
+        d->prev_lpr_index += (int32_t)slow;             /* :417 */
+        if (d->prev_lpr_index < (int32_t)fast) continue;/* :418 */
+        if (slow == 0 || (int32_t)(fast / slow) == 0) return -1;  /* :421 would panic */
+        out[n++] = (int16_t)(uint16_t)(uint32_t)(d->now_lpr / (int32_t)(fast / slow)); /* :421 */
+        d->prev_lpr_index -= (int32_t)fast;             /* :422 */
+        d->now_lpr = 0;                                 /* :423 */
+    }
+    return n;
+}
+
+/* A push-grown vector, like the `vec![]` + push of :338,:357,:409 (amortised doubling). */
+typedef struct { void *p; size_t len, cap, esz; } growvec;
+static int gv_push(growvec *v, const void *e)
+{
+    if (v->len == v->cap) {
+        size_t ncap = v->cap ? v->cap * 2 : 4;
+        void *np = realloc(v->p, ncap * v->esz);
+        if (!np) return -1;
+        v->p = np; v->cap = ncap;
+    }
+    memcpy((char *)v->p + v->len * v->esz, e, v->esz);
+    v->len++;
+    return 0;
+}
+
+/* ---- Demod::demodulate, simple_fm.rs:256-269 -------------------------------------------- */
+long fmo_demodulate(fmo_demod *d, const uint8_t *buf_in, size_t len, int16_t *out, size_t out_cap)
+{
+    if (len % 8 != 0) return -1;
+    long rc = -5;
+    uint8_t *buf = NULL; int16_t *buf_signed = NULL; fmo_cplx *complex_ = NULL;
+    int16_t *demodulated = NULL;
+    growvec lowpassed = {NULL, 0, 0, sizeof(fmo_cplx)};
+
+    buf = (uint8_t *)malloc(len ? len : 1);             /* the owned Vec<u8> argument */
+    if (!buf) goto done;
+    memcpy(buf, buf_in, len);
+    fmo_rotate_90(buf, len);                            /* :257 */
+
+    buf_signed = (int16_t *)malloc((len ? len : 1) * sizeof(int16_t));
+    if (!buf_signed) goto done;
+    fmo_center(buf, len, buf_signed);                   /* :258 */
+
+    complex_ = (fmo_cplx *)malloc((len / 2 + 1) * sizeof(fmo_cplx));
+    if (!complex_) goto done;
+    size_t nc = fmo_buf_to_complex(buf_signed, len, complex_);  /* :259 */
+
+    /* :261 low-pass filter to downsample to our desired sample rate (push-grown result) */
+    for (size_t orig = 0; orig < nc; orig++) {
+        d->lp_now.re += complex_[orig].re;
+        d->lp_now.im += complex_[orig].im;
+        d->prev_index += 1;
+        if (d->prev_index < (size_t)d->config.downsample) continue;
+        if (gv_push(&lowpassed, &d->lp_now)) goto done;
+        d->lp_now.re = 0; d->lp_now.im = 0;
+        d->prev_index = 0;
+    }
+
+    /* :264 Demodulate FM signal */
+    if (!(lowpassed.len > 1)) { rc = -2; goto done; }
+    demodulated = (int16_t *)malloc(lowpassed.len * sizeof(int16_t));
+    if (!demodulated) goto done;
+    fmo_fm_demod(d, (const fmo_cplx *)lowpassed.p, lowpassed.len, demodulated);
+
+    /* :267 Resample and return result */
+    {
+        int16_t *res = (int16_t *)malloc(lowpassed.len * sizeof(int16_t));
+        if (!res) goto done;
+        long n = fmo_low_pass_real(d, demodulated, lowpassed.len, res);
+        if (n < 0) rc = -4;
+        else if ((size_t)n > out_cap) rc = -3;
+        else { memcpy(out, res, (size_t)n * sizeof(int16_t)); rc = n; }
+        free(res);
+    }
+done:
+    free(buf); free(buf_signed); free(complex_); free(demodulated); free(lowpassed.p);
+    return rc;
+}
+
+/* ---- simple_fm file mode over complete blocks, simple_fm.rs:65-84 ----------------------- */
+long fmo_file_mode(fmo_demod *d, const uint8_t *data, size_t len, size_t block_len,
+                   int16_t *out, size_t out_cap)
+{
+    long total = 0;
+    if (block_len == 0) return -1;
+    for (size_t off = 0; off + block_len <= len; off += block_len) {
+        long n = fmo_demodulate(d, data + off, block_len, out + total, out_cap - (size_t)total);
+        if (n < 0) return n;
+        total += n;
+    }
+    return total;
+}
+
+/* ---- cpu_baseline helper -------------------------------------------------------------- */
+typedef struct {
+    const fmo_demod_config *config; const uint8_t *iq;
+    size_t c0, c1, calls, block_len; uint64_t checksum; uint32_t *out_len; int err;
+} bench_job;
+
+static void *bench_worker(void *arg)
+{
+    bench_job *j = (bench_job *)arg;
+    size_t cap = j->block_len / 2 + 16;
+    int16_t *out = (int16_t *)malloc(cap * sizeof(int16_t));
+    uint64_t h = 0;
+    for (size_t c = j->c0; c < j->c1; c++) {
+        fmo_demod d;
+        fmo_demod_new(&d, j->config);
+        long n = 0;
+        for (size_t k = 0; k < j->calls; k++) {
+            n = fmo_demodulate(&d, j->iq + (c * j->calls + k) * j->block_len, j->block_len, out, cap);
+            if (n < 0) { j->err = (int)n; break; }
+            for (long i = 0; i < n; i++)
+                h = h * 1099511628211ull + (uint16_t)out[i] + 0x9e3779b97f4a7c15ull * (c + 1);
+        }
+        if (j->out_len && n >= 0) j->out_len[c] = (uint32_t)n;
+    }
+    j->checksum = h;
+    free(out);
+    return NULL;
+}
+
+double fmo_bench_batch(const fmo_demod_config *config, const uint8_t *iq, size_t n_channels,
+                       size_t calls, size_t block_len, int n_threads, uint64_t *checksum,
+                       uint32_t *out_len)
+{
+    if (n_threads < 1) n_threads = 1;
+    if ((size_t)n_threads > n_channels) n_threads = (int)(n_channels ? n_channels : 1);
+    pthread_t *th = (pthread_t *)calloc((size_t)n_threads, sizeof(pthread_t));
+    bench_job *jobs = (bench_job *)calloc((size_t)n_threads, sizeof(bench_job));
+    struct timespec t0, t1;
+    clock_gettime(CLOCK_MONOTONIC, &t0);
+    for (int t = 0; t < n_threads; t++) {
+        jobs[t].config = config; jobs[t].iq = iq; jobs[t].calls = calls;
+        jobs[t].block_len = block_len; jobs[t].out_len = out_len;
+        jobs[t].c0 = n_channels * (size_t)t / (size_t)n_threads;
+        jobs[t].c1 = n_channels * (size_t)(t + 1) / (size_t)n_threads;
+        if (n_threads == 1) bench_worker(&jobs[t]);
+        else pthread_create(&th[t], NULL, bench_worker, &jobs[t]);
+    }
+    uint64_t h = 0; int err = 0;
+    for (int t = 0; t < n_threads; t++) {
+        if (n_threads > 1) pthread_join(th[t], NULL);
+        h ^= jobs[t].checksum;
+        if (jobs[t].err) err = jobs[t].err;
+    }
+    clock_gettime(CLOCK_MONOTONIC, &t1);
+    if (checksum) *checksum = h;
+    free(th); free(jobs);
+    if (err) return (double)err;
+    return (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec);
+}

@@ -1,0 +1,151 @@
+// fmd_index.h -- closed-form index algebra of the simple_fm demodulation chain.
+//
+// The reference (ccostes/rtl-sdr-rs, examples/simple_fm.rs:256-426) runs three sequential
+// state machines over one call's buffer: the boxcar decimator (low_pass_complex :337-352),
+// the discriminator (fm_demod :355-367) and the fractional boxcar resampler (low_pass_real
+// :408-426).  None of their *index* state depends on sample values, so every output is a
+// pure function of (call-start phases, position).  This header is that algebra; the HIP
+// kernels (fmd_kernels.hip), the host bookkeeping (fmd_api.cpp) and the CPU closed-form
+// model used by the tests (oracle/closed_form.cpp) all include it, so the tests exercise
+// the very expressions the kernel uses.
+//
+// Notation (per channel, per call):
+//   D      downsample                      p0   Demod.prev_index at call start, 0 <= p0 < D
+//   fast   rate_out, slow rate_resample    i0   Demod.prev_lpr_index at call start, 0 <= i0 < fast
+//   g      gcd(fast, slow); fr = fast/g, sr = slow/g, i0r = i0/g (i0 is always a multiple of g)
+//   ns     complex samples in the call (= nbytes / 2)
+//   M      decimated (= discriminator) samples produced this call
+//   K      audio samples produced this call
+//   lp[j]  j-th decimated sample of the call = (j == 0 ? lp_now : 0) + sum x[n], n in
+//          [max(0, D*j - p0), D*j - p0 + D)
+//   e(k)   index j of the discriminator sample that completes audio sample k
+#ifndef FMD_INDEX_H
+#define FMD_INDEX_H
+
+#include <stdint.h>
+
+#if defined(__HIPCC__) || defined(__CUDACC__)
+#define FMD_HD __host__ __device__ __forceinline__
+#else
+#define FMD_HD inline
+#endif
+
+// Constants derived once per handle from DemodConfig (simple_fm.rs:179-185).
+struct FmdRates {
+    uint32_t D;      // downsample
+    uint32_t fast;   // rate_out
+    uint32_t slow;   // rate_resample
+    uint32_t g;      // gcd(fast, slow)
+    uint32_t fr;     // fast / g
+    uint32_t sr;     // slow / g
+    int32_t  R;      // (fast / slow) as i32, the divisor of simple_fm.rs:421
+    uint32_t kt;     // audio samples per tile (kernel tiling, chosen by the host)
+};
+
+// Per-channel Demod state as it lives in HBM (32 bytes; simple_fm.rs:232-239).
+struct FmdChanState {
+    int32_t prev_index;
+    int32_t prev_lpr_index;
+    int32_t now_lpr;
+    int32_t lp_now_re, lp_now_im;
+    int32_t demod_pre_re, demod_pre_im;
+    int32_t reserved;
+};
+
+// Number of decimated samples: the decimator emits whenever prev_index reaches D (:343-349).
+FMD_HD uint32_t fmd_num_decimated(uint32_t D, uint32_t p0, uint32_t ns) { return (p0 + ns) / D; }
+FMD_HD uint32_t fmd_next_prev_index(uint32_t D, uint32_t p0, uint32_t ns) { return (p0 + ns) % D; }
+
+// Number of audio samples: prev_lpr_index gains `slow` per input and emits (subtracting `fast`)
+// whenever it reaches `fast` (:417-422); with slow <= fast at most one emit per input.
+FMD_HD uint64_t fmd_num_audio(const FmdRates& r, uint32_t i0, uint32_t M)
+{
+    return ((uint64_t)(i0 / r.g) + (uint64_t)M * r.sr) / r.fr;
+}
+FMD_HD uint32_t fmd_next_lpr_index(const FmdRates& r, uint32_t i0, uint32_t M, uint64_t K)
+{
+    return (uint32_t)(((uint64_t)(i0 / r.g) + (uint64_t)M * r.sr - K * r.fr) * r.g);
+}
+
+// e(k): smallest j with i0 + (j+1)*slow >= (k+1)*fast  <=>  j = floor(((k+1)*fast - i0 - 1) / slow).
+// In gcd-reduced units the same value is floor(((k+1)*fr - i0r - 1) / sr).
+FMD_HD uint64_t fmd_audio_end(const FmdRates& r, uint32_t i0, uint64_t k)
+{
+    return ((k + 1) * r.fr - (uint64_t)(i0 / r.g) - 1) / r.sr;
+}
+
+// First/last input sample (exclusive end) of decimated sample j >= 0, clipped to the call.
+FMD_HD int64_t fmd_win_begin(uint32_t D, uint32_t p0, int64_t j)
+{
+    int64_t n = (int64_t)D * j - (int64_t)p0;
+    return n < 0 ? 0 : n;
+}
+FMD_HD int64_t fmd_win_end(uint32_t D, uint32_t p0, int64_t j) { return (int64_t)D * (j + 1) - (int64_t)p0; }
+
+// Work decomposition of one channel-call into tiles of `kt` audio samples.
+struct FmdTile {
+    uint64_t k0, k1;   // audio samples [k0, k1) of this call
+    int64_t  jA;       // first discriminator sample summed by this tile
+    int64_t  jB;       // last discriminator sample handled (inclusive); jB < jA means none
+    int64_t  nLo, nHi; // input complex samples [nLo, nHi) the tile reads
+    uint64_t eq, er;   // (k0+1)*fr - i0r - 1 = eq*sr + er, so that e(k0+q) = eq + (er + q*fr)/sr
+    bool     last;     // also owns the tail (state update)
+};
+
+FMD_HD uint32_t fmd_num_tiles(const FmdRates& r, uint64_t K)
+{
+    uint64_t t = (K + r.kt - 1) / r.kt;
+    return t ? (uint32_t)t : 1u;
+}
+
+FMD_HD FmdTile fmd_tile(const FmdRates& r, uint32_t p0, uint32_t i0, uint32_t ns, uint32_t M, uint64_t K,
+                        uint32_t t)
+{
+    FmdTile T;
+    const uint32_t nt = fmd_num_tiles(r, K);
+    T.last = (t + 1 == nt);
+    T.k0 = (uint64_t)t * r.kt;
+    T.k1 = T.k0 + r.kt < K ? T.k0 + r.kt : K;
+    if (T.k1 < T.k0) T.k1 = T.k0;
+    const uint64_t a = (T.k0 + 1) * r.fr - (uint64_t)(i0 / r.g) - 1;
+    T.eq = a / r.sr;
+    T.er = a % r.sr;
+    // jA = e(k0 - 1) + 1 ;  e(k0-1) = floor((a - fr) / sr)
+    T.jA = T.k0 == 0 ? 0 : (int64_t)((a - r.fr) / r.sr) + 1;
+    if (T.last) T.jB = (int64_t)M - 1;
+    else        T.jB = (int64_t)(T.eq + (T.er + (uint64_t)(T.k1 - T.k0 - 1) * r.fr) / r.sr);
+    // decimated samples needed: jA-1 (predecessor) .. jB ; jA-1 == -1 is demod_pre (no input)
+    T.nLo = T.jA >= 1 ? fmd_win_begin(r.D, p0, T.jA - 1) : 0;
+    T.nHi = T.last ? (int64_t)ns : fmd_win_end(r.D, p0, T.jB);
+    if (T.nHi < T.nLo) T.nHi = T.nLo;
+    return T;
+}
+
+// Sum over samples n in [0, n) of the additive constants left after mapping bytes to
+// t = b - 128: rotate_90 (:284-296) + `as i16 - 127` (:258) give, for n mod 4 = 0..3,
+//   re = t0+1, -t3, -t4, t7+1      im = t1+1, t2+1, -t5, -t6
+FMD_HD int32_t fmd_const_re(int32_t n) { return 2 * (n >> 2) + ((n & 3) >= 1 ? 1 : 0); }
+FMD_HD int32_t fmd_const_im(int32_t n) { return 2 * (n >> 2) + ((n & 3) < 2 ? (n & 3) : 2); }
+
+// Demod::fast_atan2 (simple_fm.rs:383-405) on wrapping 32-bit integers.  The reference widens to
+// i64, multiplies by 4096 and truncates back to i32 BEFORE dividing: that is a 32-bit shift.
+FMD_HD int32_t fmd_fast_atan2(int32_t y, int32_t x)
+{
+    if (x == 0 && y == 0) return 0;
+    const uint32_t ux = (uint32_t)x;
+    const uint32_t uyabs = y < 0 ? 0u - (uint32_t)y : (uint32_t)y;
+    int32_t num, den, base;
+    if (x >= 0) { num = (int32_t)((ux - uyabs) << 12); den = (int32_t)(ux + uyabs); base = 1 << 12; }
+    else        { num = (int32_t)((ux + uyabs) << 12); den = (int32_t)(uyabs - ux); base = 3 << 12; }
+    const int32_t angle = (int32_t)((uint32_t)base - (uint32_t)(num / den));
+    return y < 0 ? (int32_t)(0u - (uint32_t)angle) : angle;
+}
+
+// a * conj(b) on Complex<i32> (num-complex 0.4), wrapping.
+FMD_HD void fmd_mul_conj(int32_t ar, int32_t ai, int32_t br, int32_t bi, int32_t& cr, int32_t& ci)
+{
+    cr = (int32_t)((uint32_t)ar * (uint32_t)br + (uint32_t)ai * (uint32_t)bi);
+    ci = (int32_t)((uint32_t)ai * (uint32_t)br - (uint32_t)ar * (uint32_t)bi);
+}
+
+#endif  // FMD_INDEX_H

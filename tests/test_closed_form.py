@@ -1,0 +1,76 @@
+"""The closed-form / tiled CPU model (oracle/closed_form.cpp, built on the product header
+rtl-sdr-rs_amd/csrc/fmd_index.h) must equal the pass-by-pass oracle for every phase, chunking
+and tile size.  This is the specification the HIP kernel implements."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import oracle_lib
+
+CONFIGS = [(6, 170000, 32000), (10, 240000, 32000), (7, 166666, 32000), (1, 48000, 48000),
+           (5, 250000, 44100), (8, 128000, 32000), (3, 340000, 48000), (128, 8000, 8000), (21, 50000, 32000)]
+
+
+def run_both(oracle, D, fast, slow, chunks, kt, seed):
+    rng = np.random.default_rng(seed)
+    cfg = oracle.config(D, fast, slow)
+    d = oracle.new(cfg)
+    st = oracle_lib.ChanState()
+    for n in chunks:
+        mode = int(rng.integers(0, 3))
+        if mode == 0:
+            buf = rng.integers(0, 256, n, dtype=np.uint8)
+        elif mode == 1:
+            buf = rng.integers(120, 136, n, dtype=np.uint8)
+        else:   # full-scale square-ish data: reaches the fast_atan2 wrap for larger D
+            buf = np.where(rng.integers(0, 2, n) > 0, 255, 0).astype(np.uint8)
+            buf = np.repeat(buf[:: 8 * D + 8], 8 * D + 8)[:n].astype(np.uint8)
+            buf = np.resize(buf, n)
+        exp = oracle.demodulate(d, buf)
+        got = oracle.closed_form(D, fast, slow, kt, st, buf)
+        assert np.array_equal(got, exp), (D, fast, slow, n, kt)
+        s = oracle.state_of(d)
+        assert (st.prev_index, st.prev_lpr_index, st.now_lpr) == (s["prev_index"], s["prev_lpr_index"], s["now_lpr"])
+        assert [st.lp_now_re, st.lp_now_im] == s["lp_now"]
+        assert [st.demod_pre_re, st.demod_pre_im] == s["demod_pre"]
+
+
+@pytest.mark.parametrize("D,fast,slow", CONFIGS)
+@pytest.mark.parametrize("kt", [1, 3, 16, 128])
+def test_closed_form_equals_oracle(oracle, D, fast, slow, kt):
+    rng = np.random.default_rng(D * 7 + kt)
+    chunks = [int(v) * 8 + 16 * D for v in rng.integers(1, 200, 6)]
+    run_both(oracle, D, fast, slow, chunks, kt, seed=D * 31 + kt)
+
+
+def test_closed_form_reference_block_size(oracle):
+    # DEFAULT_BUF_LENGTH (src/lib.rs:25) blocks at the reference config: phases 0/2/4 all occur
+    run_both(oracle, 6, 170000, 32000, [262144] * 4, 128, seed=1)
+    run_both(oracle, 10, 240000, 32000, [262144] * 3, 128, seed=2)
+
+
+def test_window_sum_matches_rotate_center(oracle):
+    rng = np.random.default_rng(3)
+    buf = rng.integers(0, 256, 256, dtype=np.uint8)
+    rot = buf.copy()
+    oracle.lib.fmo_rotate_90(rot.ctypes.data_as(C.POINTER(C.c_uint8)), rot.size)
+    s = rot.astype(np.int32) - 127
+    re, im = s[0::2], s[1::2]
+    for n0 in range(0, 20):
+        for n1 in range(n0, 60):
+            a, b = C.c_int32(), C.c_int32()
+            oracle.lib.fmcf_window_sum(buf.ctypes.data_as(C.POINTER(C.c_uint8)), n0, n1, C.byref(a), C.byref(b))
+            assert (a.value, b.value) == (int(re[n0:n1].sum()), int(im[n0:n1].sum()))
+
+
+def test_f64_sample_positions(oracle):
+    """SURVEY 8a decomposition fact: at cfg-ref the per-call f64 samples are m_b = 0, 21845, 43690, 65536 ..."""
+    D, N = 6, 262144
+    p0, mb, pos = 0, 0, []
+    for _ in range(5):
+        pos.append(mb)
+        M = (p0 + N // 2) // D
+        p0 = (p0 + N // 2) % D
+        mb += M
+    assert pos == [0, 21845, 43690, 65536, 87381]
