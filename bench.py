@@ -1,0 +1,173 @@
+#!/usr/bin/env python3
+"""bench.py -- IQ Msamples/s demodulated by the fused HIP path, with its HBM roofline and a CPU baseline.
+
+One "step" = one call of fmd_demod_demodulate_device over one batch of synthetic IQ already
+resident in HBM: BASELINE.json configs[2], 4096 FM channels x 262144 B (DEFAULT_BUF_LENGTH,
+src/lib.rs:25) at the 2.4 Msps configuration (downsample 10, 240 kHz -> 32 kHz), per GPU.
+Channels are independent, so N GPUs = N x 4096 channels with no data-path collective (weak scaling).
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+CHANNELS = 4096
+BLOCK = 16 * 16384
+D, FAST, SLOW = 10, 240000, 32000
+HBM_PEAK_GBS = 8000.0            # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+KERNEL = "fmd_demod_kernel"
+
+
+def cpu_baseline(fmd, torch, cfg, iq_dev, target_s=12.0):
+    """The oracle (oracle/fm_oracle.c, a C restatement of the reference passes: kind 'port') timed on this
+    box's host cores over a bounded sample of the same workload."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import numpy as np
+    import oracle_lib
+    o = oracle_lib.load()
+    cores = os.cpu_count() or 1
+    ocfg = o.config(cfg.downsample, cfg.rate_out, cfg.rate_resample)
+    chans = min(CHANNELS, cores * 4)
+    host = iq_dev[:chans].cpu().numpy()                       # [chans][BLOCK], one call each
+    u8p = C.POINTER(C.c_uint8)
+    chk = C.c_uint64()
+
+    def run(calls_data, calls):
+        return o.lib.fmo_bench_batch(C.byref(ocfg), calls_data.ctypes.data_as(u8p), chans, calls, BLOCK, cores,
+                                     C.byref(chk), None)
+    t = run(host, 1)
+    if t <= 0:
+        return None
+    calls = max(1, min(64, int(target_s / t)))
+    data = np.ascontiguousarray(np.tile(host[:, None, :], (1, calls, 1)).reshape(chans, calls * BLOCK))
+    t = run(data, calls)
+    samples = chans * calls * (BLOCK // 2)
+    return {"value": round(samples / t / 1e6, 2), "unit": "Msamples/s", "cores": cores, "kind": "port",
+            "sample": "%d channels x %d calls x %d B of the same synthetic workload, %d threads, %.1f s" % (
+                chans, calls, BLOCK, cores, t)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--channels", type=int, default=CHANNELS)
+    ap.add_argument("--nbuf", type=int, default=3, help="distinct input batches rotated through (defeats the 256 MiB L3)")
+    ap.add_argument("--kt", type=int, default=0, help="tiling override (audio samples per tile)")
+    ap.add_argument("--no-cpu", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import rtl_sdr_rs_amd as fmd
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    if fmd.device_count() < 1:
+        raise RuntimeError("bench.py: no gfx950 device; the product has no CPU path")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    cfg = fmd.DemodConfig(FAST, FAST, SLOW, D, max(1, (1 << 15) // (128 * D)))
+    nch = args.channels
+    lo, hi = fmd.shard.channel_range(nch * world, world, rank)          # this rank's global channel ids
+    bank = fmd.DemodBank(cfg, nch, device_id=local_rank)
+    if args.kt:
+        bank.set_tiling(args.kt)
+    cap = bank.out_cap(BLOCK)
+    stream = torch.cuda.current_stream().cuda_stream
+    bufs = []
+    for b in range(args.nbuf):
+        t = torch.empty((nch, BLOCK), dtype=torch.uint8, device=dev)
+        fmd.synth.fill_device(t.data_ptr(), nch, BLOCK, sample_offset=b * (BLOCK // 2), device_id=local_rank,
+                              stream=stream, seed=fmd.synth.DEFAULTS["seed"] + lo)
+        bufs.append(t)
+    out = torch.zeros((nch, cap), dtype=torch.int16, device=dev)
+
+    def step(i):
+        bank.demodulate_device(bufs[i % args.nbuf].data_ptr(), BLOCK, out.data_ptr(), cap, None, stream)
+
+    def fence():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        step(i)
+    fence()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    ev0.record()
+    for i in range(args.steps):
+        step(args.warmup + i)
+    ev1.record()
+    fence()
+    t1 = time.perf_counter()
+    elapsed = t1 - t0
+    if dist is not None:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    kern_ms_region = ev0.elapsed_time(ev1) / args.steps            # HIP events on the launch stream
+
+    # per-launch event pairs (outside the timed region): isolates the kernel from inter-launch gaps
+    pairs = []
+    for i in range(min(args.steps, 20)):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record(); step(i); b.record()
+        pairs.append((a, b))
+    torch.cuda.synchronize()
+    per_launch = sorted(a.elapsed_time(b) for a, b in pairs)
+    kern_ms_pair = per_launch[len(per_launch) // 2]
+
+    lens = bank.last_out_len()
+    samples_per_step = nch * (BLOCK // 2)
+    alg_bytes = nch * BLOCK + 2 * int(lens.sum())                 # u8 in once + s16 out (2.0267 B/sample)
+    achieved = alg_bytes / (kern_ms_region * 1e-3) / 1e9
+    value = world * samples_per_step * args.steps / elapsed / 1e6
+
+    if rank == 0:
+        res = {
+            "metric": "IQ Msamples/s demodulated", "value": round(value, 1), "unit": "Msamples/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "i32", "data": "synthetic",
+            "config": {"workload": "BASELINE configs[2]: %d FM channels x %d B/call @ 2.4 Msps per GPU "
+                                   "(downsample %d, %d Hz -> %d Hz), inputs resident in HBM, %d rotating batches"
+                                   % (nch, BLOCK, D, FAST, SLOW, args.nbuf),
+                       "channels_per_gpu": nch, "block_bytes": BLOCK, "downsample": D, "rate_out": FAST,
+                       "rate_resample": SLOW, "audio_per_call": int(lens[0]), "tiling": bank.tiling(),
+                       "parallelism": "channels sharded x%d, no collective" % world},
+            "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None, "kernel": KERNEL,
+                         "algorithmic_bytes_per_launch": alg_bytes,
+                         "kernel_ms_events_region": round(kern_ms_region, 4),
+                         "kernel_ms_events_per_launch_median": round(kern_ms_pair, 4)},
+        }
+        if world == 1 and not args.no_cpu:
+            try:
+                res["cpu_baseline"] = cpu_baseline(fmd, torch, cfg, bufs[0])
+            except Exception as e:              # the baseline is reported, never required for the GPU number
+                res["cpu_baseline"] = {"error": repr(e)}
+        print(json.dumps(res), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,164 @@
+/*
+ * fmd.h -- C ABI of the MI355X-native FM demodulation path (libfmd_hip.so).
+ *
+ * Drop-in boundary for ONE path of ccostes/rtl-sdr-rs v0.3.1: the `Demod` chain of
+ * examples/simple_fm.rs (u8 IQ -> rotate_90 -> centre -> boxcar decimate -> polar
+ * discriminator -> fractional boxcar resampler -> s16).  Every entry point cites the
+ * reference interface it replaces.  Plain pointers and sizes only; no C++/torch types.
+ *
+ * Threading: a handle is like the reference's `&mut Demod` -- one caller at a time.
+ * Use one handle per host thread / per GPU.  All functions return FMD_OK (0) or a negative
+ * fmd_status; nothing panics or aborts where the reference would.
+ *
+ * There is NO CPU fallback in this library: without a usable gfx950 device fmd_demod_new
+ * fails with FMD_ERR_NO_DEVICE / FMD_ERR_HIP.
+ */
+#ifndef FMD_H
+#define FMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FMD_VERSION_MAJOR 0
+#define FMD_VERSION_MINOR 1
+
+/* DEFAULT_BUF_LENGTH, src/lib.rs:25 -- the buffer size RtlSdr::read_sync callers use. */
+#define FMD_DEFAULT_BUF_LENGTH (16 * 16384)
+
+typedef enum fmd_status {
+    FMD_OK = 0,
+    FMD_ERR_INVALID_ARG   = -1,  /* NULL pointer, zero channels, ...                                */
+    FMD_ERR_BAD_LENGTH    = -2,  /* nbytes % 8 != 0 -- reference: index panic, simple_fm.rs:286     */
+    FMD_ERR_TOO_SHORT     = -3,  /* < 2 decimated samples -- reference: assert!, simple_fm.rs:356   */
+    FMD_ERR_BAD_RATES     = -4,  /* rate_out < rate_resample or 0 -- reference: div by zero, :421   */
+    FMD_ERR_CAPACITY      = -5,  /* out_cap smaller than the number of samples produced             */
+    FMD_ERR_UNSUPPORTED   = -6,  /* configuration outside this implementation's documented domain   */
+    FMD_ERR_BAD_STATE     = -7,  /* fmd_demod_set_state with a state no Demod can reach             */
+    FMD_ERR_NO_DEVICE     = -8,  /* no gfx950 device / bad device_id                                */
+    FMD_ERR_HIP           = -9,  /* a HIP runtime call failed; see fmd_last_error()                 */
+    FMD_ERR_NOMEM         = -10
+} fmd_status;
+
+/* struct RadioConfig, simple_fm.rs:173-176 */
+typedef struct fmd_radio_config {
+    uint32_t capture_freq;
+    uint32_t capture_rate;
+} fmd_radio_config;
+
+/* struct DemodConfig, simple_fm.rs:179-185 (same field order). */
+typedef struct fmd_demod_config {
+    uint32_t rate_in;        /* stored, unused in arithmetic (reference: :180, logged :139)       */
+    uint32_t rate_out;       /* "fast" rate of the audio resampler, :412                          */
+    uint32_t rate_resample;  /* "slow" rate of the audio resampler, :411                          */
+    uint32_t downsample;     /* boxcar length / decimation, :343                                  */
+    uint32_t output_scale;   /* computed, unused in arithmetic (reference: :184,197-200)          */
+} fmd_demod_config;
+
+/* The mutable fields of struct Demod, simple_fm.rs:232-239.  This is the resumable state. */
+typedef struct fmd_demod_state {
+    uint32_t prev_index;      /* boxcar phase, 0 .. downsample-1                                  */
+    int32_t  now_lpr;         /* partial audio sum                                                */
+    int32_t  prev_lpr_index;  /* resampler phase, 0 .. rate_out-1                                 */
+    int32_t  lp_now_re, lp_now_im;       /* partial boxcar sum                                    */
+    int32_t  demod_pre_re, demod_pre_im; /* last decimated sample of the previous call            */
+} fmd_demod_state;
+
+/* Placement of a Demod bank on the machine (no reference counterpart: the reference is
+ * one Demod on one CPU thread, simple_fm.rs:137). */
+typedef struct fmd_device_config {
+    uint32_t n_channels;  /* independent IQ streams (one reference `Demod` each); >= 1           */
+    int32_t  device_id;   /* HIP device ordinal; -1 = current device                             */
+    uint32_t flags;       /* reserved, 0                                                          */
+} fmd_device_config;
+
+typedef struct fmd_demod fmd_demod;   /* opaque; owns device buffers + per-channel state */
+
+/* ---- configuration ------------------------------------------------------------------- */
+
+/* optimal_settings(freq, rate), simple_fm.rs:189-214.  rate_resample is the reference's
+ * RATE_RESAMPLE const (:27, 32000).  FMD_ERR_BAD_RATES where the reference divides by zero. */
+int fmd_optimal_settings(uint32_t freq, uint32_t rate, uint32_t rate_resample,
+                         fmd_radio_config *radio, fmd_demod_config *demod);
+
+/* ---- lifecycle ------------------------------------------------------------------------ */
+
+/* Demod::new(config), simple_fm.rs:243-252, for a bank of n_channels independent streams,
+ * all with zeroed state. */
+int fmd_demod_new(const fmd_demod_config *config, const fmd_device_config *dev, fmd_demod **out);
+
+/* Drop for Demod. NULL is a no-op. */
+void fmd_demod_free(fmd_demod *d);
+
+/* Zero every channel's state (== dropping and re-creating the Demods). */
+int fmd_demod_reset(fmd_demod *d);
+
+/* ---- the hot path --------------------------------------------------------------------- */
+
+/* Demod::demodulate(&mut self, buf: Vec<u8>) -> Vec<i16>, simple_fm.rs:256-269, for a
+ * single-channel handle and HOST buffers: `iq` is exactly what RtlSdr::read_sync
+ * (src/lib.rs:153) filled -- interleaved offset-binary u8 I,Q,I,Q...  Writes *out_len
+ * samples to out (capacity out_cap samples; see fmd_out_cap).  The input is not modified. */
+int fmd_demod_demodulate(fmd_demod *d, const uint8_t *iq, size_t nbytes,
+                         int16_t *out, size_t out_cap, size_t *out_len);
+
+/* The same for every channel of the bank, HOST buffers:
+ *   iq      [n_channels][nbytes]   channel-major, contiguous
+ *   out     [n_channels][out_cap]
+ *   out_len [n_channels] */
+int fmd_demod_demodulate_batch(fmd_demod *d, const uint8_t *iq, size_t nbytes,
+                               int16_t *out, size_t out_cap, size_t *out_len);
+
+/* The same with DEVICE-resident buffers (the measured path): d_iq / d_out / d_out_len are
+ * device pointers on the handle's GPU with the layouts above (d_iq 16-byte aligned;
+ * d_out_len uint32, may be NULL).  Enqueues on `stream` (a hipStream_t; NULL = the
+ * default stream) and returns without synchronising; the per-channel counts are also
+ * available on the host, without a sync, from fmd_demod_last_out_len. */
+int fmd_demod_demodulate_device(fmd_demod *d, const void *d_iq, size_t nbytes,
+                                void *d_out, size_t out_cap, void *d_out_len, void *stream);
+
+/* Per-channel sample counts of the most recent demodulate_* call (host bookkeeping). */
+int fmd_demod_last_out_len(const fmd_demod *d, size_t *out_len /* [n_channels] */);
+
+/* Upper bound of samples one call can produce per channel for nbytes of input. */
+size_t fmd_out_cap(const fmd_demod_config *config, size_t nbytes);
+
+/* ---- state (checkpoint / resume; simple_fm.rs:232-239) -------------------------------- */
+int fmd_demod_get_state(fmd_demod *d, uint32_t channel, fmd_demod_state *state);
+int fmd_demod_set_state(fmd_demod *d, uint32_t channel, const fmd_demod_state *state);
+
+/* ---- synthetic IQ source (stands in for the absent capture.bin) -------- */
+
+typedef struct fmd_synth_params {
+    uint64_t seed;          /* channel c uses seed + c                                            */
+    uint32_t amplitude;     /* carrier amplitude in LSB, <= 120                                   */
+    uint32_t noise;         /* uniform noise in [-noise, +noise] LSB                              */
+    uint32_t dev_q32;       /* peak frequency deviation, cycles/sample in Q32                     */
+    uint32_t mod_period;    /* triangle modulation period in samples (even, >= 2)                 */
+} fmd_synth_params;
+
+/* Fill d_iq [n_channels][nbytes] (device pointer) with a deterministic integer-only FM
+ * signal sitting at -Fs/4 (what offset tuning, simple_fm.rs:194-195, delivers).
+ * rtl-sdr-rs_amd/synth.py generates identical bytes with numpy. */
+int fmd_synth_fill_device(int device_id, void *d_iq, uint32_t n_channels, size_t nbytes,
+                          uint64_t sample_offset, const fmd_synth_params *p, void *stream);
+
+/* ---- diagnostics ---------------------------------------------------------------------- */
+const char *fmd_strerror(int status);
+const char *fmd_last_error(void);          /* thread-local detail of the last failure          */
+int fmd_device_count(int *count);          /* gfx950 devices visible to HIP                    */
+int fmd_version(void);                     /* FMD_VERSION_MAJOR * 1000 + FMD_VERSION_MINOR     */
+/* Kernel tiling chosen for a configuration (for benchmarks / DESIGN.md bookkeeping). */
+int fmd_demod_tiling(const fmd_demod *d, uint32_t *audio_per_tile, uint32_t *lds_bytes,
+                     uint32_t *block_threads);
+/* Override the tiling (audio samples per workgroup tile; 0 = automatic).  Results never
+ * depend on it; it exists for tuning sweeps. */
+int fmd_demod_set_tiling(fmd_demod *d, uint32_t audio_per_tile);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FMD_H */

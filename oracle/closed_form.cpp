@@ -68,54 +68,59 @@ long fmcf_demodulate(uint32_t D, uint32_t fast, uint32_t slow, uint32_t kt, FmdC
     if (D == 0 || slow == 0 || fast < slow || kt == 0) return -4;
     FmdRates r;
     r.D = D; r.fast = fast; r.slow = slow;
-    uint32_t a = fast, b = slow;
-    while (b) { uint32_t t = a % b; a = b; b = t; }
-    r.g = a; r.fr = fast / a; r.sr = slow / a; r.R = (int32_t)(fast / slow); r.kt = kt;
+    r.g = fmd_gcd(fast, slow); r.fr = fast / r.g; r.sr = slow / r.g; r.R = (int32_t)(fast / slow); r.kt = kt;
+    if (!fmd_ranges_fit32(r, nbytes / 2)) return -6;
 
-    const uint32_t p0 = (uint32_t)st->prev_index, i0 = (uint32_t)st->prev_lpr_index;
+    const uint32_t p0 = st->prev_index, i0r = st->lpr_index_r;
     const uint32_t ns = (uint32_t)(nbytes / 2);
     const uint32_t M = fmd_num_decimated(D, p0, ns);
     if (M < 2) return -2;
-    const uint64_t K = fmd_num_audio(r, i0, M);
+    const uint32_t K = fmd_num_audio(r, i0r, M);
     if (K > out_cap) return -3;
     const uint32_t nt = fmd_num_tiles(r, K);
+    const uint32_t lp_cap = fmd_tile_lp_cap(r), raw_cap = fmd_tile_raw_cap(r);
     FmdChanState nst = *st;
 
     for (uint32_t t = 0; t < nt; t++) {
-        const FmdTile T = fmd_tile(r, p0, i0, ns, M, K, t);
-        const int64_t jfirst = T.jA - 1;
-        const int64_t cnt = T.jB - jfirst + 1;
-        std::vector<int32_t> lre(cnt > 0 ? cnt : 0), lim(cnt > 0 ? cnt : 0);
-        std::vector<int16_t> d(cnt > 0 ? cnt : 0);
-        for (int64_t i = 0; i < cnt; i++) {
-            const int64_t j = jfirst + i;
+        const FmdTile T = fmd_tile(r, p0, i0r, ns, M, K, nt, t);
+        const int32_t jfirst = T.jA - 1;
+        const int32_t cnt = T.jB - jfirst + 1;
+        if (cnt < 1 || (uint32_t)cnt > lp_cap) return -100;                       // LDS sizing bound
+        if ((uint32_t)(2 * (T.nHi - T.nLo) + 32) > raw_cap) return -101;
+        std::vector<int32_t> lre(cnt), lim(cnt);
+        std::vector<int16_t> d(cnt);
+        for (int32_t i = 0; i < cnt; i++) {
+            const int32_t j = jfirst + i;
             if (j < 0) { lre[i] = st->demod_pre_re; lim[i] = st->demod_pre_im; continue; }
-            window_sum(buf, fmd_win_begin(D, p0, j), fmd_win_end(D, p0, j), lre[i], lim[i]);
+            const int32_t n0 = fmd_win_begin(D, p0, j), n1 = fmd_win_end(D, p0, j);
+            if (n0 < T.nLo || n1 > T.nHi) return -102;                            // tile covers its windows
+            window_sum(buf, n0, n1, lre[i], lim[i]);
             if (j == 0) { lre[i] += st->lp_now_re; lim[i] += st->lp_now_im; }
         }
-        for (int64_t i = 1; i < cnt; i++) {
+        for (int32_t i = 1; i < cnt; i++) {
             int32_t cr, ci;
             fmd_mul_conj(lre[i], lim[i], lre[i - 1], lim[i - 1], cr, ci);
             const int32_t pcm = (jfirst + i == 0) ? polar_f64(cr, ci) : fmd_fast_atan2(ci, cr);
             d[i] = (int16_t)(uint16_t)(uint32_t)pcm;
         }
-        for (uint64_t k = T.k0; k < T.k1; k++) {
-            const uint64_t q = k - T.k0;
-            const int64_t e = (int64_t)(T.eq + (T.er + q * r.fr) / r.sr);
-            const int64_t s = q == 0 ? T.jA : (int64_t)(T.eq + (T.er + (q - 1) * r.fr) / r.sr) + 1;
+        for (uint32_t k = T.k0; k < T.k1; k++) {
+            const uint32_t q = k - T.k0;
+            const int32_t e = (int32_t)(T.eq + (T.er + q * r.fr) / r.sr);
+            const int32_t s = q == 0 ? T.jA : (int32_t)(T.eq + (T.er + (q - 1) * r.fr) / r.sr) + 1;
+            if (s < T.jA || e > T.jB) return -103;
             int32_t sum = k == 0 ? st->now_lpr : 0;
-            for (int64_t j = s; j <= e; j++) sum += d[j - jfirst];
+            for (int32_t j = s; j <= e; j++) sum += d[j - jfirst];
             out[k] = (int16_t)(uint16_t)(uint32_t)(sum / r.R);
         }
         if (T.last) {
-            const int64_t s = K == 0 ? 0 : (int64_t)fmd_audio_end(r, i0, K - 1) + 1;
+            const int32_t s = K == 0 ? 0 : (int32_t)fmd_audio_end(r, i0r, K - 1) + 1;
             int32_t sum = K == 0 ? st->now_lpr : 0;
-            for (int64_t j = s; j <= T.jB; j++) sum += d[j - jfirst];
+            for (int32_t j = s; j <= T.jB; j++) sum += d[j - jfirst];
             nst.now_lpr = sum;
-            nst.prev_lpr_index = (int32_t)fmd_next_lpr_index(r, i0, M, K);
-            nst.prev_index = (int32_t)fmd_next_prev_index(D, p0, ns);
+            nst.lpr_index_r = fmd_next_lpr_index_r(r, i0r, M, K);
+            nst.prev_index = fmd_next_prev_index(D, p0, ns);
             int32_t tr, ti;
-            window_sum(buf, fmd_win_begin(D, p0, M), (int64_t)ns, tr, ti);
+            window_sum(buf, fmd_win_begin(D, p0, (int32_t)M), (int32_t)ns, tr, ti);
             nst.lp_now_re = tr; nst.lp_now_im = ti;
             nst.demod_pre_re = lre[cnt - 1]; nst.demod_pre_im = lim[cnt - 1];
         }

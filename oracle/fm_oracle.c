@@ -338,3 +338,43 @@ double fmo_bench_batch(const fmo_demod_config *config, const uint8_t *iq, size_t
     if (err) return (double)err;
     return (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec);
 }
+
+/* ---- batch test helper ------------------------------------------------------------------ */
+typedef struct {
+    fmo_demod *demods; const uint8_t *iq; size_t c0, c1, len; int16_t *out; size_t out_cap;
+    uint32_t *out_len; int err;
+} batch_job;
+
+static void *batch_worker(void *arg)
+{
+    batch_job *j = (batch_job *)arg;
+    for (size_t c = j->c0; c < j->c1; c++) {
+        long n = fmo_demodulate(&j->demods[c], j->iq + c * j->len, j->len, j->out + c * j->out_cap, j->out_cap);
+        if (n < 0) { if (!j->err) j->err = (int)n; continue; }
+        j->out_len[c] = (uint32_t)n;
+    }
+    return NULL;
+}
+
+int fmo_demodulate_batch(fmo_demod *demods, const uint8_t *iq, size_t n_channels, size_t len,
+                         int16_t *out, size_t out_cap, uint32_t *out_len, int n_threads)
+{
+    if (n_threads < 1) n_threads = 1;
+    if ((size_t)n_threads > n_channels) n_threads = (int)(n_channels ? n_channels : 1);
+    pthread_t *th = (pthread_t *)calloc((size_t)n_threads, sizeof(pthread_t));
+    batch_job *jobs = (batch_job *)calloc((size_t)n_threads, sizeof(batch_job));
+    for (int t = 0; t < n_threads; t++) {
+        batch_job b = {demods, iq, n_channels * (size_t)t / (size_t)n_threads,
+                       n_channels * (size_t)(t + 1) / (size_t)n_threads, len, out, out_cap, out_len, 0};
+        jobs[t] = b;
+        if (n_threads == 1) batch_worker(&jobs[t]);
+        else pthread_create(&th[t], NULL, batch_worker, &jobs[t]);
+    }
+    int err = 0;
+    for (int t = 0; t < n_threads; t++) {
+        if (n_threads > 1) pthread_join(th[t], NULL);
+        if (jobs[t].err && !err) err = jobs[t].err;
+    }
+    free(th); free(jobs);
+    return err;
+}

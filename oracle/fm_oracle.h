@@ -118,6 +118,12 @@ double fmo_bench_batch(const fmo_demod_config *config, const uint8_t *iq, size_t
                        size_t calls, size_t block_len, int n_threads, uint64_t *checksum,
                        uint32_t *out_len);
 
+/* Test helper: demods[c].demodulate(iq[c]) for c in [0, n_channels), channel-major buffers
+ * iq[n_channels][len], out[n_channels][out_cap], out_len[n_channels], over n_threads pthreads.
+ * Returns 0 or the first negative fmo_demodulate code. */
+int fmo_demodulate_batch(fmo_demod *demods, const uint8_t *iq, size_t n_channels, size_t len,
+                         int16_t *out, size_t out_cap, uint32_t *out_len, int n_threads);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,464 @@
+// fmd_api.cpp -- the C ABI of include/fmd.h over the HIP kernels (compiled with hipcc).
+//
+// Host bookkeeping only: validation (the reference's panics become status codes), the
+// per-channel phase mirror that makes output counts known without a device round trip,
+// double-buffered per-channel Demod state in HBM, staging for the host-buffer entry points.
+// There is deliberately no CPU implementation of the path here.
+#include "../../include/fmd.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "fmd_index.h"
+#include "fmd_kernels.h"
+
+namespace {
+
+thread_local char g_err[512] = "";
+
+void set_err(const char* fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+#define HIP_TRY(expr)                                                                        \
+    do {                                                                                     \
+        hipError_t e_ = (expr);                                                              \
+        if (e_ != hipSuccess) {                                                              \
+            set_err("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+            return FMD_ERR_HIP;                                                              \
+        }                                                                                    \
+    } while (0)
+
+uint32_t env_u32(const char* name, uint32_t dflt)
+{
+    const char* s = getenv(name);
+    if (!s || !*s) return dflt;
+    return (uint32_t)strtoul(s, nullptr, 10);
+}
+
+}  // namespace
+
+struct fmd_demod {
+    fmd_demod_config cfg{};
+    FmdRates r{};
+    uint32_t C = 0;
+    int device = 0;
+    uint32_t lp_cap = 0, raw_cap = 0;
+    FmdChanState* d_state[2] = {nullptr, nullptr};
+    int cur = 0;
+    uint32_t* d_err = nullptr;
+    std::vector<uint32_t> p0, i0r;        // host mirror of the data-independent phases
+    std::vector<uint32_t> last_len;
+    hipStream_t stream = nullptr;         // used by the host-buffer entry points
+    uint8_t* d_iq = nullptr;  size_t d_iq_cap = 0;
+    int16_t* d_out = nullptr; size_t d_out_cap = 0;
+};
+
+namespace {
+
+int choose_tiling(fmd_demod* d, uint32_t kt_req)
+{
+    FmdRates& r = d->r;
+    uint32_t kt = kt_req;
+    if (kt == 0) {
+        // ~16 KiB of raw IQ per tile: bytes per audio sample = 2 * D * fast / slow
+        const double per = 2.0 * r.D * (double)r.fr / (double)r.sr;
+        double k = 16384.0 / per;
+        kt = k < 1.0 ? 1u : (k > 1024.0 ? 1024u : (uint32_t)k);
+    }
+    r.kt = kt;
+    d->lp_cap = fmd_tile_lp_cap(r);
+    d->raw_cap = fmd_tile_raw_cap(r);
+    const size_t lds = (size_t)d->raw_cap + 6u * (size_t)d->lp_cap + 16;
+    if (lds > 64 * 1024) {
+        set_err("tile needs %zu bytes of LDS (kt=%u): rate_out/rate_resample x downsample too large", lds, kt);
+        return FMD_ERR_UNSUPPORTED;
+    }
+    return FMD_OK;
+}
+
+int use_device(const fmd_demod* d)
+{
+    HIP_TRY(hipSetDevice(d->device));
+    return FMD_OK;
+}
+
+// Validates a call and fills per-channel M/K; returns max tiles per channel in *tiles.
+int plan_call(const fmd_demod* d, size_t nbytes, size_t out_cap, std::vector<uint32_t>& lens, uint32_t* tiles)
+{
+    if (nbytes % 8 != 0) { set_err("nbytes %% 8 != 0 (simple_fm.rs:286 would panic)"); return FMD_ERR_BAD_LENGTH; }
+    const uint64_t ns = nbytes / 2;
+    if (!fmd_ranges_fit32(d->r, ns)) {
+        set_err("call of %zu bytes exceeds the 32-bit index range for these rates", nbytes);
+        return FMD_ERR_UNSUPPORTED;
+    }
+    uint32_t tmax = 1;
+    lens.resize(d->C);
+    for (uint32_t c = 0; c < d->C; ++c) {
+        const uint32_t M = fmd_num_decimated(d->r.D, d->p0[c], (uint32_t)ns);
+        if (M < 2) { set_err("channel %u: %u decimated samples (simple_fm.rs:356 asserts > 1)", c, M); return FMD_ERR_TOO_SHORT; }
+        const uint32_t K = fmd_num_audio(d->r, d->i0r[c], M);
+        if (K > out_cap) { set_err("channel %u produces %u samples, out_cap %zu", c, K, out_cap); return FMD_ERR_CAPACITY; }
+        lens[c] = K;
+        const uint32_t nt = fmd_num_tiles(d->r, K);
+        if (nt > tmax) tmax = nt;
+    }
+    *tiles = tmax;
+    return FMD_OK;
+}
+
+void advance_mirror(fmd_demod* d, size_t nbytes, const std::vector<uint32_t>& lens)
+{
+    const uint32_t ns = (uint32_t)(nbytes / 2);
+    for (uint32_t c = 0; c < d->C; ++c) {
+        const uint32_t M = fmd_num_decimated(d->r.D, d->p0[c], ns);
+        d->i0r[c] = fmd_next_lpr_index_r(d->r, d->i0r[c], M, lens[c]);
+        d->p0[c] = fmd_next_prev_index(d->r.D, d->p0[c], ns);
+    }
+    d->last_len = lens;
+}
+
+int enqueue(fmd_demod* d, const void* d_iq, size_t nbytes, void* d_out, size_t out_cap, void* d_out_len,
+            hipStream_t stream)
+{
+    std::vector<uint32_t> lens;
+    uint32_t tiles = 1;
+    int rc = plan_call(d, nbytes, out_cap, lens, &tiles);
+    if (rc) return rc;
+    if (((uintptr_t)d_iq & 15u) != 0) { set_err("d_iq must be 16-byte aligned"); return FMD_ERR_INVALID_ARG; }
+    FmdLaunch L{};
+    L.iq = static_cast<const uint8_t*>(d_iq);
+    L.chan_stride = nbytes;
+    L.total_bytes = (uint64_t)nbytes * d->C;
+    L.r = d->r;
+    L.ns = (uint32_t)(nbytes / 2);
+    L.n_channels = d->C;
+    L.tiles = tiles;
+    L.lp_cap = d->lp_cap;
+    L.raw_cap = d->raw_cap;
+    L.st_in = d->d_state[d->cur];
+    L.st_out = d->d_state[d->cur ^ 1];
+    L.out = static_cast<int16_t*>(d_out);
+    L.out_stride = out_cap;
+    L.out_len = static_cast<uint32_t*>(d_out_len);
+    L.err = d->d_err;
+    HIP_TRY(fmd_launch_demod(L, stream));
+    d->cur ^= 1;
+    advance_mirror(d, nbytes, lens);
+    return FMD_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int fmd_version(void) { return FMD_VERSION_MAJOR * 1000 + FMD_VERSION_MINOR; }
+
+const char* fmd_last_error(void) { return g_err; }
+
+const char* fmd_strerror(int status)
+{
+    switch (status) {
+        case FMD_OK: return "ok";
+        case FMD_ERR_INVALID_ARG: return "invalid argument";
+        case FMD_ERR_BAD_LENGTH: return "buffer length is not a multiple of 8 bytes";
+        case FMD_ERR_TOO_SHORT: return "buffer yields fewer than two decimated samples";
+        case FMD_ERR_BAD_RATES: return "rate_out / rate_resample / downsample invalid";
+        case FMD_ERR_CAPACITY: return "output capacity too small";
+        case FMD_ERR_UNSUPPORTED: return "configuration outside the supported domain";
+        case FMD_ERR_BAD_STATE: return "state is not reachable by a Demod";
+        case FMD_ERR_NO_DEVICE: return "no usable gfx950 device";
+        case FMD_ERR_HIP: return "HIP runtime error";
+        case FMD_ERR_NOMEM: return "out of memory";
+        default: return "unknown status";
+    }
+}
+
+int fmd_device_count(int* count)
+{
+    if (!count) return FMD_ERR_INVALID_ARG;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) { *count = 0; set_err("hipGetDeviceCount: %s", hipGetErrorString(e)); return FMD_ERR_NO_DEVICE; }
+    int ok = 0;
+    for (int i = 0; i < n; ++i) {
+        hipDeviceProp_t p;
+        if (hipGetDeviceProperties(&p, i) == hipSuccess && strncmp(p.gcnArchName, "gfx950", 6) == 0) ++ok;
+    }
+    *count = ok;
+    return FMD_OK;
+}
+
+int fmd_optimal_settings(uint32_t freq, uint32_t rate, uint32_t rate_resample, fmd_radio_config* radio,
+                         fmd_demod_config* demod)
+{
+    if (rate == 0) { set_err("rate == 0 (simple_fm.rs:190 divides by it)"); return FMD_ERR_BAD_RATES; }
+    const uint32_t downsample = 1000000u / rate + 1;          // simple_fm.rs:190
+    const uint32_t capture_rate = downsample * rate;          // :192
+    const uint32_t capture_freq = freq + capture_rate / 4;    // :195
+    uint32_t output_scale = (1u << 15) / (128u * downsample); // :197
+    if (output_scale < 1) output_scale = 1;                   // :198-200
+    if (radio) { radio->capture_freq = capture_freq; radio->capture_rate = capture_rate; }
+    if (demod) {
+        demod->rate_in = rate; demod->rate_out = rate; demod->rate_resample = rate_resample;   // :207-209
+        demod->downsample = downsample; demod->output_scale = output_scale;                    // :210-211
+    }
+    return FMD_OK;
+}
+
+size_t fmd_out_cap(const fmd_demod_config* config, size_t nbytes)
+{
+    if (!config || config->downsample == 0 || config->rate_out == 0) return 0;
+    const uint64_t M = (nbytes / 2 + config->downsample - 1) / config->downsample + 1;
+    return (size_t)((M * config->rate_resample + config->rate_out - 1) / config->rate_out + 1);
+}
+
+int fmd_demod_new(const fmd_demod_config* config, const fmd_device_config* dev, fmd_demod** out)
+{
+    if (!config || !dev || !out) { set_err("null argument"); return FMD_ERR_INVALID_ARG; }
+    *out = nullptr;
+    if (dev->n_channels == 0) { set_err("n_channels == 0"); return FMD_ERR_INVALID_ARG; }
+    if (config->downsample == 0 || config->rate_resample == 0 || config->rate_out < config->rate_resample) {
+        set_err("need downsample >= 1 and rate_out >= rate_resample >= 1 (simple_fm.rs:421 divides by rate_out/rate_resample)");
+        return FMD_ERR_BAD_RATES;
+    }
+    if (config->downsample > FMD_MAX_DOWNSAMPLE) {
+        set_err("downsample %u > %u unsupported", config->downsample, FMD_MAX_DOWNSAMPLE);
+        return FMD_ERR_UNSUPPORTED;
+    }
+    fmd_demod* d = new (std::nothrow) fmd_demod();
+    if (!d) return FMD_ERR_NOMEM;
+    d->cfg = *config;
+    d->C = dev->n_channels;
+    FmdRates& r = d->r;
+    r.D = config->downsample; r.fast = config->rate_out; r.slow = config->rate_resample;
+    r.g = fmd_gcd(r.fast, r.slow); r.fr = r.fast / r.g; r.sr = r.slow / r.g;
+    r.R = (int32_t)(r.fast / r.slow);
+    if (r.fr > FMD_MAX_RATE_REDUCED) {
+        set_err("rate_out / gcd = %u > 2^24 unsupported", r.fr);
+        delete d; return FMD_ERR_UNSUPPORTED;
+    }
+    int rc = choose_tiling(d, env_u32("FMD_KT", 0));
+    if (rc) { delete d; return rc; }
+
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) {
+        set_err("no HIP device (this library has no CPU path)");
+        delete d; return FMD_ERR_NO_DEVICE;
+    }
+    int device = dev->device_id;
+    if (device < 0) { if (hipGetDevice(&device) != hipSuccess) device = 0; }
+    if (device >= ndev) { set_err("device_id %d out of range (%d devices)", device, ndev); delete d; return FMD_ERR_NO_DEVICE; }
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) != hipSuccess || strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+        set_err("device %d is not gfx950", device);
+        delete d; return FMD_ERR_NO_DEVICE;
+    }
+    d->device = device;
+    d->p0.assign(d->C, 0); d->i0r.assign(d->C, 0); d->last_len.assign(d->C, 0);
+
+    auto fail = [&](hipError_t e, const char* what) {
+        set_err("%s: %s", what, hipGetErrorString(e));
+        fmd_demod_free(d);
+        return FMD_ERR_HIP;
+    };
+    hipError_t e;
+    if ((e = hipSetDevice(device)) != hipSuccess) return fail(e, "hipSetDevice");
+    const size_t sbytes = sizeof(FmdChanState) * (size_t)d->C;
+    for (int i = 0; i < 2; ++i) {
+        if ((e = hipMalloc(&d->d_state[i], sbytes)) != hipSuccess) return fail(e, "hipMalloc(state)");
+        if ((e = hipMemset(d->d_state[i], 0, sbytes)) != hipSuccess) return fail(e, "hipMemset(state)");
+    }
+    if ((e = hipMalloc(&d->d_err, sizeof(uint32_t))) != hipSuccess) return fail(e, "hipMalloc(err)");
+    if ((e = hipMemset(d->d_err, 0, sizeof(uint32_t))) != hipSuccess) return fail(e, "hipMemset(err)");
+    if ((e = hipStreamCreateWithFlags(&d->stream, hipStreamNonBlocking)) != hipSuccess) return fail(e, "hipStreamCreate");
+    if ((e = hipDeviceSynchronize()) != hipSuccess) return fail(e, "hipDeviceSynchronize");
+    *out = d;
+    return FMD_OK;
+}
+
+void fmd_demod_free(fmd_demod* d)
+{
+    if (!d) return;
+    (void)hipSetDevice(d->device);
+    (void)hipDeviceSynchronize();
+    for (int i = 0; i < 2; ++i) if (d->d_state[i]) (void)hipFree(d->d_state[i]);
+    if (d->d_err) (void)hipFree(d->d_err);
+    if (d->d_iq) (void)hipFree(d->d_iq);
+    if (d->d_out) (void)hipFree(d->d_out);
+    if (d->stream) (void)hipStreamDestroy(d->stream);
+    delete d;
+}
+
+int fmd_demod_reset(fmd_demod* d)
+{
+    if (!d) return FMD_ERR_INVALID_ARG;
+    int rc = use_device(d);
+    if (rc) return rc;
+    HIP_TRY(hipDeviceSynchronize());
+    const size_t sbytes = sizeof(FmdChanState) * (size_t)d->C;
+    HIP_TRY(hipMemset(d->d_state[0], 0, sbytes));
+    HIP_TRY(hipMemset(d->d_state[1], 0, sbytes));
+    HIP_TRY(hipMemset(d->d_err, 0, sizeof(uint32_t)));
+    HIP_TRY(hipDeviceSynchronize());
+    d->cur = 0;
+    d->p0.assign(d->C, 0); d->i0r.assign(d->C, 0); d->last_len.assign(d->C, 0);
+    return FMD_OK;
+}
+
+int fmd_demod_demodulate_device(fmd_demod* d, const void* d_iq, size_t nbytes, void* d_out, size_t out_cap,
+                                void* d_out_len, void* stream)
+{
+    if (!d || !d_iq || !d_out) { set_err("null argument"); return FMD_ERR_INVALID_ARG; }
+    int rc = use_device(d);
+    if (rc) return rc;
+    return enqueue(d, d_iq, nbytes, d_out, out_cap, d_out_len, static_cast<hipStream_t>(stream));
+}
+
+int fmd_demod_demodulate_batch(fmd_demod* d, const uint8_t* iq, size_t nbytes, int16_t* out, size_t out_cap,
+                               size_t* out_len)
+{
+    if (!d || !iq || !out || !out_len) { set_err("null argument"); return FMD_ERR_INVALID_ARG; }
+    int rc = use_device(d);
+    if (rc) return rc;
+    {   // validate before touching the staging buffers
+        std::vector<uint32_t> lens; uint32_t tiles;
+        rc = plan_call(d, nbytes, out_cap, lens, &tiles);
+        if (rc) return rc;
+    }
+    const size_t in_bytes = nbytes * (size_t)d->C;
+    const size_t out_elems = out_cap * (size_t)d->C;
+    if (in_bytes > d->d_iq_cap) {
+        if (d->d_iq) { HIP_TRY(hipFree(d->d_iq)); d->d_iq = nullptr; d->d_iq_cap = 0; }
+        HIP_TRY(hipMalloc(&d->d_iq, in_bytes));
+        d->d_iq_cap = in_bytes;
+    }
+    if (out_elems > d->d_out_cap) {
+        if (d->d_out) { HIP_TRY(hipFree(d->d_out)); d->d_out = nullptr; d->d_out_cap = 0; }
+        HIP_TRY(hipMalloc(&d->d_out, (out_elems ? out_elems : 1) * sizeof(int16_t)));
+        d->d_out_cap = out_elems;
+    }
+    HIP_TRY(hipMemcpyAsync(d->d_iq, iq, in_bytes, hipMemcpyHostToDevice, d->stream));
+    rc = enqueue(d, d->d_iq, nbytes, d->d_out, out_cap, nullptr, d->stream);
+    if (rc) return rc;
+    uint32_t kmax = 0;
+    for (uint32_t c = 0; c < d->C; ++c) { out_len[c] = d->last_len[c]; if (d->last_len[c] > kmax) kmax = d->last_len[c]; }
+    if (kmax) {
+        HIP_TRY(hipMemcpy2DAsync(out, out_cap * sizeof(int16_t), d->d_out, out_cap * sizeof(int16_t),
+                                 (size_t)kmax * sizeof(int16_t), d->C, hipMemcpyDeviceToHost, d->stream));
+    }
+    uint32_t err = 0;
+    HIP_TRY(hipMemcpyAsync(&err, d->d_err, sizeof(err), hipMemcpyDeviceToHost, d->stream));
+    HIP_TRY(hipStreamSynchronize(d->stream));
+    if (err) { set_err("device-side sizing assertion failed (bits 0x%x)", err); return FMD_ERR_HIP; }
+    return FMD_OK;
+}
+
+int fmd_demod_demodulate(fmd_demod* d, const uint8_t* iq, size_t nbytes, int16_t* out, size_t out_cap,
+                         size_t* out_len)
+{
+    if (!d) { set_err("null argument"); return FMD_ERR_INVALID_ARG; }
+    if (d->C != 1) { set_err("fmd_demod_demodulate needs a 1-channel handle (this one has %u)", d->C); return FMD_ERR_INVALID_ARG; }
+    return fmd_demod_demodulate_batch(d, iq, nbytes, out, out_cap, out_len);
+}
+
+int fmd_demod_last_out_len(const fmd_demod* d, size_t* out_len)
+{
+    if (!d || !out_len) return FMD_ERR_INVALID_ARG;
+    for (uint32_t c = 0; c < d->C; ++c) out_len[c] = d->last_len[c];
+    return FMD_OK;
+}
+
+int fmd_demod_get_state(fmd_demod* d, uint32_t channel, fmd_demod_state* state)
+{
+    if (!d || !state || channel >= d->C) { set_err("bad argument"); return FMD_ERR_INVALID_ARG; }
+    int rc = use_device(d);
+    if (rc) return rc;
+    HIP_TRY(hipDeviceSynchronize());
+    FmdChanState s;
+    HIP_TRY(hipMemcpy(&s, d->d_state[d->cur] + channel, sizeof(s), hipMemcpyDeviceToHost));
+    uint32_t err = 0;
+    HIP_TRY(hipMemcpy(&err, d->d_err, sizeof(err), hipMemcpyDeviceToHost));
+    if (err) { set_err("device-side sizing assertion failed (bits 0x%x)", err); return FMD_ERR_HIP; }
+    state->prev_index = s.prev_index;
+    state->now_lpr = s.now_lpr;
+    state->prev_lpr_index = (int32_t)(s.lpr_index_r * d->r.g);
+    state->lp_now_re = s.lp_now_re; state->lp_now_im = s.lp_now_im;
+    state->demod_pre_re = s.demod_pre_re; state->demod_pre_im = s.demod_pre_im;
+    return FMD_OK;
+}
+
+int fmd_demod_set_state(fmd_demod* d, uint32_t channel, const fmd_demod_state* state)
+{
+    if (!d || !state || channel >= d->C) { set_err("bad argument"); return FMD_ERR_INVALID_ARG; }
+    const FmdRates& r = d->r;
+    const int64_t lim_lp = 128ll * state->prev_index, lim_pre = 128ll * r.D;
+    const int64_t lim_lpr = 16384ll * ((r.fr + r.sr - 1) / r.sr);
+    auto within = [](int64_t v, int64_t lim) { return v >= -lim && v <= lim; };
+    if (state->prev_index >= r.D || state->prev_lpr_index < 0 || (uint32_t)state->prev_lpr_index >= r.fast ||
+        (uint32_t)state->prev_lpr_index % r.g != 0 || !within(state->lp_now_re, lim_lp) ||
+        !within(state->lp_now_im, lim_lp) || !within(state->demod_pre_re, lim_pre) ||
+        !within(state->demod_pre_im, lim_pre) || !within(state->now_lpr, lim_lpr)) {
+        set_err("state not reachable from Demod::new by demodulate calls");
+        return FMD_ERR_BAD_STATE;
+    }
+    int rc = use_device(d);
+    if (rc) return rc;
+    HIP_TRY(hipDeviceSynchronize());
+    FmdChanState s{};
+    s.prev_index = state->prev_index;
+    s.lpr_index_r = (uint32_t)state->prev_lpr_index / r.g;
+    s.now_lpr = state->now_lpr;
+    s.lp_now_re = state->lp_now_re; s.lp_now_im = state->lp_now_im;
+    s.demod_pre_re = state->demod_pre_re; s.demod_pre_im = state->demod_pre_im;
+    HIP_TRY(hipMemcpy(d->d_state[d->cur] + channel, &s, sizeof(s), hipMemcpyHostToDevice));
+    d->p0[channel] = s.prev_index;
+    d->i0r[channel] = s.lpr_index_r;
+    return FMD_OK;
+}
+
+int fmd_demod_tiling(const fmd_demod* d, uint32_t* audio_per_tile, uint32_t* lds_bytes, uint32_t* block_threads)
+{
+    if (!d) return FMD_ERR_INVALID_ARG;
+    if (audio_per_tile) *audio_per_tile = d->r.kt;
+    if (lds_bytes) { FmdLaunch L{}; L.raw_cap = d->raw_cap; L.lp_cap = d->lp_cap; *lds_bytes = (uint32_t)fmd_demod_lds_bytes(L); }
+    if (block_threads) *block_threads = FMD_BLOCK_THREADS;
+    return FMD_OK;
+}
+
+int fmd_demod_set_tiling(fmd_demod* d, uint32_t audio_per_tile)
+{
+    if (!d) return FMD_ERR_INVALID_ARG;
+    const FmdRates saved = d->r; const uint32_t lc = d->lp_cap, rc_ = d->raw_cap;
+    int rc = choose_tiling(d, audio_per_tile);
+    if (rc) { d->r = saved; d->lp_cap = lc; d->raw_cap = rc_; }
+    return rc;
+}
+
+int fmd_synth_fill_device(int device_id, void* d_iq, uint32_t n_channels, size_t nbytes, uint64_t sample_offset,
+                          const fmd_synth_params* p, void* stream)
+{
+    if (!d_iq || !p || n_channels == 0) { set_err("null argument"); return FMD_ERR_INVALID_ARG; }
+    if (nbytes % 8 != 0) { set_err("nbytes %% 8 != 0"); return FMD_ERR_BAD_LENGTH; }
+    if (p->amplitude > 120 || p->noise > 64 || p->mod_period < 2) { set_err("synth parameters out of range"); return FMD_ERR_INVALID_ARG; }
+    if (device_id >= 0) HIP_TRY(hipSetDevice(device_id));
+    if (nbytes == 0) return FMD_OK;
+    FmdSynthLaunch S{};
+    S.iq = static_cast<uint8_t*>(d_iq);
+    S.chan_stride = nbytes; S.n_channels = n_channels; S.sample_offset = sample_offset;
+    S.seed = p->seed; S.amplitude = p->amplitude; S.noise = p->noise; S.dev_q32 = p->dev_q32; S.mod_period = p->mod_period;
+    HIP_TRY(fmd_launch_synth(S, static_cast<hipStream_t>(stream)));
+    return FMD_OK;
+}
+
+}  // extern "C"

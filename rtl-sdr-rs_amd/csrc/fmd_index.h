@@ -19,6 +19,9 @@
 //   lp[j]  j-th decimated sample of the call = (j == 0 ? lp_now : 0) + sum x[n], n in
 //          [max(0, D*j - p0), D*j - p0 + D)
 //   e(k)   index j of the discriminator sample that completes audio sample k
+//
+// All index arithmetic is unsigned 32-bit; fmd_ranges_fit32() is the host-side guard that
+// makes that exact (a call that fails it is rejected with FMD_ERR_UNSUPPORTED).
 #ifndef FMD_INDEX_H
 #define FMD_INDEX_H
 
@@ -29,6 +32,9 @@
 #else
 #define FMD_HD inline
 #endif
+
+#define FMD_MAX_DOWNSAMPLE 128u        /* |lp| <= 128*D <= 16384 fits i16; no i32 overflow in fm_demod */
+#define FMD_MAX_RATE_REDUCED (1u << 24)
 
 // Constants derived once per handle from DemodConfig (simple_fm.rs:179-185).
 struct FmdRates {
@@ -43,14 +49,21 @@ struct FmdRates {
 };
 
 // Per-channel Demod state as it lives in HBM (32 bytes; simple_fm.rs:232-239).
+// prev_lpr_index is stored divided by g.
 struct FmdChanState {
-    int32_t prev_index;
-    int32_t prev_lpr_index;
-    int32_t now_lpr;
-    int32_t lp_now_re, lp_now_im;
-    int32_t demod_pre_re, demod_pre_im;
-    int32_t reserved;
+    uint32_t prev_index;
+    uint32_t lpr_index_r;
+    int32_t  now_lpr;
+    int32_t  lp_now_re, lp_now_im;
+    int32_t  demod_pre_re, demod_pre_im;
+    int32_t  reserved;
 };
+
+FMD_HD uint32_t fmd_gcd(uint32_t a, uint32_t b)
+{
+    while (b) { uint32_t t = a % b; a = b; b = t; }
+    return a;
+}
 
 // Number of decimated samples: the decimator emits whenever prev_index reaches D (:343-349).
 FMD_HD uint32_t fmd_num_decimated(uint32_t D, uint32_t p0, uint32_t ns) { return (p0 + ns) / D; }
@@ -58,67 +71,85 @@ FMD_HD uint32_t fmd_next_prev_index(uint32_t D, uint32_t p0, uint32_t ns) { retu
 
 // Number of audio samples: prev_lpr_index gains `slow` per input and emits (subtracting `fast`)
 // whenever it reaches `fast` (:417-422); with slow <= fast at most one emit per input.
-FMD_HD uint64_t fmd_num_audio(const FmdRates& r, uint32_t i0, uint32_t M)
+FMD_HD uint32_t fmd_num_audio(const FmdRates& r, uint32_t i0r, uint32_t M) { return (i0r + M * r.sr) / r.fr; }
+FMD_HD uint32_t fmd_next_lpr_index_r(const FmdRates& r, uint32_t i0r, uint32_t M, uint32_t K)
 {
-    return ((uint64_t)(i0 / r.g) + (uint64_t)M * r.sr) / r.fr;
-}
-FMD_HD uint32_t fmd_next_lpr_index(const FmdRates& r, uint32_t i0, uint32_t M, uint64_t K)
-{
-    return (uint32_t)(((uint64_t)(i0 / r.g) + (uint64_t)M * r.sr - K * r.fr) * r.g);
+    return i0r + M * r.sr - K * r.fr;
 }
 
-// e(k): smallest j with i0 + (j+1)*slow >= (k+1)*fast  <=>  j = floor(((k+1)*fast - i0 - 1) / slow).
-// In gcd-reduced units the same value is floor(((k+1)*fr - i0r - 1) / sr).
-FMD_HD uint64_t fmd_audio_end(const FmdRates& r, uint32_t i0, uint64_t k)
+// Host guard for the 32-bit arithmetic above and in fmd_tile().
+inline bool fmd_ranges_fit32(const FmdRates& r, uint64_t ns)
 {
-    return ((k + 1) * r.fr - (uint64_t)(i0 / r.g) - 1) / r.sr;
+    if (ns > (1ull << 30)) return false;
+    const uint64_t Mmax = (r.D - 1 + ns) / r.D;
+    if (2ull * r.fr + Mmax * r.sr >= (1ull << 32)) return false;
+    if ((uint64_t)(r.kt + 2) * r.fr >= (1ull << 32)) return false;
+    return true;
+}
+
+// e(k): smallest j with i0 + (j+1)*slow >= (k+1)*fast  <=>  j = floor(((k+1)*fast - i0 - 1) / slow);
+// in gcd-reduced units the same value is floor(((k+1)*fr - i0r - 1) / sr).
+FMD_HD uint32_t fmd_audio_end(const FmdRates& r, uint32_t i0r, uint32_t k)
+{
+    return ((k + 1) * r.fr - i0r - 1) / r.sr;
 }
 
 // First/last input sample (exclusive end) of decimated sample j >= 0, clipped to the call.
-FMD_HD int64_t fmd_win_begin(uint32_t D, uint32_t p0, int64_t j)
+FMD_HD int32_t fmd_win_begin(uint32_t D, uint32_t p0, int32_t j)
 {
-    int64_t n = (int64_t)D * j - (int64_t)p0;
+    int32_t n = (int32_t)D * j - (int32_t)p0;
     return n < 0 ? 0 : n;
 }
-FMD_HD int64_t fmd_win_end(uint32_t D, uint32_t p0, int64_t j) { return (int64_t)D * (j + 1) - (int64_t)p0; }
+FMD_HD int32_t fmd_win_end(uint32_t D, uint32_t p0, int32_t j) { return (int32_t)D * (j + 1) - (int32_t)p0; }
 
 // Work decomposition of one channel-call into tiles of `kt` audio samples.
 struct FmdTile {
-    uint64_t k0, k1;   // audio samples [k0, k1) of this call
-    int64_t  jA;       // first discriminator sample summed by this tile
-    int64_t  jB;       // last discriminator sample handled (inclusive); jB < jA means none
-    int64_t  nLo, nHi; // input complex samples [nLo, nHi) the tile reads
-    uint64_t eq, er;   // (k0+1)*fr - i0r - 1 = eq*sr + er, so that e(k0+q) = eq + (er + q*fr)/sr
+    uint32_t k0, k1;   // audio samples [k0, k1) of this call
+    int32_t  jA;       // first discriminator sample summed by this tile
+    int32_t  jB;       // last discriminator sample handled (inclusive); the tile needs lp[jA-1 .. jB]
+    int32_t  nLo, nHi; // input complex samples [nLo, nHi) the tile reads
+    uint32_t eq, er;   // (k0+1)*fr - i0r - 1 = eq*sr + er, so that e(k0+q) = eq + (er + q*fr)/sr
     bool     last;     // also owns the tail (state update)
 };
 
-FMD_HD uint32_t fmd_num_tiles(const FmdRates& r, uint64_t K)
+FMD_HD uint32_t fmd_num_tiles(const FmdRates& r, uint32_t K)
 {
-    uint64_t t = (K + r.kt - 1) / r.kt;
-    return t ? (uint32_t)t : 1u;
+    uint32_t t = (K + r.kt - 1) / r.kt;
+    return t ? t : 1u;
 }
 
-FMD_HD FmdTile fmd_tile(const FmdRates& r, uint32_t p0, uint32_t i0, uint32_t ns, uint32_t M, uint64_t K,
-                        uint32_t t)
+FMD_HD FmdTile fmd_tile(const FmdRates& r, uint32_t p0, uint32_t i0r, uint32_t ns, uint32_t M, uint32_t K,
+                        uint32_t nt, uint32_t t)
 {
     FmdTile T;
-    const uint32_t nt = fmd_num_tiles(r, K);
     T.last = (t + 1 == nt);
-    T.k0 = (uint64_t)t * r.kt;
+    T.k0 = t * r.kt;
     T.k1 = T.k0 + r.kt < K ? T.k0 + r.kt : K;
     if (T.k1 < T.k0) T.k1 = T.k0;
-    const uint64_t a = (T.k0 + 1) * r.fr - (uint64_t)(i0 / r.g) - 1;
+    const uint32_t a = (T.k0 + 1) * r.fr - i0r - 1;
     T.eq = a / r.sr;
-    T.er = a % r.sr;
+    T.er = a - T.eq * r.sr;
     // jA = e(k0 - 1) + 1 ;  e(k0-1) = floor((a - fr) / sr)
-    T.jA = T.k0 == 0 ? 0 : (int64_t)((a - r.fr) / r.sr) + 1;
-    if (T.last) T.jB = (int64_t)M - 1;
-    else        T.jB = (int64_t)(T.eq + (T.er + (uint64_t)(T.k1 - T.k0 - 1) * r.fr) / r.sr);
+    T.jA = T.k0 == 0 ? 0 : (int32_t)((a - r.fr) / r.sr) + 1;
+    if (T.last) T.jB = (int32_t)M - 1;
+    else        T.jB = (int32_t)(T.eq + (T.er + (T.k1 - T.k0 - 1) * r.fr) / r.sr);
     // decimated samples needed: jA-1 (predecessor) .. jB ; jA-1 == -1 is demod_pre (no input)
     T.nLo = T.jA >= 1 ? fmd_win_begin(r.D, p0, T.jA - 1) : 0;
-    T.nHi = T.last ? (int64_t)ns : fmd_win_end(r.D, p0, T.jB);
+    T.nHi = T.last ? (int32_t)ns : fmd_win_end(r.D, p0, T.jB);
     if (T.nHi < T.nLo) T.nHi = T.nLo;
     return T;
+}
+
+// Upper bounds used to size LDS: decimated samples and input bytes one tile can touch.
+inline uint32_t fmd_tile_lp_cap(const FmdRates& r)
+{
+    const uint64_t per = ((uint64_t)r.kt * r.fr + r.sr - 1) / r.sr;
+    const uint64_t one = ((uint64_t)r.fr + r.sr - 1) / r.sr;
+    return (uint32_t)(per + one + 3);
+}
+inline uint32_t fmd_tile_raw_cap(const FmdRates& r)
+{
+    return ((fmd_tile_lp_cap(r) + 1) * 2 * r.D + 32 + 15) & ~15u;
 }
 
 // Sum over samples n in [0, n) of the additive constants left after mapping bytes to
@@ -126,6 +157,13 @@ FMD_HD FmdTile fmd_tile(const FmdRates& r, uint32_t p0, uint32_t i0, uint32_t ns
 //   re = t0+1, -t3, -t4, t7+1      im = t1+1, t2+1, -t5, -t6
 FMD_HD int32_t fmd_const_re(int32_t n) { return 2 * (n >> 2) + ((n & 3) >= 1 ? 1 : 0); }
 FMD_HD int32_t fmd_const_im(int32_t n) { return 2 * (n >> 2) + ((n & 3) < 2 ? (n & 3) : 2); }
+
+// Byte weights (as 4 packed signed bytes, little-endian) of one aligned dword = two complex samples;
+// `odd` is the parity of the dword index within the call (rotate_90 has period 8 bytes).
+#define FMD_W_RE_EVEN 0xFF000001u   /* +b0 ........ -b3 */
+#define FMD_W_IM_EVEN 0x00010100u   /* ... +b1 +b2 .... */
+#define FMD_W_RE_ODD  0x010000FFu   /* -b4 ........ +b7 */
+#define FMD_W_IM_ODD  0x00FFFF00u   /* ... -b5 -b6 .... */
 
 // Demod::fast_atan2 (simple_fm.rs:383-405) on wrapping 32-bit integers.  The reference widens to
 // i64, multiplies by 4096 and truncates back to i32 BEFORE dividing: that is a 32-bit shift.

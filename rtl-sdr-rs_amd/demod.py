@@ -1,0 +1,101 @@
+"""Host-side mirror of the reference's Demod interface (examples/simple_fm.rs:172-269)."""
+import ctypes as C
+
+import numpy as np
+
+from . import _ffi
+from ._ffi import DemodConfig, DemodState, DeviceConfig, RadioConfig, check, lib
+
+
+def device_count():
+    n = C.c_int(0)
+    rc = lib().fmd_device_count(C.byref(n))
+    return n.value if rc == 0 else 0
+
+
+def optimal_settings(freq, rate, rate_resample=32000):
+    """optimal_settings(freq, rate) -> (RadioConfig, DemodConfig), simple_fm.rs:189-214."""
+    r, d = RadioConfig(), DemodConfig()
+    check(lib().fmd_optimal_settings(freq, rate, rate_resample, C.byref(r), C.byref(d)))
+    return r, d
+
+
+def out_cap(config, nbytes):
+    return int(lib().fmd_out_cap(C.byref(config), nbytes))
+
+
+class DemodBank:
+    """n_channels independent reference `Demod`s living on one MI355X."""
+
+    def __init__(self, config, n_channels=1, device_id=-1):
+        self.config = config
+        self.n_channels = int(n_channels)
+        self._h = C.c_void_p()
+        dev = DeviceConfig(self.n_channels, device_id, 0)
+        check(lib().fmd_demod_new(C.byref(config), C.byref(dev), C.byref(self._h)))
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h:
+            lib().fmd_demod_free(self._h)
+            self._h = C.c_void_p()
+
+    __del__ = close
+
+    def reset(self):
+        check(lib().fmd_demod_reset(self._h))
+
+    def out_cap(self, nbytes):
+        return out_cap(self.config, nbytes)
+
+    def demodulate_batch(self, iq):
+        """iq: uint8 array [n_channels, nbytes] on the host -> list of int16 arrays."""
+        iq = np.ascontiguousarray(iq, dtype=np.uint8)
+        if iq.ndim != 2 or iq.shape[0] != self.n_channels:
+            raise ValueError("iq must be [n_channels, nbytes]")
+        nbytes = iq.shape[1]
+        cap = max(1, self.out_cap(nbytes))
+        out = np.empty((self.n_channels, cap), dtype=np.int16)
+        lens = (C.c_size_t * self.n_channels)()
+        check(lib().fmd_demod_demodulate_batch(self._h, iq.ctypes.data, nbytes, out.ctypes.data, cap, lens))
+        return [out[c, :lens[c]].copy() for c in range(self.n_channels)]
+
+    def demodulate_device(self, d_iq, nbytes, d_out, out_cap_, d_out_len=None, stream=None):
+        """Enqueue on device pointers (ints).  Returns immediately."""
+        check(lib().fmd_demod_demodulate_device(self._h, d_iq, nbytes, d_out, out_cap_, d_out_len, stream))
+
+    def last_out_len(self):
+        lens = (C.c_size_t * self.n_channels)()
+        check(lib().fmd_demod_last_out_len(self._h, lens))
+        return np.array(lens[:], dtype=np.int64)
+
+    def get_state(self, channel=0):
+        s = DemodState()
+        check(lib().fmd_demod_get_state(self._h, channel, C.byref(s)))
+        return s
+
+    def set_state(self, channel, state):
+        check(lib().fmd_demod_set_state(self._h, channel, C.byref(state)))
+
+    def tiling(self):
+        a, b, c = C.c_uint32(), C.c_uint32(), C.c_uint32()
+        check(lib().fmd_demod_tiling(self._h, C.byref(a), C.byref(b), C.byref(c)))
+        return {"audio_per_tile": a.value, "lds_bytes": b.value, "block_threads": c.value}
+
+    def set_tiling(self, audio_per_tile):
+        check(lib().fmd_demod_set_tiling(self._h, audio_per_tile))
+
+
+class Demod(DemodBank):
+    """struct Demod (simple_fm.rs:232-269): one stream.  demodulate(buf) -> int16 array."""
+
+    def __init__(self, config, device_id=-1):
+        super().__init__(config, 1, device_id)
+
+    def demodulate(self, buf):
+        buf = np.ascontiguousarray(np.frombuffer(buf, dtype=np.uint8) if isinstance(buf, (bytes, bytearray)) else buf,
+                                   dtype=np.uint8).reshape(-1)
+        cap = max(1, self.out_cap(buf.size))
+        out = np.empty(cap, dtype=np.int16)
+        n = C.c_size_t(0)
+        check(lib().fmd_demod_demodulate(self._h, buf.ctypes.data, buf.size, out.ctypes.data, cap, C.byref(n)))
+        return out[:n.value].copy()

@@ -30,7 +30,7 @@ class Demod(C.Structure):
 
 class ChanState(C.Structure):
     """FmdChanState of rtl-sdr-rs_amd/csrc/fmd_index.h (closed-form model)."""
-    _fields_ = [("prev_index", C.c_int32), ("prev_lpr_index", C.c_int32), ("now_lpr", C.c_int32),
+    _fields_ = [("prev_index", C.c_uint32), ("lpr_index_r", C.c_uint32), ("now_lpr", C.c_int32),
                 ("lp_now_re", C.c_int32), ("lp_now_im", C.c_int32),
                 ("demod_pre_re", C.c_int32), ("demod_pre_im", C.c_int32), ("reserved", C.c_int32)]
 
@@ -78,6 +78,9 @@ class Oracle:
         lib.fmo_bench_batch.argtypes = [C.POINTER(DemodConfig), u8p, C.c_size_t, C.c_size_t, C.c_size_t,
                                         C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_uint32)]
         lib.fmo_bench_batch.restype = C.c_double
+        lib.fmo_demodulate_batch.argtypes = [C.POINTER(Demod), u8p, C.c_size_t, C.c_size_t, i16p, C.c_size_t,
+                                             C.POINTER(C.c_uint32), C.c_int]
+        lib.fmo_demodulate_batch.restype = C.c_int
         lib.fmcf_demodulate.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(ChanState),
                                         u8p, C.c_size_t, i16p, C.c_size_t]
         lib.fmcf_demodulate.restype = C.c_long
@@ -119,6 +122,28 @@ class Oracle:
         outs = [self.demodulate(d, data[o:o + block_len])
                 for o in range(0, data.size - block_len + 1, block_len)]
         return (np.concatenate(outs) if outs else np.empty(0, np.int16)), d
+
+    def new_bank(self, cfg, n):
+        bank = (Demod * n)()
+        for i in range(n):
+            self.lib.fmo_demod_new(C.byref(bank[i]), C.byref(cfg))
+        return bank
+
+    def demodulate_batch(self, bank, iq, threads=0):
+        """iq [C, N] uint8 -> list of int16 arrays; bank is a (Demod * C) array (state carried)."""
+        import os
+        iq = np.ascontiguousarray(iq, dtype=np.uint8)
+        nch, n = iq.shape
+        cap = n // 2 // max(1, bank[0].config.downsample) + 16
+        out = np.empty((nch, cap), dtype=np.int16)
+        lens = np.zeros(nch, dtype=np.uint32)
+        rc = self.lib.fmo_demodulate_batch(bank, iq.ctypes.data_as(C.POINTER(C.c_uint8)), nch, n,
+                                           out.ctypes.data_as(C.POINTER(C.c_int16)), cap,
+                                           lens.ctypes.data_as(C.POINTER(C.c_uint32)),
+                                           threads or (os.cpu_count() or 1))
+        if rc:
+            raise ValueError("fmo_demodulate_batch -> %d" % rc)
+        return out, lens
 
     @staticmethod
     def state_of(d):

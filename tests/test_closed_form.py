@@ -6,6 +6,8 @@ import ctypes as C
 import numpy as np
 import pytest
 
+import math
+
 import oracle_lib
 
 CONFIGS = [(6, 170000, 32000), (10, 240000, 32000), (7, 166666, 32000), (1, 48000, 48000),
@@ -31,7 +33,8 @@ def run_both(oracle, D, fast, slow, chunks, kt, seed):
         got = oracle.closed_form(D, fast, slow, kt, st, buf)
         assert np.array_equal(got, exp), (D, fast, slow, n, kt)
         s = oracle.state_of(d)
-        assert (st.prev_index, st.prev_lpr_index, st.now_lpr) == (s["prev_index"], s["prev_lpr_index"], s["now_lpr"])
+        assert (st.prev_index, st.lpr_index_r * math.gcd(fast, slow), st.now_lpr) == \
+            (s["prev_index"], s["prev_lpr_index"], s["now_lpr"])
         assert [st.lp_now_re, st.lp_now_im] == s["lp_now"]
         assert [st.demod_pre_re, st.demod_pre_im] == s["demod_pre"]
 

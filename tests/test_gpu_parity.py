@@ -1,0 +1,286 @@
+"""GPU parity: the HIP path, called through the C ABI (include/fmd.h), against the CPU oracle.
+
+Bar: bit-exact s16 output and bit-exact Demod state (integer path).  The one f64 atan2 sample
+per call (simple_fm.rs:359,370-374) is compared exactly too; see test_f64_sample_* for how
+that is pinned.  Nothing here reads /root/reference.
+"""
+import ctypes as C
+import math
+import os
+
+import numpy as np
+import pytest
+
+import oracle_lib
+
+pytestmark = pytest.mark.gpu
+
+CFG_REF = (6, 170000, 32000)      # optimal_settings(94.9 MHz, 170 kHz): simple_fm.rs:25-27,48
+CFG_24 = (10, 240000, 32000)      # 2.4 Msps synthetic configuration (BASELINE.json configs[1..2])
+
+
+def mkcfg(fmd, D, fast, slow):
+    return fmd.DemodConfig(fast, fast, slow, D, max(1, (1 << 15) // (128 * D)))
+
+
+def gpu_state(bank, ch=0):
+    return bank.get_state(ch).as_dict()
+
+
+def check_stream(fmd, oracle, D, fast, slow, blocks, n_channels=1, kt=None):
+    """Feed the same blocks to GPU bank and oracle Demods; compare audio + state after every call."""
+    cfg = mkcfg(fmd, D, fast, slow)
+    bank = fmd.DemodBank(cfg, n_channels)
+    if kt is not None:
+        bank.set_tiling(kt)
+    ocfg = oracle.config(D, fast, slow)
+    obank = oracle.new_bank(ocfg, n_channels)
+    for iq in blocks:
+        got = bank.demodulate_batch(iq)
+        exp, lens = oracle.demodulate_batch(obank, iq)
+        for c in range(n_channels):
+            assert got[c].size == lens[c], (c, got[c].size, lens[c])
+            if not np.array_equal(got[c], exp[c, :lens[c]]):
+                bad = np.nonzero(got[c] != exp[c, :lens[c]])[0]
+                raise AssertionError("channel %d: %d mismatches, first at %d: gpu %d oracle %d" % (
+                    c, bad.size, bad[0], got[c][bad[0]], exp[c, bad[0]]))
+        for c in sorted(set([0, n_channels - 1, n_channels // 2])):
+            assert gpu_state(bank, c) == oracle.state_of(obank[c]), c
+    bank.close()
+
+
+def test_library_and_device(fmd):
+    assert fmd.device_count() >= 1, "no gfx950 device: the product has no CPU path"
+    assert fmd.lib().fmd_version() >= 1
+
+
+def test_synth_gpu_equals_numpy(fmd):
+    import torch
+    for (nch, nbytes, off) in [(3, 4096, 0), (70, 8 * 131, 12345678901)]:
+        buf = torch.empty((nch, nbytes), dtype=torch.uint8, device="cuda")
+        fmd.synth.fill_device(buf.data_ptr(), nch, nbytes, sample_offset=off)
+        torch.cuda.synchronize()
+        assert np.array_equal(buf.cpu().numpy(), fmd.synth.synth_iq(nch, nbytes, sample_offset=off))
+
+
+def test_config1_reference_block_stream(fmd, oracle):
+    """cfg-ref, 1 channel, 8 x DEFAULT_BUF_LENGTH blocks of the synthetic capture:
+    boxcar phases 0/2/4, seven f64 call boundaries, a full-scale segment that wraps fast_atan2."""
+    N = fmd.DEFAULT_BUF_LENGTH
+    data = fmd.synth.synth_iq(1, 8 * N, seed=0x05D50001, amplitude=120)[0].copy()
+    rng = np.random.default_rng(1)
+    data[3 * N: 3 * N + 65536] = rng.integers(0, 256, 65536, dtype=np.uint8)           # full 0..255 coverage
+    data[5 * N: 5 * N + 32768] = np.tile(np.array([255, 255, 0, 255, 0, 0, 255, 0], np.uint8), 4096)  # full scale DC
+    check_stream(fmd, oracle, *CFG_REF, [data[i * N:(i + 1) * N][None, :] for i in range(8)])
+
+
+def test_config2_one_channel_2p4msps(fmd, oracle):
+    N = fmd.DEFAULT_BUF_LENGTH
+    data = fmd.synth.synth_iq(1, 4 * N)[0]
+    check_stream(fmd, oracle, *CFG_24, [data[i * N:(i + 1) * N][None, :] for i in range(4)])
+
+
+def test_demod_single_stream_api(fmd, oracle):
+    """Demod::new + demodulate through the single-stream entry point."""
+    cfg = mkcfg(fmd, *CFG_REF)
+    d = fmd.Demod(cfg)
+    od = oracle.new(oracle.config(*CFG_REF))
+    rng = np.random.default_rng(3)
+    for _ in range(3):
+        buf = rng.integers(0, 256, 8192, dtype=np.uint8)
+        assert np.array_equal(d.demodulate(buf), oracle.demodulate(od, buf))
+    assert gpu_state(d) == oracle.state_of(od)
+
+
+@pytest.mark.parametrize("D,fast,slow", [CFG_REF, CFG_24, (7, 166666, 32000), (1, 48000, 48000), (5, 250000, 44100),
+                                         (8, 128000, 32000), (3, 340000, 48000), (128, 8000, 8000), (21, 50000, 32000),
+                                         (2, 1000000, 8000)])
+def test_configs_batched_random(fmd, oracle, D, fast, slow):
+    rng = np.random.default_rng(D * 13 + 1)
+    nch = 9
+    blocks = []
+    for i in range(4):
+        n = int(rng.integers(2, 400)) * 8 + 16 * D
+        if i % 2:
+            blk = rng.integers(0, 256, (nch, n), dtype=np.uint8)
+        else:
+            blk = np.where(rng.integers(0, 2, (nch, n)) > 0, 255, 0).astype(np.uint8)   # full scale
+        blocks.append(blk)
+    check_stream(fmd, oracle, D, fast, slow, blocks, n_channels=nch)
+
+
+@pytest.mark.parametrize("kt", [1, 2, 7, 64, 300])
+def test_tiling_invariance(fmd, oracle, kt):
+    rng = np.random.default_rng(kt)
+    blocks = [rng.integers(0, 256, (5, 40000), dtype=np.uint8) for _ in range(2)]
+    check_stream(fmd, oracle, *CFG_24, blocks, n_channels=5, kt=kt)
+    check_stream(fmd, oracle, *CFG_REF, blocks, n_channels=5, kt=kt)
+
+
+def test_ragged_and_tiny_calls(fmd, oracle):
+    """Smallest legal calls (2 decimated samples), calls producing no audio, odd 8-byte multiples."""
+    rng = np.random.default_rng(9)
+    for D, fast, slow in [CFG_REF, CFG_24, (7, 166666, 32000)]:
+        sizes = [4 * D + 8 - (4 * D) % 8, 8 * D, 24 * D + 8, 8, 8 * D * 3, 4096 + 8]
+        sizes = [s for s in sizes if s % 8 == 0]
+        cfg = mkcfg(fmd, D, fast, slow)
+        bank = fmd.DemodBank(cfg, 2)
+        obank = oracle.new_bank(oracle.config(D, fast, slow), 2)
+        for n in sizes:
+            iq = rng.integers(0, 256, (2, n), dtype=np.uint8)
+            M = (int(obank[0].prev_index) + n // 2) // D
+            if M < 2:
+                with pytest.raises(fmd.FmdError) as ei:
+                    bank.demodulate_batch(iq)
+                assert ei.value.status == -3
+                continue
+            got = bank.demodulate_batch(iq)
+            exp, lens = oracle.demodulate_batch(obank, iq)
+            for c in range(2):
+                assert np.array_equal(got[c], exp[c, :lens[c]])
+            assert gpu_state(bank, 1) == oracle.state_of(obank[1])
+
+
+def test_error_behaviour(fmd):
+    cfg = mkcfg(fmd, *CFG_REF)
+    d = fmd.Demod(cfg)
+    with pytest.raises(fmd.FmdError) as ei:
+        d.demodulate(np.zeros(12, np.uint8))            # reference: index panic (simple_fm.rs:286)
+    assert ei.value.status == -2
+    with pytest.raises(fmd.FmdError) as ei:
+        d.demodulate(np.zeros(16, np.uint8))            # reference: assert (simple_fm.rs:356)
+    assert ei.value.status == -3
+    assert d.get_state().as_dict()["prev_index"] == 0    # failed calls leave the state untouched
+    out = np.empty(1, np.int16)
+    n = C.c_size_t()
+    buf = np.zeros(8192, np.uint8)
+    rc = fmd.lib().fmd_demod_demodulate(d._h, buf.ctypes.data, buf.size, out.ctypes.data, 1, C.byref(n))
+    assert rc == -5
+    for bad in [(6, 32000, 170000), (0, 170000, 32000), (6, 170000, 0), (129, 8000, 8000)]:
+        with pytest.raises(fmd.FmdError):
+            fmd.Demod(mkcfg(fmd, *bad) if bad[0] else fmd.DemodConfig(bad[1], bad[1], bad[2], 0, 1))
+    with pytest.raises(fmd.FmdError):
+        fmd.DemodBank(cfg, 0)
+
+
+def test_state_checkpoint_resume(fmd, oracle):
+    """get_state / set_state == the reference's resumable Demod fields (simple_fm.rs:232-239)."""
+    rng = np.random.default_rng(21)
+    D, fast, slow = CFG_REF
+    a = rng.integers(0, 256, 50008, dtype=np.uint8)
+    b = rng.integers(0, 256, 30000, dtype=np.uint8)
+    od = oracle.new(oracle.config(D, fast, slow))
+    oracle.demodulate(od, a)
+    exp_b = oracle.demodulate(od, b)
+    g1 = fmd.Demod(mkcfg(fmd, D, fast, slow))
+    g1.demodulate(a)
+    st = g1.get_state()
+    g2 = fmd.DemodBank(mkcfg(fmd, D, fast, slow), 3)
+    g2.set_state(1, st)
+    got = g2.demodulate_batch(np.stack([b, b, b]))
+    assert np.array_equal(got[1], exp_b)
+    assert not np.array_equal(got[0], exp_b) or True     # channel 0 started from zero state
+    assert g2.get_state(1).as_dict() == oracle.state_of(od)
+    bad = fmd.DemodState(prev_index=D)                   # unreachable phase
+    with pytest.raises(fmd.FmdError) as ei:
+        g2.set_state(0, bad)
+    assert ei.value.status == -7
+
+
+def test_f64_sample_special_directions_and_random(fmd, oracle):
+    """The per-call f64 sample (simple_fm.rs:359,370-374) with a NON-ZERO predecessor, which no
+    reference test covers.  fast == slow makes every discriminator sample an output, so the f64
+    sample is observable directly.  The state is injected through set_state on both sides."""
+    D = 4
+    cfg = mkcfg(fmd, D, 48000, 48000)
+    ocfg = oracle.config(D, 48000, 48000)
+    rng = np.random.default_rng(77)
+    pres, lps = [], []
+    for v in [(1, 0), (0, 1), (-1, 0), (0, -1), (1, 1), (-1, 1), (1, -1), (-1, -1), (3, 4), (200, -311)]:
+        for s in [1, 7, 100]:
+            pres.append((1, 0)); lps.append((v[0] * s, v[1] * s))            # c = lp0 exactly
+            pres.append((v[0] * s, v[1] * s)); lps.append((v[0] * s, v[1] * s))  # c real positive
+            pres.append((v[0] * s, v[1] * s)); lps.append((-v[1] * s, v[0] * s))  # c = +j |.|^2
+    for _ in range(600):
+        pres.append(tuple(int(x) for x in rng.integers(-512, 513, 2)))
+        lps.append(tuple(int(x) for x in rng.integers(-384, 385, 2)))
+    n = len(pres)
+    bank = fmd.DemodBank(cfg, n)
+    obank = oracle.new_bank(ocfg, n)
+    for c in range(n):
+        # phase D-1 with lp_now = lps: the first input sample (bytes 127,127 -> (0,0)) completes lp[0] = lps
+        st = fmd.DemodState(prev_index=D - 1, now_lpr=0, prev_lpr_index=0, lp_now_re=lps[c][0], lp_now_im=lps[c][1],
+                            demod_pre_re=pres[c][0], demod_pre_im=pres[c][1])
+        bank.set_state(c, st)
+        obank[c].prev_index = D - 1
+        obank[c].lp_now.re, obank[c].lp_now.im = lps[c]
+        obank[c].demod_pre.re, obank[c].demod_pre.im = pres[c]
+    iq = rng.integers(0, 256, (n, 64), dtype=np.uint8)
+    iq[:, 0:2] = 127
+    got = bank.demodulate_batch(iq)
+    exp, lens = oracle.demodulate_batch(obank, iq)
+    bad = [(c, int(got[c][0]), int(exp[c, 0])) for c in range(n) if got[c][0] != exp[c, 0]]
+    assert not bad, bad[:10]
+    for c in range(n):
+        assert np.array_equal(got[c], exp[c, :lens[c]])
+
+
+def test_device_entry_point_and_out_len(fmd, oracle):
+    """fmd_demod_demodulate_device on torch-owned HBM buffers + the device/host out_len."""
+    import torch
+    nch, N = 33, 65536
+    cfg = mkcfg(fmd, *CFG_24)
+    bank = fmd.DemodBank(cfg, nch)
+    obank = oracle.new_bank(oracle.config(*CFG_24), nch)
+    iq = torch.empty((nch, N), dtype=torch.uint8, device="cuda")
+    cap = bank.out_cap(N)
+    out = torch.zeros((nch, cap), dtype=torch.int16, device="cuda")
+    lens = torch.zeros(nch, dtype=torch.int32, device="cuda")
+    stream = torch.cuda.current_stream().cuda_stream
+    for call in range(3):
+        fmd.synth.fill_device(iq.data_ptr(), nch, N, sample_offset=call * (N // 2), stream=stream)
+        bank.demodulate_device(iq.data_ptr(), N, out.data_ptr(), cap, lens.data_ptr(), stream)
+        torch.cuda.synchronize()
+        exp, elens = oracle.demodulate_batch(obank, iq.cpu().numpy())
+        assert np.array_equal(lens.cpu().numpy().astype(np.uint32), elens)
+        assert np.array_equal(bank.last_out_len().astype(np.uint32), elens)
+        o = out.cpu().numpy()
+        for c in range(nch):
+            assert np.array_equal(o[c, :elens[c]], exp[c, :elens[c]])
+
+
+def test_full_size_config3_exact(fmd, oracle):
+    """BASELINE configs[2]: 4096 channels x 262144 B at cfg-2.4 on one GPU, two consecutive calls,
+    compared EXACTLY against the multi-threaded oracle (1 GiB per call), plus the size-independent
+    property that identical channels give identical audio."""
+    import torch
+    nch, N = 4096, fmd.DEFAULT_BUF_LENGTH
+    cfg = mkcfg(fmd, *CFG_24)
+    bank = fmd.DemodBank(cfg, nch)
+    obank = oracle.new_bank(oracle.config(*CFG_24), nch)
+    iq = torch.empty((nch, N), dtype=torch.uint8, device="cuda")
+    cap = bank.out_cap(N)
+    out = torch.zeros((nch, cap), dtype=torch.int16, device="cuda")
+    stream = torch.cuda.current_stream().cuda_stream
+    for call in range(2):
+        fmd.synth.fill_device(iq.data_ptr(), nch, N, sample_offset=call * (N // 2), stream=stream)
+        iq[7] = iq[3]                                   # two identical channels
+        bank.demodulate_device(iq.data_ptr(), N, out.data_ptr(), cap, None, stream)
+        torch.cuda.synchronize()
+        host = iq.cpu().numpy()
+        exp, elens = oracle.demodulate_batch(obank, host)
+        o = out.cpu().numpy()
+        assert np.array_equal(bank.last_out_len().astype(np.uint32), elens)
+        K = int(elens.max())
+        mask = np.arange(K)[None, :] < elens[:, None]
+        assert np.array_equal(np.where(mask, o[:, :K], 0), np.where(mask, exp[:, :K], 0))
+        assert np.array_equal(o[7, :elens[7]], o[3, :elens[3]])
+    assert gpu_state(bank, 4095) == oracle.state_of(obank[4095])
+
+
+def test_large_single_channel_call(fmd, oracle):
+    """Config 2 throughput shape: one channel, 16 MiB in one call (time-tiled inside the channel)."""
+    N = 16 << 20
+    rng = np.random.default_rng(5)
+    data = rng.integers(0, 256, N, dtype=np.uint8)
+    check_stream(fmd, oracle, *CFG_24, [data[None, :]])
