@@ -103,6 +103,13 @@ def lib():
         if not os.path.exists(SO_PATH):
             raise ImportError("%s not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
                               "(hipcc --offload-arch=gfx950). There is no CPU fallback." % SO_PATH)
+        # One HIP runtime per process: torch bundles its own libamdhip64.so.7 (same soname as
+        # /opt/rocm's).  Whichever loads first serves both, and device pointers / streams are
+        # only shareable with torch when it is torch's -- so let torch load it first if present.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         l = C.CDLL(SO_PATH)
         for name, (res, args) in PROTOTYPES.items():
             fn = getattr(l, name)
