@@ -129,6 +129,41 @@ long fmcf_demodulate(uint32_t D, uint32_t fast, uint32_t slow, uint32_t kt, FmdC
     return (long)K;
 }
 
+// The division-free tile form used by the production kernel (phase-class plans) must describe
+// exactly the same tiles as fmd_tile().  Returns 0, or a positive code naming the first mismatch.
+int fmcf_check_plan(uint32_t D, uint32_t fast, uint32_t slow, uint32_t kt, uint32_t p0, uint32_t i0r, uint32_t ns)
+{
+    FmdRates r;
+    r.D = D; r.fast = fast; r.slow = slow;
+    r.g = fmd_gcd(fast, slow); r.fr = fast / r.g; r.sr = slow / r.g; r.R = (int32_t)(fast / slow); r.kt = kt;
+    if (!fmd_plan_possible(r) || !fmd_ranges_fit32(r, ns)) return -1;
+    const FmdClassPlan P = fmd_make_plan(r, p0, i0r, ns);
+    const uint32_t M = fmd_num_decimated(D, p0, ns), K = fmd_num_audio(r, i0r, M), nt = fmd_num_tiles(r, K);
+    if (P.M != M || P.K != K || P.nt != nt) return 1;
+    const uint32_t Qt = fmd_plan_Qt(r);
+    const uint32_t fa = r.fr / r.sr, fb = r.fr % r.sr;
+    const float inv_sr = 1.0f / (float)r.sr;
+    for (uint32_t t = 0; t < nt; t++) {
+        const FmdTile A = fmd_tile(r, p0, i0r, ns, M, K, nt, t);
+        const FmdTile B = fmd_tile_fast(r, P, Qt, ns, t);
+        if (A.k0 != B.k0 || A.k1 != B.k1) return 2;
+        if (A.jA != B.jA) return 3;
+        if (A.jB != B.jB) return 4;
+        if (A.nLo != B.nLo || A.nHi != B.nHi) return 5;
+        if (A.eq != B.eq || A.er != B.er || A.last != B.last) return 6;
+        for (uint32_t q = 0; q < A.k1 - A.k0; q++) {
+            const uint32_t e0 = A.eq + (A.er + q * r.fr) / r.sr;
+            const uint32_t e1 = B.eq + q * fa + fmd_udiv_small(B.er + q * fb, r.sr, inv_sr);
+            if (e0 != e1) return 7;
+        }
+    }
+    return 0;
+}
+
+int32_t fmcf_fast_atan2_q(int32_t y, int32_t x) { return fmd_fast_atan2_q(y, x); }
+uint32_t fmcf_udiv_small(uint32_t t, uint32_t d) { return fmd_udiv_small(t, d, 1.0f / (float)d); }
+int32_t fmcf_sdiv_small(int32_t s, int32_t d) { return fmd_sdiv_small(s, d, 1.0f / (float)d); }
+
 // Expose the scalar pieces so the tests can pin them against the oracle directly.
 int32_t fmcf_fast_atan2(int32_t y, int32_t x) { return fmd_fast_atan2(y, x); }
 void fmcf_window_sum(const uint8_t* chan, int64_t n0, int64_t n1, int32_t* re, int32_t* im)

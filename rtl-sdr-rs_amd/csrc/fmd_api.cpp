@@ -1,7 +1,7 @@
 // fmd_api.cpp -- the C ABI of include/fmd.h over the HIP kernels (compiled with hipcc).
 //
-// Host bookkeeping only: validation (the reference's panics become status codes), the
-// per-channel phase mirror that makes output counts known without a device round trip,
+// Host bookkeeping only: validation (the reference's panics become status codes), the phase
+// classes that make output counts and tile geometry known without a device round trip,
 // double-buffered per-channel Demod state in HBM, staging for the host-buffer entry points.
 // There is deliberately no CPU implementation of the path here.
 #include "../../include/fmd.h"
@@ -12,7 +12,9 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <map>
 #include <new>
+#include <utility>
 #include <vector>
 
 #include "fmd_index.h"
@@ -46,6 +48,14 @@ uint32_t env_u32(const char* name, uint32_t dflt)
     return (uint32_t)strtoul(s, nullptr, 10);
 }
 
+// Channels sharing the data-independent phases (prev_index, prev_lpr_index / g).  Channels created
+// together and fed equal-sized buffers stay in one class forever; only set_state splits them.
+struct PhaseClass {
+    uint32_t p0 = 0, i0r = 0;
+    uint32_t count = 0;      // channels in the class
+    uint32_t last_K = 0;     // audio samples of the most recent call
+};
+
 }  // namespace
 
 struct fmd_demod {
@@ -54,11 +64,14 @@ struct fmd_demod {
     uint32_t C = 0;
     int device = 0;
     uint32_t lp_cap = 0, raw_cap = 0;
+    bool force_generic = false;
     FmdChanState* d_state[2] = {nullptr, nullptr};
     int cur = 0;
     uint32_t* d_err = nullptr;
-    std::vector<uint32_t> p0, i0r;        // host mirror of the data-independent phases
-    std::vector<uint32_t> last_len;
+    std::vector<PhaseClass> classes;      // host mirror of the phases
+    std::vector<uint32_t> chan_class;     // [C] index into classes
+    uint8_t* d_chan_class = nullptr;      // device copy, valid while 1 < classes <= FMD_MAX_CLASSES
+    bool d_chan_class_dirty = true;
     hipStream_t stream = nullptr;         // used by the host-buffer entry points
     uint8_t* d_iq = nullptr;  size_t d_iq_cap = 0;
     int16_t* d_out = nullptr; size_t d_out_cap = 0;
@@ -71,15 +84,17 @@ int choose_tiling(fmd_demod* d, uint32_t kt_req)
     FmdRates& r = d->r;
     uint32_t kt = kt_req;
     if (kt == 0) {
-        // ~16 KiB of raw IQ per tile: bytes per audio sample = 2 * D * fast / slow
+        // ~19 KiB of raw IQ per tile (bytes per audio sample = 2 * D * fast / slow), rounded to a
+        // multiple of sr so that the division-free tile kernel applies.
         const double per = 2.0 * r.D * (double)r.fr / (double)r.sr;
-        double k = 16384.0 / per;
+        double k = 19456.0 / per;
         kt = k < 1.0 ? 1u : (k > 1024.0 ? 1024u : (uint32_t)k);
+        if (kt >= r.sr) kt -= kt % r.sr;
     }
     r.kt = kt;
     d->lp_cap = fmd_tile_lp_cap(r);
     d->raw_cap = fmd_tile_raw_cap(r);
-    const size_t lds = (size_t)d->raw_cap + 6u * (size_t)d->lp_cap + 16;
+    const size_t lds = (size_t)d->raw_cap + 6u * (size_t)d->lp_cap + 32;
     if (lds > 64 * 1024) {
         set_err("tile needs %zu bytes of LDS (kt=%u): rate_out/rate_resample x downsample too large", lds, kt);
         return FMD_ERR_UNSUPPORTED;
@@ -93,8 +108,44 @@ int use_device(const fmd_demod* d)
     return FMD_OK;
 }
 
-// Validates a call and fills per-channel M/K; returns max tiles per channel in *tiles.
-int plan_call(const fmd_demod* d, size_t nbytes, size_t out_cap, std::vector<uint32_t>& lens, uint32_t* tiles)
+void reset_classes(fmd_demod* d)
+{
+    d->classes.assign(1, PhaseClass{});
+    d->classes[0].count = d->C;
+    d->chan_class.assign(d->C, 0u);
+    d->d_chan_class_dirty = true;
+}
+
+// Re-cluster after one channel's phases changed.
+void regroup(fmd_demod* d, uint32_t channel, uint32_t p0, uint32_t i0r)
+{
+    std::vector<std::pair<uint32_t, uint32_t>> ph(d->C);
+    for (uint32_t c = 0; c < d->C; ++c) ph[c] = {d->classes[d->chan_class[c]].p0, d->classes[d->chan_class[c]].i0r};
+    std::vector<uint32_t> lastK(d->C);
+    for (uint32_t c = 0; c < d->C; ++c) lastK[c] = d->classes[d->chan_class[c]].last_K;
+    ph[channel] = {p0, i0r};
+    std::map<std::pair<uint32_t, uint32_t>, uint32_t> ids;
+    d->classes.clear();
+    for (uint32_t c = 0; c < d->C; ++c) {
+        auto it = ids.find(ph[c]);
+        if (it == ids.end()) {
+            it = ids.emplace(ph[c], (uint32_t)d->classes.size()).first;
+            PhaseClass pc; pc.p0 = ph[c].first; pc.i0r = ph[c].second; pc.last_K = lastK[c];
+            d->classes.push_back(pc);
+        }
+        d->chan_class[c] = it->second;
+        d->classes[it->second].count++;
+    }
+    d->d_chan_class_dirty = true;
+}
+
+bool tile_kernel_ok(const fmd_demod* d)
+{
+    return !d->force_generic && d->classes.size() <= FMD_MAX_CLASSES && fmd_tile_kernel_supports(d->r, d->raw_cap);
+}
+
+// Validates a call; fills one plan per class and the grid's tiles-per-channel.
+int plan_call(const fmd_demod* d, size_t nbytes, size_t out_cap, std::vector<FmdClassPlan>& plans, uint32_t* tiles)
 {
     if (nbytes % 8 != 0) { set_err("nbytes %% 8 != 0 (simple_fm.rs:286 would panic)"); return FMD_ERR_BAD_LENGTH; }
     const uint64_t ns = nbytes / 2;
@@ -103,37 +154,38 @@ int plan_call(const fmd_demod* d, size_t nbytes, size_t out_cap, std::vector<uin
         return FMD_ERR_UNSUPPORTED;
     }
     uint32_t tmax = 1;
-    lens.resize(d->C);
-    for (uint32_t c = 0; c < d->C; ++c) {
-        const uint32_t M = fmd_num_decimated(d->r.D, d->p0[c], (uint32_t)ns);
-        if (M < 2) { set_err("channel %u: %u decimated samples (simple_fm.rs:356 asserts > 1)", c, M); return FMD_ERR_TOO_SHORT; }
-        const uint32_t K = fmd_num_audio(d->r, d->i0r[c], M);
-        if (K > out_cap) { set_err("channel %u produces %u samples, out_cap %zu", c, K, out_cap); return FMD_ERR_CAPACITY; }
-        lens[c] = K;
-        const uint32_t nt = fmd_num_tiles(d->r, K);
-        if (nt > tmax) tmax = nt;
+    plans.resize(d->classes.size());
+    for (size_t k = 0; k < d->classes.size(); ++k) {
+        const FmdClassPlan P = fmd_make_plan(d->r, d->classes[k].p0, d->classes[k].i0r, (uint32_t)ns);
+        if (P.M < 2) { set_err("%u decimated samples (simple_fm.rs:356 asserts > 1)", P.M); return FMD_ERR_TOO_SHORT; }
+        if (P.K > out_cap) { set_err("a channel produces %u samples, out_cap %zu", P.K, out_cap); return FMD_ERR_CAPACITY; }
+        plans[k] = P;
+        if (P.nt > tmax) tmax = P.nt;
     }
     *tiles = tmax;
     return FMD_OK;
 }
 
-void advance_mirror(fmd_demod* d, size_t nbytes, const std::vector<uint32_t>& lens)
+void advance_classes(fmd_demod* d, size_t nbytes, const std::vector<FmdClassPlan>& plans)
 {
     const uint32_t ns = (uint32_t)(nbytes / 2);
-    for (uint32_t c = 0; c < d->C; ++c) {
-        const uint32_t M = fmd_num_decimated(d->r.D, d->p0[c], ns);
-        d->i0r[c] = fmd_next_lpr_index_r(d->r, d->i0r[c], M, lens[c]);
-        d->p0[c] = fmd_next_prev_index(d->r.D, d->p0[c], ns);
+    bool merged = false;
+    for (size_t k = 0; k < d->classes.size(); ++k) {
+        PhaseClass& pc = d->classes[k];
+        pc.i0r = fmd_next_lpr_index_r(d->r, pc.i0r, plans[k].M, plans[k].K);
+        pc.p0 = fmd_next_prev_index(d->r.D, pc.p0, ns);
+        pc.last_K = plans[k].K;
+        for (size_t m = 0; m < k; ++m) merged |= (d->classes[m].p0 == pc.p0 && d->classes[m].i0r == pc.i0r);
     }
-    d->last_len = lens;
+    (void)merged;   // classes that converge stay separate; that only costs a plan slot
 }
 
 int enqueue(fmd_demod* d, const void* d_iq, size_t nbytes, void* d_out, size_t out_cap, void* d_out_len,
             hipStream_t stream)
 {
-    std::vector<uint32_t> lens;
+    std::vector<FmdClassPlan> plans;
     uint32_t tiles = 1;
-    int rc = plan_call(d, nbytes, out_cap, lens, &tiles);
+    int rc = plan_call(d, nbytes, out_cap, plans, &tiles);
     if (rc) return rc;
     if (((uintptr_t)d_iq & 15u) != 0) { set_err("d_iq must be 16-byte aligned"); return FMD_ERR_INVALID_ARG; }
     FmdLaunch L{};
@@ -152,9 +204,30 @@ int enqueue(fmd_demod* d, const void* d_iq, size_t nbytes, void* d_out, size_t o
     L.out_stride = out_cap;
     L.out_len = static_cast<uint32_t*>(d_out_len);
     L.err = d->d_err;
-    HIP_TRY(fmd_launch_demod(L, stream));
+    if (tile_kernel_ok(d)) {
+        const FmdRates& r = d->r;
+        L.Qt = fmd_plan_Qt(r);
+        L.fa = r.fr / r.sr; L.fb = r.fr % r.sr;
+        L.inv_sr = 1.0f / (float)r.sr; L.inv_R = 1.0f / (float)r.R;
+        for (size_t k = 0; k < plans.size(); ++k) L.cls[k] = plans[k];
+        L.chan_class = nullptr;
+        if (d->classes.size() > 1) {
+            if (d->d_chan_class_dirty) {
+                std::vector<uint8_t> ids(d->C);
+                for (uint32_t c = 0; c < d->C; ++c) ids[c] = (uint8_t)d->chan_class[c];
+                if (!d->d_chan_class) HIP_TRY(hipMalloc(&d->d_chan_class, d->C));
+                HIP_TRY(hipDeviceSynchronize());
+                HIP_TRY(hipMemcpy(d->d_chan_class, ids.data(), d->C, hipMemcpyHostToDevice));
+                d->d_chan_class_dirty = false;
+            }
+            L.chan_class = d->d_chan_class;
+        }
+        HIP_TRY(fmd_launch_tile(L, stream));
+    } else {
+        HIP_TRY(fmd_launch_generic(L, stream));
+    }
     d->cur ^= 1;
-    advance_mirror(d, nbytes, lens);
+    advance_classes(d, nbytes, plans);
     return FMD_OK;
 }
 
@@ -248,6 +321,7 @@ int fmd_demod_new(const fmd_demod_config* config, const fmd_device_config* dev, 
         set_err("rate_out / gcd = %u > 2^24 unsupported", r.fr);
         delete d; return FMD_ERR_UNSUPPORTED;
     }
+    d->force_generic = env_u32("FMD_FORCE_GENERIC", 0) != 0;
     int rc = choose_tiling(d, env_u32("FMD_KT", 0));
     if (rc) { delete d; return rc; }
 
@@ -265,7 +339,7 @@ int fmd_demod_new(const fmd_demod_config* config, const fmd_device_config* dev, 
         delete d; return FMD_ERR_NO_DEVICE;
     }
     d->device = device;
-    d->p0.assign(d->C, 0); d->i0r.assign(d->C, 0); d->last_len.assign(d->C, 0);
+    reset_classes(d);
 
     auto fail = [&](hipError_t e, const char* what) {
         set_err("%s: %s", what, hipGetErrorString(e));
@@ -294,6 +368,7 @@ void fmd_demod_free(fmd_demod* d)
     (void)hipDeviceSynchronize();
     for (int i = 0; i < 2; ++i) if (d->d_state[i]) (void)hipFree(d->d_state[i]);
     if (d->d_err) (void)hipFree(d->d_err);
+    if (d->d_chan_class) (void)hipFree(d->d_chan_class);
     if (d->d_iq) (void)hipFree(d->d_iq);
     if (d->d_out) (void)hipFree(d->d_out);
     if (d->stream) (void)hipStreamDestroy(d->stream);
@@ -312,7 +387,7 @@ int fmd_demod_reset(fmd_demod* d)
     HIP_TRY(hipMemset(d->d_err, 0, sizeof(uint32_t)));
     HIP_TRY(hipDeviceSynchronize());
     d->cur = 0;
-    d->p0.assign(d->C, 0); d->i0r.assign(d->C, 0); d->last_len.assign(d->C, 0);
+    reset_classes(d);
     return FMD_OK;
 }
 
@@ -332,8 +407,8 @@ int fmd_demod_demodulate_batch(fmd_demod* d, const uint8_t* iq, size_t nbytes, i
     int rc = use_device(d);
     if (rc) return rc;
     {   // validate before touching the staging buffers
-        std::vector<uint32_t> lens; uint32_t tiles;
-        rc = plan_call(d, nbytes, out_cap, lens, &tiles);
+        std::vector<FmdClassPlan> plans; uint32_t tiles;
+        rc = plan_call(d, nbytes, out_cap, plans, &tiles);
         if (rc) return rc;
     }
     const size_t in_bytes = nbytes * (size_t)d->C;
@@ -352,7 +427,11 @@ int fmd_demod_demodulate_batch(fmd_demod* d, const uint8_t* iq, size_t nbytes, i
     rc = enqueue(d, d->d_iq, nbytes, d->d_out, out_cap, nullptr, d->stream);
     if (rc) return rc;
     uint32_t kmax = 0;
-    for (uint32_t c = 0; c < d->C; ++c) { out_len[c] = d->last_len[c]; if (d->last_len[c] > kmax) kmax = d->last_len[c]; }
+    for (uint32_t c = 0; c < d->C; ++c) {
+        const uint32_t K = d->classes[d->chan_class[c]].last_K;
+        out_len[c] = K;
+        if (K > kmax) kmax = K;
+    }
     if (kmax) {
         HIP_TRY(hipMemcpy2DAsync(out, out_cap * sizeof(int16_t), d->d_out, out_cap * sizeof(int16_t),
                                  (size_t)kmax * sizeof(int16_t), d->C, hipMemcpyDeviceToHost, d->stream));
@@ -375,7 +454,7 @@ int fmd_demod_demodulate(fmd_demod* d, const uint8_t* iq, size_t nbytes, int16_t
 int fmd_demod_last_out_len(const fmd_demod* d, size_t* out_len)
 {
     if (!d || !out_len) return FMD_ERR_INVALID_ARG;
-    for (uint32_t c = 0; c < d->C; ++c) out_len[c] = d->last_len[c];
+    for (uint32_t c = 0; c < d->C; ++c) out_len[c] = d->classes[d->chan_class[c]].last_K;
     return FMD_OK;
 }
 
@@ -422,8 +501,8 @@ int fmd_demod_set_state(fmd_demod* d, uint32_t channel, const fmd_demod_state* s
     s.lp_now_re = state->lp_now_re; s.lp_now_im = state->lp_now_im;
     s.demod_pre_re = state->demod_pre_re; s.demod_pre_im = state->demod_pre_im;
     HIP_TRY(hipMemcpy(d->d_state[d->cur] + channel, &s, sizeof(s), hipMemcpyHostToDevice));
-    d->p0[channel] = s.prev_index;
-    d->i0r[channel] = s.lpr_index_r;
+    const PhaseClass& pc = d->classes[d->chan_class[channel]];
+    if (pc.p0 != s.prev_index || pc.i0r != s.lpr_index_r) regroup(d, channel, s.prev_index, s.lpr_index_r);
     return FMD_OK;
 }
 
@@ -431,7 +510,10 @@ int fmd_demod_tiling(const fmd_demod* d, uint32_t* audio_per_tile, uint32_t* lds
 {
     if (!d) return FMD_ERR_INVALID_ARG;
     if (audio_per_tile) *audio_per_tile = d->r.kt;
-    if (lds_bytes) { FmdLaunch L{}; L.raw_cap = d->raw_cap; L.lp_cap = d->lp_cap; *lds_bytes = (uint32_t)fmd_demod_lds_bytes(L); }
+    if (lds_bytes) {
+        FmdLaunch L{}; L.raw_cap = d->raw_cap; L.lp_cap = d->lp_cap;
+        *lds_bytes = (uint32_t)(tile_kernel_ok(d) ? fmd_tile_lds_bytes(L) : fmd_generic_lds_bytes(L));
+    }
     if (block_threads) *block_threads = FMD_BLOCK_THREADS;
     return FMD_OK;
 }

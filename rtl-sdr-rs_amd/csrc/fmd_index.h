@@ -140,6 +140,96 @@ FMD_HD FmdTile fmd_tile(const FmdRates& r, uint32_t p0, uint32_t i0r, uint32_t n
     return T;
 }
 
+// ---- phase classes and the division-free tile form ------------------------------------------
+// Channels that share (p0, i0r) share every index of the call.  When kt is a multiple of sr,
+// kt*fr = Qt*sr exactly and all tiles of a class have the same internal structure shifted by
+// t*Qt decimated samples, so a tile needs only multiply-adds of the per-class constants below
+// (computed once per call on the host).
+struct FmdClassPlan {
+    uint32_t p0, i0r;   // call-start phases of the class
+    uint32_t M, K, nt;  // decimated / audio samples and tiles of this call
+    uint32_t eq0, er0;  // fr - i0r - 1 = eq0*sr + er0          (tile 0's eq, every tile's er)
+    uint32_t c1;        // ceil((i0r + 1) / sr):  jA(t >= 1) = t*Qt - c1 + 1
+    uint32_t jBrel;     // jB(non-last tile t) = t*Qt + jBrel
+    uint32_t pad[3];
+};
+
+inline bool fmd_plan_possible(const FmdRates& r) { return r.kt % r.sr == 0; }
+inline uint32_t fmd_plan_Qt(const FmdRates& r) { return (uint32_t)((uint64_t)r.kt * r.fr / r.sr); }
+
+inline FmdClassPlan fmd_make_plan(const FmdRates& r, uint32_t p0, uint32_t i0r, uint32_t ns)
+{
+    FmdClassPlan P{};
+    P.p0 = p0; P.i0r = i0r;
+    P.M = fmd_num_decimated(r.D, p0, ns);
+    P.K = fmd_num_audio(r, i0r, P.M);
+    P.nt = fmd_num_tiles(r, P.K);
+    const uint32_t a0 = r.fr - i0r - 1;
+    P.eq0 = a0 / r.sr;
+    P.er0 = a0 % r.sr;
+    P.c1 = (i0r + r.sr) / r.sr;
+    P.jBrel = P.eq0 + (uint32_t)(((uint64_t)P.er0 + (uint64_t)(r.kt - 1) * r.fr) / r.sr);
+    return P;
+}
+
+FMD_HD FmdTile fmd_tile_fast(const FmdRates& r, const FmdClassPlan& P, uint32_t Qt, uint32_t ns, uint32_t t)
+{
+    FmdTile T;
+    T.last = (t + 1 == P.nt);
+    T.k0 = t * r.kt;
+    T.k1 = T.k0 + r.kt < P.K ? T.k0 + r.kt : P.K;
+    if (T.k1 < T.k0) T.k1 = T.k0;
+    T.eq = t * Qt + P.eq0;
+    T.er = P.er0;
+    T.jA = t == 0 ? 0 : (int32_t)(t * Qt - P.c1 + 1);
+    T.jB = T.last ? (int32_t)P.M - 1 : (int32_t)(t * Qt + P.jBrel);
+    T.nLo = T.jA >= 1 ? fmd_win_begin(r.D, P.p0, T.jA - 1) : 0;
+    T.nHi = T.last ? (int32_t)ns : fmd_win_end(r.D, P.p0, T.jB);
+    if (T.nHi < T.nLo) T.nHi = T.nLo;
+    return T;
+}
+
+// floor(t / d) for 0 <= t < 2^24, 1 <= d < 2^24, t / d < 2^20, with inv_d = 1.0f / d: the f32
+// estimate is within 1 of the quotient, one exact remainder fixes it.
+FMD_HD uint32_t fmd_udiv_small(uint32_t t, uint32_t d, float inv_d)
+{
+    uint32_t q = (uint32_t)((float)t * inv_d);
+    const int32_t rem = (int32_t)t - (int32_t)(q * d);
+    if (rem < 0) --q;
+    else if (rem >= (int32_t)d) ++q;
+    return q;
+}
+
+// Truncating s / d (Rust `/` on i32, simple_fm.rs:421) for |s| < 2^24, 1 <= d < 2^24.
+FMD_HD int32_t fmd_sdiv_small(int32_t s, int32_t d, float inv_d)
+{
+    int32_t q = (int32_t)((float)s * inv_d);            // conversion truncates toward zero
+    const int32_t rem = s - q * d;
+    if (s >= 0) { if (rem < 0) --q; else if (rem >= d) ++q; }
+    else        { if (rem > 0) ++q; else if (rem <= -d) --q; }
+    return q;
+}
+
+// Truncating num / den for den > 0, |num / den| <= 4097 (the fast_atan2 quotient): f32 estimate
+// within 1, exact wrapping-remainder fix-up.  Needs den < 2^30.
+FMD_HD float fmd_rcp(float x)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_rcpf(x);                    // v_rcp_f32, 1 ulp
+#else
+    return 1.0f / x;
+#endif
+}
+
+FMD_HD int32_t fmd_sdiv_q13(int32_t num, int32_t den)
+{
+    int32_t q = (int32_t)((float)num * fmd_rcp((float)den));
+    const int32_t rem = (int32_t)((uint32_t)num - (uint32_t)q * (uint32_t)den);
+    if (num >= 0) { if (rem < 0) --q; else if (rem >= den) ++q; }
+    else          { if (rem > 0) ++q; else if (rem <= -den) --q; }
+    return q;
+}
+
 // Upper bounds used to size LDS: decimated samples and input bytes one tile can touch.
 inline uint32_t fmd_tile_lp_cap(const FmdRates& r)
 {
@@ -177,6 +267,20 @@ FMD_HD int32_t fmd_fast_atan2(int32_t y, int32_t x)
     else        { num = (int32_t)((ux + uyabs) << 12); den = (int32_t)(uyabs - ux); base = 3 << 12; }
     const int32_t angle = (int32_t)((uint32_t)base - (uint32_t)(num / den));
     return y < 0 ? (int32_t)(0u - (uint32_t)angle) : angle;
+}
+
+// The same function with the cheap exact division; valid while x + |y| < 2^30 (downsample <= 64).
+FMD_HD int32_t fmd_fast_atan2_q(int32_t y, int32_t x)
+{
+    const uint32_t ux = (uint32_t)x;
+    const uint32_t uyabs = y < 0 ? 0u - (uint32_t)y : (uint32_t)y;
+    const uint32_t dif = ux - uyabs, sum = ux + uyabs;
+    const bool xpos = x >= 0;
+    const int32_t num = (int32_t)((xpos ? dif : sum) << 12);
+    const int32_t den = xpos ? (int32_t)sum : (int32_t)(0u - dif);
+    const int32_t angle = (xpos ? (1 << 12) : (3 << 12)) - fmd_sdiv_q13(num, den);
+    const int32_t res = y < 0 ? -angle : angle;
+    return den == 0 ? 0 : res;
 }
 
 // a * conj(b) on Complex<i32> (num-complex 0.4), wrapping.

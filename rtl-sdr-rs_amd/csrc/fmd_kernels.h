@@ -8,6 +8,8 @@
 #include "fmd_index.h"
 
 #define FMD_BLOCK_THREADS 256
+#define FMD_MAX_CLASSES 4
+#define FMD_TILE_MAX_LOADS 8      /* 16-byte chunks per thread the tile kernel can stage */
 
 // Device-side error bits (FmdLaunch::err), all "cannot happen" conditions.
 #define FMD_DEVERR_LP_CAP  1u
@@ -29,6 +31,12 @@ struct FmdLaunch {
     uint64_t out_stride;      // samples
     uint32_t* out_len;        // [n_channels] or nullptr
     uint32_t* err;            // device error word
+    // ---- tile kernel only (phase-class plans; see fmd_index.h) ----
+    uint32_t Qt;              // decimated samples per full tile = kt * fr / sr
+    uint32_t fa, fb;          // fr = fa * sr + fb
+    float    inv_sr, inv_R;
+    const uint8_t* chan_class;// [n_channels] class id, or nullptr when every channel is class 0
+    FmdClassPlan cls[FMD_MAX_CLASSES];
 };
 
 struct FmdSynthLaunch {
@@ -40,8 +48,13 @@ struct FmdSynthLaunch {
     uint32_t amplitude, noise, dev_q32, mod_period;
 };
 
-size_t fmd_demod_lds_bytes(const FmdLaunch& L);
-hipError_t fmd_launch_demod(const FmdLaunch& L, hipStream_t stream);
+// Can the division-free tile kernel run this configuration?  (Otherwise the generic kernel does.)
+bool fmd_tile_kernel_supports(const FmdRates& r, uint32_t raw_cap);
+
+size_t fmd_generic_lds_bytes(const FmdLaunch& L);
+size_t fmd_tile_lds_bytes(const FmdLaunch& L);
+hipError_t fmd_launch_generic(const FmdLaunch& L, hipStream_t stream);
+hipError_t fmd_launch_tile(const FmdLaunch& L, hipStream_t stream);
 hipError_t fmd_launch_synth(const FmdSynthLaunch& S, hipStream_t stream);
 
 #endif

@@ -56,7 +56,7 @@ __device__ __forceinline__ uint32_t pack_lp(int re, int im) { return ((uint32_t)
 __device__ __forceinline__ int lp_re(uint32_t p) { return (int)(int16_t)(p & 0xFFFFu); }
 __device__ __forceinline__ int lp_im(uint32_t p) { return (int)(int16_t)(p >> 16); }
 
-__global__ void __launch_bounds__(FMD_BLOCK_THREADS) fmd_demod_kernel(const FmdLaunch L)
+__global__ void __launch_bounds__(FMD_BLOCK_THREADS) fmd_demod_generic_kernel(const FmdLaunch L)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint32_t* const raw_w = reinterpret_cast<uint32_t*>(smem);
@@ -162,6 +162,185 @@ __global__ void __launch_bounds__(FMD_BLOCK_THREADS) fmd_demod_kernel(const FmdL
     }
 }
 
+// =================================================================================================
+// Tile kernel: the production path.  Differences from the generic kernel above:
+//   * tile geometry comes from host-made per-phase-class plans (FmdClassPlan): no integer division
+//     on the device except one exact f32-reciprocal divide per discriminator / audio sample;
+//   * every 16-byte load of the tile is in flight before the first wait (up to 8 per lane);
+//   * decimation windows of an even downsample are DH whole dwords: 3 VALU ops per dword
+//     (xor, 2 x v_dot4_i32_i8), sign by dword parity applied once per window;
+//   * the predecessor sample comes from the neighbouring lane (DPP wave_shr:1); each wave-round
+//     covers 63 new windows + 1 overlap, so no LDS exchange and no barrier between the boxcar
+//     and the discriminator; complex multiply by v_dot2_i32_i16 on packed (re, im).
+// =================================================================================================
+typedef short fmd_s2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ uint32_t wave_shr1(uint32_t v)
+{
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
+}
+
+__device__ __forceinline__ int sdot2(uint32_t a, uint32_t b)
+{
+    return __builtin_amdgcn_sdot2(__builtin_bit_cast(fmd_s2, a), __builtin_bit_cast(fmd_s2, b), 0, false);
+}
+
+// c = a * conj(b) for packed (re | im << 16) operands whose components fit i16.
+__device__ __forceinline__ void mul_conj_pk(uint32_t a, uint32_t b, int& cr, int& ci)
+{
+    const uint32_t a_sw = __builtin_amdgcn_alignbit(a, a, 16);               // (im, re)
+    const uint32_t b_cj = (b & 0xFFFFu) | ((0u - (b >> 16)) << 16);           // (re, -im)
+    cr = sdot2(a, b);
+    ci = sdot2(a_sw, b_cj);
+}
+
+// DH whole dwords starting at LDS dword index `w0`; `odd` = parity of the call-relative dword index.
+template <int DH>
+__device__ __forceinline__ void lds_window_fast(const uint32_t* __restrict__ raw_w, int w0, bool odd, int& re, int& im)
+{
+    int er = 0, ei = 0, orr = 0, oi = 0;
+#pragma unroll
+    for (int i = 0; i < DH; ++i) {
+        const uint32_t w = raw_w[w0 + i] ^ 0x80808080u;
+        if (i & 1) { orr = sdot4(w, FMD_W_RE_EVEN, orr); oi = sdot4(w, FMD_W_IM_EVEN, oi); }
+        else       { er = sdot4(w, FMD_W_RE_EVEN, er);  ei = sdot4(w, FMD_W_IM_EVEN, ei); }
+    }
+    const int dr = er - orr, di = ei - oi;
+    // additive constants: every dword +1 on re; every even-indexed (call-relative) dword +2 on im
+    re = (odd ? -dr : dr) + DH;
+    im = (odd ? -di : di) + 2 * (odd ? DH / 2 : (DH + 1) / 2);
+}
+
+template <int DH>
+__global__ void __launch_bounds__(FMD_BLOCK_THREADS) fmd_demod_tile_kernel(const FmdLaunch L)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint32_t* const raw_w = reinterpret_cast<uint32_t*>(smem);
+    int16_t* const d16 = reinterpret_cast<int16_t*>(smem + L.raw_cap);
+    uint32_t* const last_lp = reinterpret_cast<uint32_t*>(smem + L.raw_cap + ((2u * L.lp_cap + 15u) & ~15u));
+
+    const uint32_t tid = threadIdx.x;
+    const uint32_t lane = tid & 63u, wave = tid >> 6;
+    const uint32_t c = blockIdx.x / L.tiles;
+    const uint32_t t = blockIdx.x - c * L.tiles;
+    const FmdRates r = L.r;
+    const uint32_t ci = L.chan_class ? L.chan_class[c] : 0u;
+    const FmdClassPlan P = L.cls[ci];
+    if (t >= P.nt) return;
+    const FmdTile T = fmd_tile_fast(r, P, L.Qt, L.ns, t);
+    const uint32_t p0 = P.p0;
+    const int jfirst = T.jA - 1;
+    const int cnt = T.jB - jfirst + 1;
+
+    // ---- stage: all loads in flight, then one pass of ds_write_b128 ------------------------
+    const uint64_t gbase = (uint64_t)(uintptr_t)L.iq + (uint64_t)c * L.chan_stride;
+    const uint64_t gLo = gbase + 2ull * (uint32_t)T.nLo;
+    const uint64_t gHi = gbase + 2ull * (uint32_t)T.nHi;
+    const uint64_t a0 = gLo & ~15ull;
+    const uint32_t nchunks = (uint32_t)((gHi - a0 + 15) >> 4);
+    if ((uint32_t)cnt > L.lp_cap || nchunks * 16u > L.raw_cap || nchunks > FMD_TILE_MAX_LOADS * FMD_BLOCK_THREADS) {
+        if (tid == 0) atomicOr(L.err, (uint32_t)cnt > L.lp_cap ? FMD_DEVERR_LP_CAP : FMD_DEVERR_RAW_CAP);
+        return;
+    }
+    const uint64_t gend = (uint64_t)(uintptr_t)L.iq + L.total_bytes;
+    if (a0 + 16ull * nchunks <= gend) {
+        // LDS-DMA (global_load_lds_dwordx4): 1 KiB per wave-instruction straight into the tile image,
+        // destination = wave-uniform base (M0) + lane * 16; no VGPR round trip, no ds_write pass.
+        const unsigned char* src = reinterpret_cast<const unsigned char*>((uintptr_t)a0);
+#pragma unroll
+        for (int l = 0; l < FMD_TILE_MAX_LOADS; ++l) {
+            const uint32_t i = tid + l * FMD_BLOCK_THREADS;
+            if (i < nchunks)
+                __builtin_amdgcn_global_load_lds(
+                    (const __attribute__((address_space(1))) void*)(src + 16ull * i),
+                    (__attribute__((address_space(3))) void*)(smem + 16u * (i - lane)), 16, 0, 0);
+        }
+    } else {   // the whole array ends inside this tile's last chunk (sizes are multiples of 8)
+        for (uint32_t i = tid; i < nchunks; i += FMD_BLOCK_THREADS) {
+            const uint64_t a = a0 + 16ull * i;
+            uint4 v;
+            if (a + 16 <= gend) v = *reinterpret_cast<const uint4*>((uintptr_t)a);
+            else { const uint2 h = *reinterpret_cast<const uint2*>((uintptr_t)a); v = make_uint4(h.x, h.y, 0u, 0u); }
+            reinterpret_cast<uint4*>(smem)[i] = v;
+        }
+    }
+    const int wofs = (int)((int64_t)(gbase - a0) >> 2);      // LDS dword index of the call's dword 0
+    const bool fastwin = DH > 0 && (p0 & 1u) == 0u;          // windows are whole dwords
+    const FmdChanState st = L.st_in[c];
+    __syncthreads();
+
+    // ---- boxcar + discriminator, 63 new decimated samples per wave-round --------------------
+    constexpr int NW = FMD_BLOCK_THREADS / 64;
+    for (int base = (int)wave * 63; base < cnt; base += NW * 63) {
+        const int i = base + (int)lane;                       // lane 0 re-does the previous round's last window
+        const bool act = i < cnt;
+        const int j = jfirst + i;
+        int re = 0, im = 0;
+        if (fastwin) {
+            if (act) {
+                const int jj = j < 1 ? 1 : j;
+                const int m0 = DH * jj - (int)(p0 >> 1);      // call-relative dword index of the window
+                lds_window_fast<(DH > 0 ? DH : 1)>(raw_w, wofs + m0, (m0 & 1) != 0, re, im);
+            }
+            if (jfirst <= 0 && base == 0 && act && j <= 0) {   // call start only: demod_pre and the clipped first window
+                if (j < 0) { re = st.demod_pre_re; im = st.demod_pre_im; }
+                else {
+                    lds_window_sum(raw_w, wofs, 0, fmd_win_end(r.D, p0, 0), re, im);
+                    re += st.lp_now_re; im += st.lp_now_im;
+                }
+            }
+        } else if (act) {
+            if (j < 0) { re = st.demod_pre_re; im = st.demod_pre_im; }
+            else {
+                lds_window_sum(raw_w, wofs, fmd_win_begin(r.D, p0, j), fmd_win_end(r.D, p0, j), re, im);
+                if (j == 0) { re += st.lp_now_re; im += st.lp_now_im; }
+            }
+        }
+        const uint32_t pk = pack_lp(re, im);
+        const uint32_t prev = wave_shr1(pk);
+        if (act && lane > 0) {
+            int cr, cim;
+            mul_conj_pk(pk, prev, cr, cim);
+            int pcm = fmd_fast_atan2_q(cim, cr);              // (:362)
+            if (jfirst < 0 && base == 0 && j == 0) pcm = polar_f64(cr, cim);   // first sample of the call (:359)
+            d16[i] = (int16_t)pcm;
+        }
+        if (T.last && act && j == T.jB) last_lp[0] = pk;
+    }
+    __syncthreads();
+
+    // ---- low_pass_real: one audio sample per lane -----------------------------------------
+    const uint32_t nk = T.k1 - T.k0;
+    int16_t* const outc = L.out + (uint64_t)c * L.out_stride;
+    for (uint32_t q = tid; q < nk; q += FMD_BLOCK_THREADS) {
+        const int e = (int)(T.eq + q * L.fa + fmd_udiv_small(T.er + q * L.fb, r.sr, L.inv_sr));
+        const int s = q == 0 ? T.jA
+                             : (int)(T.eq + (q - 1) * L.fa + fmd_udiv_small(T.er + (q - 1) * L.fb, r.sr, L.inv_sr)) + 1;
+        int sum = (T.k0 + q == 0) ? st.now_lpr : 0;
+        for (int jj = s; jj <= e; ++jj) sum += d16[jj - jfirst];
+        outc[T.k0 + q] = (int16_t)fmd_sdiv_small(sum, r.R, L.inv_R);
+    }
+
+    // ---- Demod state after the call (last tile only) ----------------------------------------
+    if (T.last && tid == 0) {
+        FmdChanState ns_;
+        const int s = P.K == 0 ? 0 : (int)fmd_audio_end(r, P.i0r, P.K - 1) + 1;
+        int sum = P.K == 0 ? st.now_lpr : 0;
+        for (int jj = s; jj <= T.jB; ++jj) sum += d16[jj - jfirst];
+        ns_.now_lpr = sum;
+        ns_.lpr_index_r = fmd_next_lpr_index_r(r, P.i0r, P.M, P.K);
+        ns_.prev_index = fmd_next_prev_index(r.D, p0, L.ns);
+        int tr, ti;
+        lds_window_sum(raw_w, wofs, fmd_win_begin(r.D, p0, (int)P.M), (int)L.ns, tr, ti);
+        ns_.lp_now_re = tr; ns_.lp_now_im = ti;
+        const uint32_t l = last_lp[0];                        // lp[M-1]; M >= 2 is guaranteed by the host
+        ns_.demod_pre_re = lp_re(l); ns_.demod_pre_im = lp_im(l);
+        ns_.reserved = 0;
+        L.st_out[c] = ns_;
+        if (L.out_len) L.out_len[c] = P.K;
+    }
+}
+
 // ---- synthetic FM source (integer only; mirrored bit-for-bit by rtl-sdr-rs_amd/synth.py) ------
 __host__ __device__ __forceinline__ uint64_t mix64(uint64_t z)
 {
@@ -220,17 +399,51 @@ __global__ void __launch_bounds__(256) fmd_synth_kernel(const FmdSynthLaunch S)
 
 }  // namespace
 
-size_t fmd_demod_lds_bytes(const FmdLaunch& L)
+size_t fmd_generic_lds_bytes(const FmdLaunch& L)
 {
     return ((size_t)L.raw_cap + 4u * (size_t)L.lp_cap + 2u * (size_t)L.lp_cap + 15u) & ~(size_t)15u;
 }
 
-hipError_t fmd_launch_demod(const FmdLaunch& L, hipStream_t stream)
+size_t fmd_tile_lds_bytes(const FmdLaunch& L)
 {
-    const size_t lds = fmd_demod_lds_bytes(L);
+    return (size_t)L.raw_cap + ((2u * (size_t)L.lp_cap + 15u) & ~(size_t)15u) + 16u;
+}
+
+bool fmd_tile_kernel_supports(const FmdRates& r, uint32_t raw_cap)
+{
+    if (r.kt % r.sr != 0) return false;                                   // plans need kt*fr = Qt*sr
+    if (r.D > 64) return false;                                           // fmd_sdiv_q13: x + |y| < 2^30
+    if ((uint64_t)r.sr * (r.kt + 2) >= (1u << 24)) return false;          // fmd_udiv_small operands
+    if ((uint64_t)((r.fr + r.sr - 1) / r.sr + 2) * 32768ull >= (1u << 24)) return false;   // |group sum| < 2^24
+    if ((uint32_t)r.R >= (1u << 24)) return false;
+    if (raw_cap > 16u * FMD_TILE_MAX_LOADS * FMD_BLOCK_THREADS) return false;
+    return true;
+}
+
+hipError_t fmd_launch_generic(const FmdLaunch& L, hipStream_t stream)
+{
+    const size_t lds = fmd_generic_lds_bytes(L);
     const uint64_t blocks = (uint64_t)L.n_channels * L.tiles;
     if (blocks == 0 || blocks > 0x7FFFFFFFull) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(fmd_demod_kernel, dim3((uint32_t)blocks), dim3(FMD_BLOCK_THREADS), lds, stream, L);
+    hipLaunchKernelGGL(fmd_demod_generic_kernel, dim3((uint32_t)blocks), dim3(FMD_BLOCK_THREADS), lds, stream, L);
+    return hipGetLastError();
+}
+
+hipError_t fmd_launch_tile(const FmdLaunch& L, hipStream_t stream)
+{
+    const size_t lds = fmd_tile_lds_bytes(L);
+    const uint64_t blocks = (uint64_t)L.n_channels * L.tiles;
+    if (blocks == 0 || blocks > 0x7FFFFFFFull) return hipErrorInvalidValue;
+    const dim3 g((uint32_t)blocks), b(FMD_BLOCK_THREADS);
+    const uint32_t dh = (L.r.D % 2 == 0) ? L.r.D / 2 : 0;
+    switch (dh) {
+        case 1: hipLaunchKernelGGL(fmd_demod_tile_kernel<1>, g, b, lds, stream, L); break;
+        case 2: hipLaunchKernelGGL(fmd_demod_tile_kernel<2>, g, b, lds, stream, L); break;
+        case 3: hipLaunchKernelGGL(fmd_demod_tile_kernel<3>, g, b, lds, stream, L); break;   // cfg-ref, D = 6
+        case 4: hipLaunchKernelGGL(fmd_demod_tile_kernel<4>, g, b, lds, stream, L); break;
+        case 5: hipLaunchKernelGGL(fmd_demod_tile_kernel<5>, g, b, lds, stream, L); break;   // 2.4 Msps, D = 10
+        default: hipLaunchKernelGGL(fmd_demod_tile_kernel<0>, g, b, lds, stream, L); break;  // generic windows
+    }
     return hipGetLastError();
 }
 

@@ -284,3 +284,46 @@ def test_large_single_channel_call(fmd, oracle):
     rng = np.random.default_rng(5)
     data = rng.integers(0, 256, N, dtype=np.uint8)
     check_stream(fmd, oracle, *CFG_24, [data[None, :]])
+
+
+def test_generic_kernel_forced(fmd, oracle, monkeypatch):
+    """The fallback kernel (in-kernel index divisions; used for > 4 phase classes, tilings that are
+    not a multiple of the reduced resample rate, downsample > 64) stays bit-exact too."""
+    monkeypatch.setenv("FMD_FORCE_GENERIC", "1")
+    rng = np.random.default_rng(31)
+    blocks = [rng.integers(0, 256, (6, 65536), dtype=np.uint8) for _ in range(3)]
+    check_stream(fmd, oracle, *CFG_24, blocks, n_channels=6)
+    check_stream(fmd, oracle, *CFG_REF, blocks, n_channels=6)
+
+
+@pytest.mark.parametrize("nclasses", [2, 4, 7])
+def test_phase_classes(fmd, oracle, nclasses):
+    """Channels with different call-start phases in one bank: <= 4 classes run the tile kernel with a
+    per-channel class table, more fall back to the generic kernel.  Phases are desynchronised the way a
+    caller could: by checkpointing a Demod that has consumed a different amount of input."""
+    D, fast, slow = CFG_REF
+    nch = 12
+    rng = np.random.default_rng(nclasses)
+    cfg = mkcfg(fmd, D, fast, slow)
+    bank = fmd.DemodBank(cfg, nch)
+    obank = oracle.new_bank(oracle.config(D, fast, slow), nch)
+    for c in range(nch):
+        k = c % nclasses
+        if k == 0:
+            continue
+        pre = rng.integers(0, 256, 8 * (40 + 13 * k), dtype=np.uint8)    # different lengths -> different phases
+        oracle.demodulate(obank[c], pre)
+        s = oracle.state_of(obank[c])
+        bank.set_state(c, fmd.DemodState(prev_index=s["prev_index"], now_lpr=s["now_lpr"],
+                                         prev_lpr_index=s["prev_lpr_index"], lp_now_re=s["lp_now"][0],
+                                         lp_now_im=s["lp_now"][1], demod_pre_re=s["demod_pre"][0],
+                                         demod_pre_im=s["demod_pre"][1]))
+    for _ in range(3):
+        iq = rng.integers(0, 256, (nch, 30008), dtype=np.uint8)
+        got = bank.demodulate_batch(iq)
+        exp, lens = oracle.demodulate_batch(obank, iq)
+        for c in range(nch):
+            assert got[c].size == lens[c]
+            assert np.array_equal(got[c], exp[c, :lens[c]]), c
+    for c in range(nch):
+        assert gpu_state(bank, c) == oracle.state_of(obank[c])

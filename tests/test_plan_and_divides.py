@@ -1,0 +1,70 @@
+"""CPU checks of the pieces the production (tile) kernel adds on top of the closed-form model:
+phase-class plans (division-free tile geometry), the exact small divides, and the
+fast_atan2 variant with the f32-reciprocal quotient.  All are shared host/device code in
+rtl-sdr-rs_amd/csrc/fmd_index.h, exercised here through oracle/closed_form.cpp."""
+import ctypes as C
+import math
+
+import numpy as np
+import pytest
+
+
+@pytest.fixture(scope="module")
+def cf(oracle):
+    lib = oracle.lib
+    lib.fmcf_check_plan.argtypes = [C.c_uint32] * 7
+    lib.fmcf_check_plan.restype = C.c_int
+    lib.fmcf_fast_atan2_q.argtypes = [C.c_int32, C.c_int32]
+    lib.fmcf_fast_atan2_q.restype = C.c_int32
+    lib.fmcf_udiv_small.argtypes = [C.c_uint32, C.c_uint32]
+    lib.fmcf_udiv_small.restype = C.c_uint32
+    lib.fmcf_sdiv_small.argtypes = [C.c_int32, C.c_int32]
+    lib.fmcf_sdiv_small.restype = C.c_int32
+    return lib
+
+
+@pytest.mark.parametrize("D,fast,slow", [(6, 170000, 32000), (10, 240000, 32000), (7, 166666, 32000),
+                                         (1, 48000, 48000), (5, 250000, 44100), (8, 128000, 32000),
+                                         (3, 340000, 48000), (2, 1000000, 8000), (21, 50000, 32000)])
+def test_plan_tiles_equal_generic_tiles(cf, D, fast, slow):
+    g = math.gcd(fast, slow)
+    fr, sr = fast // g, slow // g
+    rng = np.random.default_rng(D)
+    for mult in [1, 2, 3, 8]:
+        kt = sr * mult
+        if kt > 4096:
+            continue
+        for _ in range(12):
+            p0 = int(rng.integers(0, D))
+            i0r = int(rng.integers(0, fr))
+            ns = int(rng.integers(2 * D, 200000))
+            assert cf.fmcf_check_plan(D, fast, slow, kt, p0, i0r, ns) == 0, (kt, p0, i0r, ns)
+        # every reachable phase of the reference block size
+        for p0 in range(0, D):
+            assert cf.fmcf_check_plan(D, fast, slow, kt, p0, (p0 * 7) % fr, 131072) == 0
+
+
+def test_fast_atan2_q_equals_reference_form(cf, oracle):
+    rng = np.random.default_rng(1)
+    lim = 2 * (128 * 64) ** 2                       # |c| bound at downsample 64
+    ys = np.concatenate([rng.integers(-lim, lim + 1, 20000), rng.integers(-300, 301, 20000),
+                         np.array([0, 0, 0, 1, -1, 524288, -524288, lim, -lim, lim, 0, 0])])
+    xs = np.concatenate([rng.integers(-lim, lim + 1, 20000), rng.integers(-300, 301, 20000),
+                         np.array([0, 1179648, 524288, 0, 0, 524288, 524287, lim, lim, -lim, -lim, 524287])])
+    for y, x in zip(ys.tolist(), xs.tolist()):
+        assert cf.fmcf_fast_atan2_q(y, x) == oracle.lib.fmo_fast_atan2(y, x), (y, x)
+
+
+def test_small_divides_exact(cf):
+    rng = np.random.default_rng(2)
+    for _ in range(20000):
+        d = int(rng.integers(1, 40000))
+        t = int(rng.integers(0, min(1 << 24, d * 1000)))
+        assert cf.fmcf_udiv_small(t, d) == t // d
+        s = int(rng.integers(-(1 << 23), 1 << 23))
+        r = int(rng.integers(1, 600))
+        q = abs(s) // r
+        assert cf.fmcf_sdiv_small(s, r) == (q if s >= 0 else -q)
+    for d in [1, 2, 3, 5, 7, 16, 85]:
+        for t in list(range(0, 5 * d + 3)) + [d * 1000 - 1, d * 1000, d * 1000 + 1]:
+            assert cf.fmcf_udiv_small(t, d) == t // d
