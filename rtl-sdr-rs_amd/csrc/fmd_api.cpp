@@ -511,7 +511,7 @@ int fmd_demod_tiling(const fmd_demod* d, uint32_t* audio_per_tile, uint32_t* lds
     if (!d) return FMD_ERR_INVALID_ARG;
     if (audio_per_tile) *audio_per_tile = d->r.kt;
     if (lds_bytes) {
-        FmdLaunch L{}; L.raw_cap = d->raw_cap; L.lp_cap = d->lp_cap;
+        FmdLaunch L{}; L.raw_cap = d->raw_cap; L.lp_cap = d->lp_cap; L.fa = d->r.fr / d->r.sr;
         *lds_bytes = (uint32_t)(tile_kernel_ok(d) ? fmd_tile_lds_bytes(L) : fmd_generic_lds_bytes(L));
     }
     if (block_threads) *block_threads = FMD_BLOCK_THREADS;
