@@ -5,7 +5,7 @@ import subprocess
 
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(PKG_DIR)
-SO_PATH = os.path.join(PKG_DIR, "libfmd_hip.so")
+SO_PATH = os.environ.get("FMD_LIB") or os.path.join(PKG_DIR, "libfmd_hip.so")   # FMD_LIB: tuning builds only
 CSRC = os.path.join(PKG_DIR, "csrc")
 
 FMD_OK = 0

@@ -65,6 +65,9 @@ struct fmd_demod {
     int device = 0;
     uint32_t lp_cap = 0, raw_cap = 0;
     bool force_generic = false;
+    int n_cus = 0;                        // compute units of the device
+    int persist_mode = 1;                 // FMD_PERSIST: 1 = persistent kernel when eligible, 0 = one block per tile
+    uint32_t persist_blocks = 0;          // grid of the persistent kernel for the current tiling (0 = not computed)
     FmdChanState* d_state[2] = {nullptr, nullptr};
     int cur = 0;
     uint32_t* d_err = nullptr;
@@ -92,6 +95,7 @@ int choose_tiling(fmd_demod* d, uint32_t kt_req)
         if (kt >= r.sr) kt -= kt % r.sr;
     }
     r.kt = kt;
+    d->persist_blocks = 0;
     d->lp_cap = fmd_tile_lp_cap(r);
     d->raw_cap = fmd_tile_raw_cap(r);
     const size_t lds = (size_t)d->raw_cap + 6u * (size_t)d->lp_cap + 32;
@@ -204,6 +208,9 @@ int enqueue(fmd_demod* d, const void* d_iq, size_t nbytes, void* d_out, size_t o
     L.out_stride = out_cap;
     L.out_len = static_cast<uint32_t*>(d_out_len);
     L.err = d->d_err;
+#ifdef FMD_EXPERIMENT
+    L.dbg = env_u32("FMD_DBG", 0);
+#endif
     if (tile_kernel_ok(d)) {
         const FmdRates& r = d->r;
         L.Qt = fmd_plan_Qt(r);
@@ -221,6 +228,14 @@ int enqueue(fmd_demod* d, const void* d_iq, size_t nbytes, void* d_out, size_t o
                 d->d_chan_class_dirty = false;
             }
             L.chan_class = d->d_chan_class;
+        }
+        if (d->persist_mode && fmd_persist_supports(d->raw_cap)) {
+            if (!d->persist_blocks) {
+                int bpc = (int)env_u32("FMD_BPC", 0);
+                if (bpc <= 0) bpc = fmd_persist_blocks_per_cu(L);
+                if (bpc > 0) d->persist_blocks = (uint32_t)bpc * (uint32_t)d->n_cus;
+            }
+            L.persist_blocks = d->persist_blocks;
         }
         HIP_TRY(fmd_launch_tile(L, stream));
     } else {
@@ -339,6 +354,8 @@ int fmd_demod_new(const fmd_demod_config* config, const fmd_device_config* dev, 
         delete d; return FMD_ERR_NO_DEVICE;
     }
     d->device = device;
+    d->n_cus = prop.multiProcessorCount;
+    d->persist_mode = (int)env_u32("FMD_PERSIST", 1);
     reset_classes(d);
 
     auto fail = [&](hipError_t e, const char* what) {

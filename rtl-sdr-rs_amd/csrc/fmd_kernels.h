@@ -31,6 +31,8 @@ struct FmdLaunch {
     uint64_t out_stride;      // samples
     uint32_t* out_len;        // [n_channels] or nullptr
     uint32_t* err;            // device error word
+    uint32_t dbg;             // ablation bits, honoured only by -DFMD_EXPERIMENT builds (tuning; never shipped)
+    uint32_t persist_blocks;  // > 0: persistent kernel with this many blocks; 0: one block per tile
     // ---- tile kernel only (phase-class plans; see fmd_index.h) ----
     uint32_t Qt;              // decimated samples per full tile = kt * fr / sr
     uint32_t fa, fb;          // fr = fa * sr + fb
@@ -50,6 +52,11 @@ struct FmdSynthLaunch {
 
 // Can the division-free tile kernel run this configuration?  (Otherwise the generic kernel does.)
 bool fmd_tile_kernel_supports(const FmdRates& r, uint32_t raw_cap);
+
+// The persistent kernel prefetches a whole tile in registers: FMD_PERSIST_LOADS x 16 B per lane.
+#define FMD_PERSIST_LOADS 5
+inline bool fmd_persist_supports(uint32_t raw_cap) { return raw_cap <= 16u * FMD_PERSIST_LOADS * FMD_BLOCK_THREADS; }
+int fmd_persist_blocks_per_cu(const FmdLaunch& L);   // occupancy of the persistent kernel for this config
 
 size_t fmd_generic_lds_bytes(const FmdLaunch& L);
 size_t fmd_tile_lds_bytes(const FmdLaunch& L);

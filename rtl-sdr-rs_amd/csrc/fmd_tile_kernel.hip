@@ -1,4 +1,4 @@
-// fmd_tile_kernel.hip -- the production demodulation kernel for gfx950 (CDNA4, wave64).
+// fmd_tile_kernel.hip -- the production demodulation kernels for gfx950 (CDNA4, wave64).
 //
 // One launch fuses every pass of Demod::demodulate (examples/simple_fm.rs:256-269):
 //   rotate_90 (:276-299) + `as i16 - 127` (:258) + buf_to_complex (:441-450)
@@ -10,23 +10,34 @@
 // traffic is the u8 input once (+ a < 1 % tile halo) and the s16 output.  Memory-bound integer
 // streaming: no MFMA.
 //
-// grid = (tiles, channels); a tile is `kt` consecutive audio samples of one channel-call.
-//   * tile geometry: host-made per-phase-class plans (FmdClassPlan, fmd_index.h) -> multiply-adds;
-//   * staging: LDS-DMA (global_load_lds_dwordx4), 1 KiB per wave-instruction, every load of the tile in
-//     flight before the single wait; no VGPR round trip, no ds_write pass;
-//   * boxcar: for an even downsample a window is DH whole dwords, 3 VALU ops per dword (xor, 2 x dot4)
-//     with per-lane weight registers that already carry the rotation sign of the dword parity;
-//   * predecessor sample from the neighbouring lane (DPP wave_shr:1): a wave-round is 63 new windows
-//     + 1 overlap, so there is no LDS exchange and no barrier between boxcar and discriminator;
-//   * discriminator: complex multiply by 2 x v_dot2_i32_i16 on packed (re, im); branch-free
-//     fast_atan2 with an exact f32-reciprocal divide;
-//   * resampler: one audio sample per lane from the tile's discriminator samples in LDS.
+// A tile is `kt` consecutive audio samples of one channel-call; its geometry comes from host-made
+// per-phase-class plans (FmdClassPlan, fmd_index.h), so the device only does multiply-adds.
+//   tile_body (shared):
+//     * boxcar: for an even downsample a window is DH whole dwords, 3 VALU ops per dword (xor, 2 x dot4)
+//       with per-lane weight registers that already carry the rotation sign of the dword parity;
+//     * predecessor sample from the neighbouring lane (DPP wave_shr:1): a wave-round is 63 new windows
+//       + 1 overlap, so there is no LDS exchange and no barrier between boxcar and discriminator;
+//     * discriminator: complex multiply by 2 x v_dot2_i32_i16 on packed (re, im); branch-free
+//       fast_atan2 with an exact f32-reciprocal divide;
+//     * resampler: one audio sample per lane from the tile's discriminator samples in LDS.
+//   fmd_demod_persist_kernel (default): grid = CUs x resident blocks; each block walks tiles
+//     lin, lin + G, ... and keeps the NEXT tile's 16-byte loads in flight in registers while it
+//     computes the current one (issue early / write late), so HBM requests never stop during compute.
+//   fmd_demod_tile_kernel: one block per tile, LDS-DMA staging (global_load_lds_dwordx4); any tile size.
 #include "fmd_device.h"
 #include "fmd_kernels.h"
 
 namespace {
 
 using namespace fmd_dev;
+
+// Ablation switches exist only in -DFMD_EXPERIMENT tuning builds (libfmd_hip_exp.so); the shipped
+// library compiles them to `false`.
+#ifdef FMD_EXPERIMENT
+#define FMD_ABLATE(bit) ((L.dbg >> (bit)) & 1u)
+#else
+#define FMD_ABLATE(bit) false
+#endif
 
 typedef short fmd_s2 __attribute__((ext_vector_type(2)));
 
@@ -72,59 +83,72 @@ __device__ __forceinline__ void lds_dma16(const unsigned char* g, unsigned char*
                                      (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
 
-template <int DH>
-__global__ void __launch_bounds__(FMD_BLOCK_THREADS) fmd_demod_tile_kernel(const FmdLaunch L)
+// Where a tile's bytes are and where they land in LDS (all wave-uniform).
+struct TileCtx {
+    FmdTile T;
+    uint64_t a0;        // 16-byte aligned global address of the first staged chunk
+    uint32_t nchunks;   // 16-byte chunks staged
+    int wofs;           // LDS dword index of the call's dword 0 (may be negative)
+    int jfirst, cnt;    // decimated samples jfirst .. jfirst + cnt - 1 are formed (jfirst == -1: demod_pre)
+    uint32_t c, cls;
+    bool valid;         // false: empty grid slot (t >= the class's tile count)
+    bool whole;         // every staged chunk lies inside the input array
+};
+
+__device__ __forceinline__ TileCtx tile_setup(const FmdLaunch& L, uint32_t c, uint32_t t)
 {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    TileCtx X;
+    X.c = c;
+    X.cls = L.chan_class ? L.chan_class[c] : 0u;
+    const FmdClassPlan& P = L.cls[X.cls];
+    X.valid = t < P.nt;
+    X.T = fmd_tile_fast(L.r, P, L.Qt, L.ns, X.valid ? t : 0u);
+    X.jfirst = X.T.jA - 1;
+    X.cnt = X.T.jB - X.jfirst + 1;
+    const uint64_t gbase = (uint64_t)(uintptr_t)L.iq + (uint64_t)c * L.chan_stride;
+    const uint64_t gLo = gbase + 2ull * (uint32_t)X.T.nLo;
+    const uint64_t gHi = gbase + 2ull * (uint32_t)X.T.nHi;
+    X.a0 = gLo & ~15ull;
+    X.nchunks = (uint32_t)((gHi - X.a0 + 15) >> 4);
+    X.wofs = (int)((int64_t)(gbase - X.a0) >> 2);
+    X.whole = X.a0 + 16ull * X.nchunks <= (uint64_t)(uintptr_t)L.iq + L.total_bytes;
+    return X;
+}
+
+// Synchronous staging for the one tile whose last chunk crosses the end of the input array
+// (array sizes are multiples of 8, chunks of 16).
+__device__ __forceinline__ void stage_slow(const FmdLaunch& L, const TileCtx& X, unsigned char* smem, uint32_t tid)
+{
+    const uint64_t gend = (uint64_t)(uintptr_t)L.iq + L.total_bytes;
+    for (uint32_t i = tid; i < X.nchunks; i += FMD_BLOCK_THREADS) {
+        const uint64_t a = X.a0 + 16ull * i;
+        uint4 v;
+        if (a + 16 <= gend) v = *reinterpret_cast<const uint4*>((uintptr_t)a);
+        else { const uint2 h = *reinterpret_cast<const uint2*>((uintptr_t)a); v = make_uint4(h.x, h.y, 0u, 0u); }
+        reinterpret_cast<uint4*>(smem)[i] = v;
+    }
+}
+
+// Everything after the tile's bytes are visible in LDS.  Contains one __syncthreads().
+template <int DH>
+__device__ __forceinline__ void tile_body(const FmdLaunch& L, const TileCtx& X, unsigned char* smem)
+{
+    const FmdRates& r = L.r;
+    const FmdClassPlan& P = L.cls[X.cls];
+    const FmdTile& T = X.T;
     const uint32_t glen = L.fa + 1u;           // a resampler group spans fa or fa+1 discriminator samples
     const uint32_t d16_bytes = (2u * (L.lp_cap + glen + 1u) + 15u) & ~15u;
-    uint32_t* const raw_w = reinterpret_cast<uint32_t*>(smem);
+    const uint32_t* const raw_w = reinterpret_cast<const uint32_t*>(smem);
     int16_t* const d16 = reinterpret_cast<int16_t*>(smem + L.raw_cap);
     uint32_t* const last_lp = reinterpret_cast<uint32_t*>(smem + L.raw_cap + d16_bytes);
 
     const uint32_t tid = threadIdx.x;
     const uint32_t lane = tid & 63u, wave = tid >> 6;
-    const uint32_t t = blockIdx.x;
-    const uint32_t c = blockIdx.z * 65535u + blockIdx.y;
-    if (c >= L.n_channels) return;
-    const FmdRates r = L.r;
-    const uint32_t cls = L.chan_class ? L.chan_class[c] : 0u;
-    const FmdClassPlan P = L.cls[cls];
-    if (t >= P.nt) return;
-    const FmdTile T = fmd_tile_fast(r, P, L.Qt, L.ns, t);
-    const uint32_t p0 = P.p0;
-    const int jfirst = T.jA - 1;               // lp[jfirst .. jB] are needed; jfirst == -1 is demod_pre
-    const int cnt = T.jB - jfirst + 1;
-
-    // ---- stage the tile's raw bytes: LDS-DMA, all loads in flight, one wait ---------------------
-    const uint64_t gbase = (uint64_t)(uintptr_t)L.iq + (uint64_t)c * L.chan_stride;
-    const uint64_t gLo = gbase + 2ull * (uint32_t)T.nLo;
-    const uint64_t gHi = gbase + 2ull * (uint32_t)T.nHi;
-    const uint64_t a0 = gLo & ~15ull;
-    const uint32_t nchunks = (uint32_t)((gHi - a0 + 15) >> 4);
-    if ((uint32_t)cnt > L.lp_cap || nchunks * 16u > L.raw_cap) {
-        if (tid == 0) atomicOr(L.err, (uint32_t)cnt > L.lp_cap ? FMD_DEVERR_LP_CAP : FMD_DEVERR_RAW_CAP);
-        return;
-    }
-    const uint64_t gend = (uint64_t)(uintptr_t)L.iq + L.total_bytes;
-    if (a0 + 16ull * nchunks <= gend) {
-        const unsigned char* src = reinterpret_cast<const unsigned char*>((uintptr_t)a0) + 16u * tid;
-        unsigned char* dst = smem + 1024u * wave;          // wave-uniform; the hardware adds lane * 16
-        const uint32_t nfull = nchunks >> 8, ntail = nchunks & 255u;
-        for (uint32_t l = 0; l < nfull; ++l) lds_dma16(src + 4096u * l, dst + 4096u * l);
-        if (tid < ntail) lds_dma16(src + 4096u * nfull, dst + 4096u * nfull);
-    } else {   // the whole array ends inside this tile's last chunk (sizes are multiples of 8)
-        for (uint32_t i = tid; i < nchunks; i += FMD_BLOCK_THREADS) {
-            const uint64_t a = a0 + 16ull * i;
-            uint4 v;
-            if (a + 16 <= gend) v = *reinterpret_cast<const uint4*>((uintptr_t)a);
-            else { const uint2 h = *reinterpret_cast<const uint2*>((uintptr_t)a); v = make_uint4(h.x, h.y, 0u, 0u); }
-            reinterpret_cast<uint4*>(smem)[i] = v;
-        }
-    }
-    const int wofs = (int)((int64_t)(gbase - a0) >> 2);      // LDS dword index of the call's dword 0
+    const uint32_t p0 = P.p0, c = X.c;
+    const int jfirst = X.jfirst, cnt = X.cnt, wofs = X.wofs;
     const bool fastwin = DH > 0 && (p0 & 1u) == 0u;          // windows are DH whole dwords
-    const FmdChanState st = L.st_in[c];
+    FmdChanState st{};
+    if (jfirst <= 0 || T.k0 == 0 || T.last) st = L.st_in[c]; // only call-start and call-end tiles need the state
 
     // Lane-constant weights of the fast window.  The window of decimated sample j starts at call dword
     // m0 = DH*j - p0/2; rotate_90's sign pattern has period 2 dwords and a wave-round advances j by an
@@ -136,7 +160,6 @@ __global__ void __launch_bounds__(FMD_BLOCK_THREADS) fmd_demod_tile_kernel(const
     const uint32_t wreA = odd ? FMD_W_RE_ODD : FMD_W_RE_EVEN, wreB = odd ? FMD_W_RE_EVEN : FMD_W_RE_ODD;
     const uint32_t wimA = odd ? FMD_W_IM_ODD : FMD_W_IM_EVEN, wimB = odd ? FMD_W_IM_EVEN : FMD_W_IM_ODD;
     const int im0 = 2 * (odd ? DH / 2 : (DH + 1) / 2);       // +2 per call-even dword; re gets +1 per dword
-    __syncthreads();
 
     // ---- boxcar + discriminator, 63 new decimated samples per wave-round ------------------------
     for (int base = (int)wave * 63; base < cnt; base += NW * 63) {
@@ -144,7 +167,8 @@ __global__ void __launch_bounds__(FMD_BLOCK_THREADS) fmd_demod_tile_kernel(const
         const bool act = i < cnt;
         const int j = jfirst + i;
         int re = 0, im = 0;
-        if (fastwin) {
+        if (FMD_ABLATE(1)) { re = (int)lane; im = j & 255; }              // ablation: no window
+        else if (fastwin) {
             if (act) {
                 const int jj = j < 1 ? 1 : j;
                 const uint32_t* __restrict__ p = raw_w + (wofs + DH * jj - (int)hp);
@@ -174,7 +198,9 @@ __global__ void __launch_bounds__(FMD_BLOCK_THREADS) fmd_demod_tile_kernel(const
         const uint32_t prev = wave_shr1(pk);
         if (act && lane > 0) {
             int cr, cim;
-            int pcm = disc_fast(pk, prev, cr, cim);                              // (:362)
+            int pcm;
+            if (FMD_ABLATE(0)) { pcm = (int)(pk ^ prev); cr = 1; cim = 0; }     // ablation: no discriminator
+            else pcm = disc_fast(pk, prev, cr, cim);                             // (:362)
             if (jfirst < 0 && base == 0 && j == 0) pcm = polar_f64(cr, cim);     // first sample of the call (:359)
             d16[i] = (int16_t)pcm;
         }
@@ -186,6 +212,7 @@ __global__ void __launch_bounds__(FMD_BLOCK_THREADS) fmd_demod_tile_kernel(const
     const uint32_t nk = T.k1 - T.k0;
     int16_t* const outc = L.out + (uint64_t)c * L.out_stride;
     for (uint32_t q = tid; q < nk; q += FMD_BLOCK_THREADS) {
+        if (FMD_ABLATE(2)) { outc[T.k0 + q] = d16[q + 1]; continue; }           // ablation: no resampler
         const int e = (int)(T.eq + q * L.fa + fmd_udiv_small(T.er + q * L.fb, r.sr, L.inv_sr));
         const int s = q == 0 ? T.jA
                              : (int)(T.eq + (q - 1) * L.fa + fmd_udiv_small(T.er + (q - 1) * L.fb, r.sr, L.inv_sr)) + 1;
@@ -217,6 +244,139 @@ __global__ void __launch_bounds__(FMD_BLOCK_THREADS) fmd_demod_tile_kernel(const
     }
 }
 
+__device__ __forceinline__ bool tile_fits(const FmdLaunch& L, const TileCtx& X, uint32_t tid)
+{
+    if ((uint32_t)X.cnt > L.lp_cap || X.nchunks * 16u > L.raw_cap) {
+        if (tid == 0) atomicOr(L.err, (uint32_t)X.cnt > L.lp_cap ? FMD_DEVERR_LP_CAP : FMD_DEVERR_RAW_CAP);
+        return false;
+    }
+    return true;
+}
+
+// ---- one block per tile, LDS-DMA staging ------------------------------------------------------------
+template <int DH>
+__global__ void __launch_bounds__(FMD_BLOCK_THREADS) fmd_demod_tile_kernel(const FmdLaunch L)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const uint32_t tid = threadIdx.x, wave = tid >> 6;
+    const uint32_t c = blockIdx.z * 65535u + blockIdx.y;
+    if (c >= L.n_channels) return;
+    const TileCtx X = tile_setup(L, c, blockIdx.x);
+    if (!X.valid || !tile_fits(L, X, tid)) return;
+    if (X.whole) {
+        // global_load_lds_dwordx4: 1 KiB per wave-instruction straight into the tile image, destination =
+        // wave-uniform base (M0) + lane * 16; no VGPR round trip, no ds_write pass, one wait for all.
+        const unsigned char* src = reinterpret_cast<const unsigned char*>((uintptr_t)X.a0) + 16u * tid;
+        unsigned char* dst = smem + 1024u * wave;
+        const uint32_t nfull = X.nchunks >> 8, ntail = X.nchunks & 255u;
+        for (uint32_t l = 0; l < nfull; ++l) lds_dma16(src + 4096u * l, dst + 4096u * l);
+        if (tid < ntail) lds_dma16(src + 4096u * nfull, dst + 4096u * nfull);
+    } else {
+        stage_slow(L, X, smem, tid);
+    }
+    if (FMD_ABLATE(3)) {                                     // ablation: staging skeleton only
+        __syncthreads();
+        if (tid == 0) L.out[(uint64_t)c * L.out_stride + X.T.k0] = (int16_t)reinterpret_cast<uint32_t*>(smem)[blockIdx.x & 63u];
+        return;
+    }
+    __syncthreads();
+    tile_body<DH>(L, X, smem);
+}
+
+// ---- persistent blocks, next tile's loads in flight during compute ---------------------------------------
+// FMD_PERSIST_LOADS (= 5) x 16 B per lane as NAMED members: hipcc keeps these in VGPRs, whereas a
+// `uint4 v[5]` that is conditionally (re)defined across loop iterations is demoted to scratch.
+struct TileRegs { uint4 a, b, c, d, e; };
+static_assert(FMD_PERSIST_LOADS == 5, "TileRegs holds five 16-byte chunks per lane");
+
+__device__ __forceinline__ TileRegs issue_loads(const TileCtx& X, uint32_t tid)
+{
+    const uint4* src = reinterpret_cast<const uint4*>((uintptr_t)X.a0);
+    const uint32_t lastc = X.nchunks - 1u;                   // surplus lanes re-read the last chunk (in bounds)
+    TileRegs v;
+    uint32_t i;
+    i = tid;                            v.a = src[i < lastc ? i : lastc];
+    i = tid + 1u * FMD_BLOCK_THREADS;   v.b = src[i < lastc ? i : lastc];
+    i = tid + 2u * FMD_BLOCK_THREADS;   v.c = src[i < lastc ? i : lastc];
+    i = tid + 3u * FMD_BLOCK_THREADS;   v.d = src[i < lastc ? i : lastc];
+    i = tid + 4u * FMD_BLOCK_THREADS;   v.e = src[i < lastc ? i : lastc];
+    return v;
+}
+
+__device__ __forceinline__ void write_loads(const TileCtx& X, const TileRegs& v, unsigned char* smem, uint32_t tid)
+{
+    uint4* dst = reinterpret_cast<uint4*>(smem) + tid;
+    const uint32_t n = X.nchunks;
+    if (tid < n) dst[0] = v.a;
+    if (tid + 1u * FMD_BLOCK_THREADS < n) dst[1 * FMD_BLOCK_THREADS] = v.b;
+    if (tid + 2u * FMD_BLOCK_THREADS < n) dst[2 * FMD_BLOCK_THREADS] = v.c;
+    if (tid + 3u * FMD_BLOCK_THREADS < n) dst[3 * FMD_BLOCK_THREADS] = v.d;
+    if (tid + 4u * FMD_BLOCK_THREADS < n) dst[4 * FMD_BLOCK_THREADS] = v.e;
+}
+
+template <int DH>
+__global__ void __launch_bounds__(FMD_BLOCK_THREADS) fmd_demod_persist_kernel(const FmdLaunch L)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const uint32_t tid = threadIdx.x;
+    const uint32_t total = L.tiles * L.n_channels, G = gridDim.x;
+    uint32_t lin = blockIdx.x;
+    if (lin >= total) return;
+    const uint32_t dq = G / L.tiles, dr = G - dq * L.tiles;   // (c, t) step of one grid stride
+    uint32_t c = lin / L.tiles, t = lin - c * L.tiles;
+
+    constexpr uint32_t kMaxChunks = FMD_PERSIST_LOADS * FMD_BLOCK_THREADS;
+    TileRegs v{};
+    {
+        const TileCtx first = tile_setup(L, c, t);
+        if (first.valid && first.whole && first.nchunks <= kMaxChunks) v = issue_loads(first, tid);
+    }
+    for (;;) {
+        // Only (c, t) and the prefetched registers are carried across iterations; the tile context is a few
+        // scalar multiply-adds and is recomputed rather than kept live.
+        const TileCtx cur = tile_setup(L, c, t);
+        if (cur.valid && !tile_fits(L, cur, tid)) return;
+        lin += G; c += dq; t += dr;
+        if (t >= L.tiles) { t -= L.tiles; ++c; }
+        const bool more = lin < total;
+        if (cur.valid) {
+            if (cur.whole && cur.nchunks <= kMaxChunks) write_loads(cur, v, smem, tid);   // loads issued a tile ago
+            else stage_slow(L, cur, smem, tid);
+        }
+        if (more) {
+            const TileCtx nxt = tile_setup(L, c, t);
+            if (nxt.valid && nxt.whole && nxt.nchunks <= kMaxChunks) v = issue_loads(nxt, tid);   // in flight during compute
+        }
+        if (cur.valid) {
+            __syncthreads();
+            if (!FMD_ABLATE(3)) tile_body<DH>(L, cur, smem);
+            __syncthreads();                                          // LDS free for the next tile
+        }
+        if (!more) break;
+    }
+}
+
+template <int DH>
+void launch_one(const FmdLaunch& L, dim3 g, size_t lds, hipStream_t stream)
+{
+    hipLaunchKernelGGL(fmd_demod_tile_kernel<DH>, g, dim3(FMD_BLOCK_THREADS), lds, stream, L);
+}
+
+template <int DH>
+int persist_blocks_per_cu(size_t lds)
+{
+    int nb = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fmd_demod_persist_kernel<DH>, FMD_BLOCK_THREADS, lds) !=
+        hipSuccess) nb = 0;
+    return nb;
+}
+
+template <int DH>
+void launch_persist(const FmdLaunch& L, uint32_t blocks, size_t lds, hipStream_t stream)
+{
+    hipLaunchKernelGGL(fmd_demod_persist_kernel<DH>, dim3(blocks), dim3(FMD_BLOCK_THREADS), lds, stream, L);
+}
+
 }  // namespace
 
 size_t fmd_tile_lds_bytes(const FmdLaunch& L)
@@ -236,21 +396,49 @@ bool fmd_tile_kernel_supports(const FmdRates& r, uint32_t raw_cap)
     return true;
 }
 
+int fmd_persist_blocks_per_cu(const FmdLaunch& L)
+{
+    const size_t lds = fmd_tile_lds_bytes(L);
+    const uint32_t dh = (L.r.D % 2 == 0) ? L.r.D / 2 : 0;
+    switch (dh) {
+        case 1: return persist_blocks_per_cu<1>(lds);
+        case 2: return persist_blocks_per_cu<2>(lds);
+        case 3: return persist_blocks_per_cu<3>(lds);
+        case 4: return persist_blocks_per_cu<4>(lds);
+        case 5: return persist_blocks_per_cu<5>(lds);
+        default: return persist_blocks_per_cu<0>(lds);
+    }
+}
+
 hipError_t fmd_launch_tile(const FmdLaunch& L, hipStream_t stream)
 {
     const size_t lds = fmd_tile_lds_bytes(L);
     if (L.n_channels == 0 || L.tiles == 0) return hipErrorInvalidValue;
+    const uint32_t dh = (L.r.D % 2 == 0) ? L.r.D / 2 : 0;
+    if (L.persist_blocks) {
+        const uint64_t total = (uint64_t)L.tiles * L.n_channels;
+        if (total > 0xFFFFFFFFull) return hipErrorInvalidValue;
+        const uint32_t blocks = total < L.persist_blocks ? (uint32_t)total : L.persist_blocks;
+        switch (dh) {
+            case 1: launch_persist<1>(L, blocks, lds, stream); break;
+            case 2: launch_persist<2>(L, blocks, lds, stream); break;
+            case 3: launch_persist<3>(L, blocks, lds, stream); break;   // cfg-ref, D = 6
+            case 4: launch_persist<4>(L, blocks, lds, stream); break;
+            case 5: launch_persist<5>(L, blocks, lds, stream); break;   // 2.4 Msps, D = 10
+            default: launch_persist<0>(L, blocks, lds, stream); break;  // generic windows
+        }
+        return hipGetLastError();
+    }
     const uint32_t gy = L.n_channels < 65535u ? L.n_channels : 65535u;
     const uint32_t gz = (L.n_channels + 65534u) / 65535u;
-    const dim3 g(L.tiles, gy, gz), b(FMD_BLOCK_THREADS);
-    const uint32_t dh = (L.r.D % 2 == 0) ? L.r.D / 2 : 0;
+    const dim3 g(L.tiles, gy, gz);
     switch (dh) {
-        case 1: hipLaunchKernelGGL(fmd_demod_tile_kernel<1>, g, b, lds, stream, L); break;
-        case 2: hipLaunchKernelGGL(fmd_demod_tile_kernel<2>, g, b, lds, stream, L); break;
-        case 3: hipLaunchKernelGGL(fmd_demod_tile_kernel<3>, g, b, lds, stream, L); break;   // cfg-ref, D = 6
-        case 4: hipLaunchKernelGGL(fmd_demod_tile_kernel<4>, g, b, lds, stream, L); break;
-        case 5: hipLaunchKernelGGL(fmd_demod_tile_kernel<5>, g, b, lds, stream, L); break;   // 2.4 Msps, D = 10
-        default: hipLaunchKernelGGL(fmd_demod_tile_kernel<0>, g, b, lds, stream, L); break;  // generic windows
+        case 1: launch_one<1>(L, g, lds, stream); break;
+        case 2: launch_one<2>(L, g, lds, stream); break;
+        case 3: launch_one<3>(L, g, lds, stream); break;
+        case 4: launch_one<4>(L, g, lds, stream); break;
+        case 5: launch_one<5>(L, g, lds, stream); break;
+        default: launch_one<0>(L, g, lds, stream); break;
     }
     return hipGetLastError();
 }
