@@ -66,6 +66,7 @@ struct fmd_demod {
     uint32_t lp_cap = 0, raw_cap = 0;
     bool force_generic = false;
     int n_cus = 0;                        // compute units of the device
+    uint32_t block_threads = 256;         // FMD_NT: workgroup size of the one-block-per-tile kernel
     int persist_mode = 1;                 // FMD_PERSIST: 1 = persistent kernel when eligible, 0 = one block per tile
     uint32_t persist_blocks = 0;          // grid of the persistent kernel for the current tiling (0 = not computed)
     FmdChanState* d_state[2] = {nullptr, nullptr};
@@ -90,7 +91,7 @@ int choose_tiling(fmd_demod* d, uint32_t kt_req)
         // ~19 KiB of raw IQ per tile (bytes per audio sample = 2 * D * fast / slow), rounded to a
         // multiple of sr so that the division-free tile kernel applies.
         const double per = 2.0 * r.D * (double)r.fr / (double)r.sr;
-        double k = 19456.0 / per;
+        double k = 19456.0 * (double)d->block_threads / 256.0 / per;
         kt = k < 1.0 ? 1u : (k > 1024.0 ? 1024u : (uint32_t)k);
         if (kt >= r.sr) kt -= kt % r.sr;
     }
@@ -229,6 +230,7 @@ int enqueue(fmd_demod* d, const void* d_iq, size_t nbytes, void* d_out, size_t o
             }
             L.chan_class = d->d_chan_class;
         }
+        L.block_threads = d->block_threads;
         if (d->persist_mode && fmd_persist_supports(d->raw_cap)) {
             if (!d->persist_blocks) {
                 int bpc = (int)env_u32("FMD_BPC", 0);
@@ -337,6 +339,8 @@ int fmd_demod_new(const fmd_demod_config* config, const fmd_device_config* dev, 
         delete d; return FMD_ERR_UNSUPPORTED;
     }
     d->force_generic = env_u32("FMD_FORCE_GENERIC", 0) != 0;
+    d->block_threads = env_u32("FMD_NT", 256);
+    if (d->block_threads != 128 && d->block_threads != 512) d->block_threads = 256;
     int rc = choose_tiling(d, env_u32("FMD_KT", 0));
     if (rc) { delete d; return rc; }
 
@@ -355,7 +359,7 @@ int fmd_demod_new(const fmd_demod_config* config, const fmd_device_config* dev, 
     }
     d->device = device;
     d->n_cus = prop.multiProcessorCount;
-    d->persist_mode = (int)env_u32("FMD_PERSIST", 1);
+    d->persist_mode = (int)env_u32("FMD_PERSIST", 0);
     reset_classes(d);
 
     auto fail = [&](hipError_t e, const char* what) {
@@ -370,8 +374,8 @@ int fmd_demod_new(const fmd_demod_config* config, const fmd_device_config* dev, 
         if ((e = hipMalloc(&d->d_state[i], sbytes)) != hipSuccess) return fail(e, "hipMalloc(state)");
         if ((e = hipMemset(d->d_state[i], 0, sbytes)) != hipSuccess) return fail(e, "hipMemset(state)");
     }
-    if ((e = hipMalloc(&d->d_err, sizeof(uint32_t))) != hipSuccess) return fail(e, "hipMalloc(err)");
-    if ((e = hipMemset(d->d_err, 0, sizeof(uint32_t))) != hipSuccess) return fail(e, "hipMemset(err)");
+    if ((e = hipMalloc(&d->d_err, 64)) != hipSuccess) return fail(e, "hipMalloc(err)");
+    if ((e = hipMemset(d->d_err, 0, 64)) != hipSuccess) return fail(e, "hipMemset(err)");
     if ((e = hipStreamCreateWithFlags(&d->stream, hipStreamNonBlocking)) != hipSuccess) return fail(e, "hipStreamCreate");
     if ((e = hipDeviceSynchronize()) != hipSuccess) return fail(e, "hipDeviceSynchronize");
     *out = d;
@@ -531,7 +535,7 @@ int fmd_demod_tiling(const fmd_demod* d, uint32_t* audio_per_tile, uint32_t* lds
         FmdLaunch L{}; L.raw_cap = d->raw_cap; L.lp_cap = d->lp_cap; L.fa = d->r.fr / d->r.sr;
         *lds_bytes = (uint32_t)(tile_kernel_ok(d) ? fmd_tile_lds_bytes(L) : fmd_generic_lds_bytes(L));
     }
-    if (block_threads) *block_threads = FMD_BLOCK_THREADS;
+    if (block_threads) *block_threads = tile_kernel_ok(d) ? d->block_threads : FMD_BLOCK_THREADS;
     return FMD_OK;
 }
 

@@ -33,6 +33,7 @@ struct FmdLaunch {
     uint32_t* err;            // device error word
     uint32_t dbg;             // ablation bits, honoured only by -DFMD_EXPERIMENT builds (tuning; never shipped)
     uint32_t persist_blocks;  // > 0: persistent kernel with this many blocks; 0: one block per tile
+    uint32_t block_threads;   // one-block-per-tile kernel: 128, 256 (default) or 512 threads
     // ---- tile kernel only (phase-class plans; see fmd_index.h) ----
     uint32_t Qt;              // decimated samples per full tile = kt * fr / sr
     uint32_t fa, fb;          // fr = fa * sr + fb

@@ -39,11 +39,32 @@ using namespace fmd_dev;
 #define FMD_ABLATE(bit) false
 #endif
 
+// Explicit address spaces exist only in the device pass (the host pass parses the same bodies).
+#if defined(__HIP_DEVICE_COMPILE__)
+#define FMD_AS_GLOBAL __attribute__((address_space(1)))
+#define FMD_AS_CONSTANT __attribute__((address_space(4)))
+#else
+#define FMD_AS_GLOBAL
+#define FMD_AS_CONSTANT
+#endif
+
 typedef short fmd_s2 __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ uint32_t wave_shr1(uint32_t v)
 {
     return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
+}
+
+// lane l <- v[l-1] for l >= 1; lane 0 keeps old[0] (no source lane, bound_ctrl off).
+__device__ __forceinline__ uint32_t wave_shr1_old(uint32_t old, uint32_t v)
+{
+    return (uint32_t)__builtin_amdgcn_update_dpp((int)old, (int)v, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
+}
+
+// lane l <- v[(l + 63) % 64]: lane 0 receives lane 63.
+__device__ __forceinline__ uint32_t wave_ror1(uint32_t v)
+{
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x13C /* wave_ror:1 */, 0xf, 0xf, false);
 }
 
 __device__ __forceinline__ int sdot2(uint32_t a, uint32_t b)
@@ -55,26 +76,34 @@ __device__ __forceinline__ int sdot2(uint32_t a, uint32_t b)
 // (re | im << 16, components fit i16).  c = a * conj(b) is returned for the f64 sample.
 // Division: |quotient| <= 4097, so an f32 estimate is within 1 and one exact (wrapping) remainder fixes
 // it; valid while x + |y| < 2^30, i.e. downsample <= 64.  Same results as fmd_fast_atan2 (tested).
-__device__ __forceinline__ int disc_fast(uint32_t a, uint32_t b, int& cr, int& ci)
+__device__ __forceinline__ int disc_fast(uint32_t a, uint32_t b)
 {
     const uint32_t a_sw = __builtin_amdgcn_alignbit(a, a, 16);          // (im, re)
     const uint32_t b_cj = (b & 0xFFFFu) | ((0u - (b >> 16)) << 16);      // (re, -im)
-    cr = sdot2(a, b);                                                    // ar*br + ai*bi
-    ci = sdot2(a_sw, b_cj);                                              // ai*br - ar*bi
+    const int cr = sdot2(a, b);                                          // ar*br + ai*bi
+    const int ci = sdot2(a_sw, b_cj);                                    // ai*br - ar*bi
     const uint32_t ux = (uint32_t)cr;
-    const uint32_t yabs = (uint32_t)(ci < 0 ? -ci : ci);
+    const uint32_t my = (uint32_t)(ci >> 31);                            // sign masks: (v ^ m) - m = m ? -v : v
+    const uint32_t yabs = ((uint32_t)ci ^ my) - my;
     const uint32_t dif = ux - yabs, sum = ux + yabs;
     const bool xpos = cr >= 0;
     const int num = (int)((xpos ? dif : sum) << 12);                     // the i64 product truncated to i32 (:397,399)
     const uint32_t den = xpos ? sum : yabs - ux;
-    const uint32_t unum = num < 0 ? 0u - (uint32_t)num : (uint32_t)num;
+    const uint32_t mn = (uint32_t)(num >> 31);
+    const uint32_t unum = ((uint32_t)num ^ mn) - mn;
     uint32_t q = (uint32_t)((float)unum * __builtin_amdgcn_rcpf((float)den));
     const int rem = (int)(unum - q * den);
     q = q + (rem >= (int)den ? 1u : 0u) - (rem < 0 ? 1u : 0u);
-    const int qs = num < 0 ? -(int)q : (int)q;                           // truncating signed quotient
-    int angle = (xpos ? (1 << 12) : (3 << 12)) - qs;
-    angle = ci < 0 ? -angle : angle;
-    return den == 0u ? 0 : angle;                                        // x == 0 && y == 0 (:388)
+    const uint32_t qs = (q ^ mn) - mn;                                   // truncating signed quotient
+    const uint32_t angle = (xpos ? (1u << 12) : (3u << 12)) - qs;
+    const uint32_t res = (angle ^ my) - my;
+    return den == 0u ? 0 : (int)res;                                     // x == 0 && y == 0 (:388)
+}
+
+// (re, im) -> re | im << 16 in one v_perm_b32.
+__device__ __forceinline__ uint32_t pack_lp_perm(int re, int im)
+{
+    return __builtin_amdgcn_perm((uint32_t)im, (uint32_t)re, 0x05040100u);
 }
 
 __device__ __forceinline__ void lds_dma16(const unsigned char* g, unsigned char* lds_wave_base)
@@ -117,10 +146,11 @@ __device__ __forceinline__ TileCtx tile_setup(const FmdLaunch& L, uint32_t c, ui
 
 // Synchronous staging for the one tile whose last chunk crosses the end of the input array
 // (array sizes are multiples of 8, chunks of 16).
+template <int NT>
 __device__ __forceinline__ void stage_slow(const FmdLaunch& L, const TileCtx& X, unsigned char* smem, uint32_t tid)
 {
     const uint64_t gend = (uint64_t)(uintptr_t)L.iq + L.total_bytes;
-    for (uint32_t i = tid; i < X.nchunks; i += FMD_BLOCK_THREADS) {
+    for (uint32_t i = tid; i < X.nchunks; i += NT) {
         const uint64_t a = X.a0 + 16ull * i;
         uint4 v;
         if (a + 16 <= gend) v = *reinterpret_cast<const uint4*>((uintptr_t)a);
@@ -130,17 +160,15 @@ __device__ __forceinline__ void stage_slow(const FmdLaunch& L, const TileCtx& X,
 }
 
 // Everything after the tile's bytes are visible in LDS.  Contains one __syncthreads().
-template <int DH>
+template <int DH, int NT>
 __device__ __forceinline__ void tile_body(const FmdLaunch& L, const TileCtx& X, unsigned char* smem)
 {
     const FmdRates& r = L.r;
     const FmdClassPlan& P = L.cls[X.cls];
     const FmdTile& T = X.T;
     const uint32_t glen = L.fa + 1u;           // a resampler group spans fa or fa+1 discriminator samples
-    const uint32_t d16_bytes = (2u * (L.lp_cap + glen + 1u) + 15u) & ~15u;
     const uint32_t* const raw_w = reinterpret_cast<const uint32_t*>(smem);
     int16_t* const d16 = reinterpret_cast<int16_t*>(smem + L.raw_cap);
-    uint32_t* const last_lp = reinterpret_cast<uint32_t*>(smem + L.raw_cap + d16_bytes);
 
     const uint32_t tid = threadIdx.x;
     const uint32_t lane = tid & 63u, wave = tid >> 6;
@@ -148,70 +176,107 @@ __device__ __forceinline__ void tile_body(const FmdLaunch& L, const TileCtx& X, 
     const int jfirst = X.jfirst, cnt = X.cnt, wofs = X.wofs;
     const bool fastwin = DH > 0 && (p0 & 1u) == 0u;          // windows are DH whole dwords
     FmdChanState st{};
-    if (jfirst <= 0 || T.k0 == 0 || T.last) st = L.st_in[c]; // only call-start and call-end tiles need the state
+    if (jfirst <= 0 || T.k0 == 0 || T.last) {                // only call-start and call-end tiles need the state
+        // st_in is read-only for the whole launch (st_out is the other buffer): constant address space ->
+        // one s_load_dwordx8 on the scalar path, which does not touch vmcnt (the prefetch stays in flight).
+        typedef const FMD_AS_CONSTANT FmdChanState* cptr_t;
+        st = *((cptr_t)(uintptr_t)L.st_in + c);
+    }
 
     // Lane-constant weights of the fast window.  The window of decimated sample j starts at call dword
-    // m0 = DH*j - p0/2; rotate_90's sign pattern has period 2 dwords and a wave-round advances j by an
-    // even number, so the parity of m0 -- hence the weights -- is fixed per lane for the whole tile.
-    constexpr int NW = FMD_BLOCK_THREADS / 64;
+    // m0 = DH*j - p0/2; rotate_90's sign pattern has period 2 dwords, a lane's two windows are 64 samples
+    // apart and a wave-round advances by an even number, so the parity of m0 -- hence the weights -- is
+    // fixed per lane for the whole tile.
+    constexpr int NW = NT / 64;
+    constexpr int RS = 127;                                  // new decimated samples per wave-round
     const uint32_t hp = p0 >> 1;
-    const int j0 = jfirst + (int)wave * 63 + (int)lane;
+    const int j0 = jfirst + (int)wave * RS + (int)lane;
     const bool odd = ((((DH & 1) ? ((uint32_t)j0 ^ hp) : hp)) & 1u) != 0u;
     const uint32_t wreA = odd ? FMD_W_RE_ODD : FMD_W_RE_EVEN, wreB = odd ? FMD_W_RE_EVEN : FMD_W_RE_ODD;
     const uint32_t wimA = odd ? FMD_W_IM_ODD : FMD_W_IM_EVEN, wimB = odd ? FMD_W_IM_EVEN : FMD_W_IM_ODD;
     const int im0 = 2 * (odd ? DH / 2 : (DH + 1) / 2);       // +2 per call-even dword; re gets +1 per dword
+    const int last = cnt - 1;
 
-    // ---- boxcar + discriminator, 63 new decimated samples per wave-round ------------------------
-    for (int base = (int)wave * 63; base < cnt; base += NW * 63) {
-        const int i = base + (int)lane;                      // lane 0 re-does the previous round's last window
-        const bool act = i < cnt;
-        const int j = jfirst + i;
-        int re = 0, im = 0;
-        if (FMD_ABLATE(1)) { re = (int)lane; im = j & 255; }              // ablation: no window
-        else if (fastwin) {
-            if (act) {
-                const int jj = j < 1 ? 1 : j;
-                const uint32_t* __restrict__ p = raw_w + (wofs + DH * jj - (int)hp);
-                re = DH; im = im0;
+    // ---- boxcar + discriminator ------------------------------------------------------------------
+    // A wave-round is 128 windows, two per lane (i and i + 64: two independent dependency chains the
+    // scheduler interleaves), producing 127 new discriminator samples; lane 0's first window repeats the
+    // previous round's last one and only serves as predecessor.
+    if (fastwin) {
+        // Hot loop: no branches, no special cases.  Lanes whose window lies outside the tile (the two
+        // call-start samples of tile 0, surplus lanes of the last round) read whatever LDS holds there --
+        // out-of-range DS reads return 0 -- and their results are either not stored or patched below.
+        const int wbase = wofs - (int)hp + DH * jfirst;      // LDS dword index of window i is wbase + DH * i
+        for (int base = (int)wave * RS; base < last && !FMD_ABLATE(6); base += NW * RS) {
+            const int i1 = base + (int)lane, i2 = i1 + 64;
+            int re1 = DH, im1 = im0, re2 = DH, im2 = im0;
+            if (FMD_ABLATE(1)) { re1 = (int)lane; im1 = i1 & 255; re2 = im1; im2 = re1; }   // ablation: no window
+            else {
+                const uint32_t* __restrict__ pa = raw_w + (uint32_t)(wbase + DH * i1);
+                const uint32_t* __restrict__ pb = raw_w + (uint32_t)(wbase + DH * i2);
 #pragma unroll
                 for (int u = 0; u < (DH > 0 ? DH : 1); ++u) {
-                    const uint32_t w = p[u] ^ 0x80808080u;   // u8 -> s8 (b - 128)
-                    re = sdot4(w, (u & 1) ? wreB : wreA, re);
-                    im = sdot4(w, (u & 1) ? wimB : wimA, im);
+                    const uint32_t wa = pa[u] ^ 0x80808080u, wb = pb[u] ^ 0x80808080u;   // u8 -> s8 (b - 128)
+                    re1 = sdot4(wa, (u & 1) ? wreB : wreA, re1);
+                    im1 = sdot4(wa, (u & 1) ? wimB : wimA, im1);
+                    re2 = sdot4(wb, (u & 1) ? wreB : wreA, re2);
+                    im2 = sdot4(wb, (u & 1) ? wimB : wimA, im2);
                 }
             }
-            if (jfirst <= 0 && base == 0 && act && j <= 0) { // call start: demod_pre / the clipped first window
-                if (j < 0) { re = st.demod_pre_re; im = st.demod_pre_im; }
-                else {
-                    lds_window_sum(raw_w, wofs, 0, fmd_win_end(r.D, p0, 0), re, im);
-                    re += st.lp_now_re; im += st.lp_now_im;
-                }
+            const uint32_t pk1 = pack_lp_perm(re1, im1), pk2 = pack_lp_perm(re2, im2);
+            const uint32_t prev1 = wave_shr1(pk1);           // lane l <- first window of lane l-1
+            const uint32_t prev2 = wave_shr1_old(wave_ror1(pk1), pk2);   // lane l <- second of l-1; lane 0 <- first of 63
+            int d1, d2;
+            if (FMD_ABLATE(0)) { d1 = (int)(pk1 ^ prev1); d2 = (int)(pk2 ^ prev2); }    // ablation: no discriminator
+            else { d1 = disc_fast(pk1, prev1); d2 = disc_fast(pk2, prev2); }            // (:362)
+            if (lane > 0 && i1 < cnt) d16[i1] = (int16_t)d1;
+            if (i2 < cnt) d16[i2] = (int16_t)d2;
+        }
+        // Call start (at most once per channel-call, one lane): lp[-1] is demod_pre, lp[0] is the clipped first
+        // window plus lp_now, d[0] takes the f64 path (:359); d[0] and d[1] are rewritten with them.  Same
+        // wave as the loop's own stores to these entries, so program order makes the patch win.
+        if (jfirst <= 0 && tid == 0) {
+            int r0, i0, r1, i1w, cr, ci;
+            lds_window_sum(raw_w, wofs, 0, fmd_win_end(r.D, p0, 0), r0, i0);
+            r0 += st.lp_now_re; i0 += st.lp_now_im;
+            lds_window_sum(raw_w, wofs, fmd_win_begin(r.D, p0, 1), fmd_win_end(r.D, p0, 1), r1, i1w);
+            if (jfirst < 0) {
+                fmd_mul_conj(r0, i0, st.demod_pre_re, st.demod_pre_im, cr, ci);
+                d16[1] = (int16_t)polar_f64(cr, ci);
             }
-        } else if (act) {
-            if (j < 0) { re = st.demod_pre_re; im = st.demod_pre_im; }
+            fmd_mul_conj(r1, i1w, r0, i0, cr, ci);
+            d16[1 - jfirst] = (int16_t)fmd_fast_atan2(ci, cr);
+        }
+    } else {
+        // Windows that are not whole dwords (odd downsample or odd phase): the general window sum.
+        for (int base = (int)wave * RS; base < last; base += NW * RS) {
+            const int i1 = base + (int)lane, i2 = i1 + 64;
+            const int j1 = jfirst + (i1 < last ? i1 : last), j2 = jfirst + (i2 < last ? i2 : last);
+            int re1, im1, re2, im2;
+            if (j1 < 0) { re1 = st.demod_pre_re; im1 = st.demod_pre_im; }
             else {
-                lds_window_sum(raw_w, wofs, fmd_win_begin(r.D, p0, j), fmd_win_end(r.D, p0, j), re, im);
-                if (j == 0) { re += st.lp_now_re; im += st.lp_now_im; }
+                lds_window_sum(raw_w, wofs, fmd_win_begin(r.D, p0, j1), fmd_win_end(r.D, p0, j1), re1, im1);
+                if (j1 == 0) { re1 += st.lp_now_re; im1 += st.lp_now_im; }
             }
+            lds_window_sum(raw_w, wofs, fmd_win_begin(r.D, p0, j2), fmd_win_end(r.D, p0, j2), re2, im2);   // j2 >= 63
+            const uint32_t pk1 = pack_lp(re1, im1), pk2 = pack_lp(re2, im2);
+            const uint32_t prev1 = wave_shr1(pk1);
+            const uint32_t prev2 = wave_shr1_old(wave_ror1(pk1), pk2);
+            int d1 = disc_fast(pk1, prev1), d2 = disc_fast(pk2, prev2);
+            if (jfirst < 0 && base == 0 && i1 == 1) {        // first sample of the call (:359)
+                int cr, ci;
+                fmd_mul_conj(lp_re(pk1), lp_im(pk1), lp_re(prev1), lp_im(prev1), cr, ci);
+                d1 = polar_f64(cr, ci);
+            }
+            if (lane > 0 && i1 < cnt) d16[i1] = (int16_t)d1;
+            if (i2 < cnt) d16[i2] = (int16_t)d2;
         }
-        const uint32_t pk = pack_lp(re, im);
-        const uint32_t prev = wave_shr1(pk);
-        if (act && lane > 0) {
-            int cr, cim;
-            int pcm;
-            if (FMD_ABLATE(0)) { pcm = (int)(pk ^ prev); cr = 1; cim = 0; }     // ablation: no discriminator
-            else pcm = disc_fast(pk, prev, cr, cim);                             // (:362)
-            if (jfirst < 0 && base == 0 && j == 0) pcm = polar_f64(cr, cim);     // first sample of the call (:359)
-            d16[i] = (int16_t)pcm;
-        }
-        if (T.last && act && j == T.jB) last_lp[0] = pk;
     }
     __syncthreads();
 
     // ---- low_pass_real: one audio sample per lane -------------------------------------------------
-    const uint32_t nk = T.k1 - T.k0;
+    const uint32_t nk = FMD_ABLATE(7) ? 0u : T.k1 - T.k0;
     int16_t* const outc = L.out + (uint64_t)c * L.out_stride;
-    for (uint32_t q = tid; q < nk; q += FMD_BLOCK_THREADS) {
+    for (uint32_t q = tid; q < nk; q += NT) {
         if (FMD_ABLATE(2)) { outc[T.k0 + q] = d16[q + 1]; continue; }           // ablation: no resampler
         const int e = (int)(T.eq + q * L.fa + fmd_udiv_small(T.er + q * L.fb, r.sr, L.inv_sr));
         const int s = q == 0 ? T.jA
@@ -225,7 +290,7 @@ __device__ __forceinline__ void tile_body(const FmdLaunch& L, const TileCtx& X, 
     }
 
     // ---- Demod state after the call (last tile only; :232-239) -------------------------------------
-    if (T.last && tid == 0) {
+    if (T.last && tid == 0 && !FMD_ABLATE(5)) {
         FmdChanState ns_;
         const int s = P.K == 0 ? 0 : (int)fmd_audio_end(r, P.i0r, P.K - 1) + 1;
         int sum = P.K == 0 ? st.now_lpr : 0;
@@ -236,8 +301,9 @@ __device__ __forceinline__ void tile_body(const FmdLaunch& L, const TileCtx& X, 
         int tr, ti;
         lds_window_sum(raw_w, wofs, fmd_win_begin(r.D, p0, (int)P.M), (int)L.ns, tr, ti);
         ns_.lp_now_re = tr; ns_.lp_now_im = ti;
-        const uint32_t l = last_lp[0];                       // lp[M-1]; M >= 2 is guaranteed by the host
-        ns_.demod_pre_re = lp_re(l); ns_.demod_pre_im = lp_im(l);
+        int pr, pi;                                          // demod_pre = lp[M-1]; M >= 2 is guaranteed by the host
+        lds_window_sum(raw_w, wofs, fmd_win_begin(r.D, p0, (int)P.M - 1), fmd_win_end(r.D, p0, (int)P.M - 1), pr, pi);
+        ns_.demod_pre_re = pr; ns_.demod_pre_im = pi;
         ns_.reserved = 0;
         L.st_out[c] = ns_;
         if (L.out_len) L.out_len[c] = P.K;
@@ -254,8 +320,8 @@ __device__ __forceinline__ bool tile_fits(const FmdLaunch& L, const TileCtx& X, 
 }
 
 // ---- one block per tile, LDS-DMA staging ------------------------------------------------------------
-template <int DH>
-__global__ void __launch_bounds__(FMD_BLOCK_THREADS) fmd_demod_tile_kernel(const FmdLaunch L)
+template <int DH, int NT>
+__global__ void __launch_bounds__(NT) fmd_demod_tile_kernel(const FmdLaunch L)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const uint32_t tid = threadIdx.x, wave = tid >> 6;
@@ -263,16 +329,17 @@ __global__ void __launch_bounds__(FMD_BLOCK_THREADS) fmd_demod_tile_kernel(const
     if (c >= L.n_channels) return;
     const TileCtx X = tile_setup(L, c, blockIdx.x);
     if (!X.valid || !tile_fits(L, X, tid)) return;
-    if (X.whole) {
+    if (FMD_ABLATE(4)) {                                     // ablation: no loads at all (compute on LDS garbage)
+    } else if (X.whole) {
         // global_load_lds_dwordx4: 1 KiB per wave-instruction straight into the tile image, destination =
         // wave-uniform base (M0) + lane * 16; no VGPR round trip, no ds_write pass, one wait for all.
         const unsigned char* src = reinterpret_cast<const unsigned char*>((uintptr_t)X.a0) + 16u * tid;
         unsigned char* dst = smem + 1024u * wave;
-        const uint32_t nfull = X.nchunks >> 8, ntail = X.nchunks & 255u;
-        for (uint32_t l = 0; l < nfull; ++l) lds_dma16(src + 4096u * l, dst + 4096u * l);
-        if (tid < ntail) lds_dma16(src + 4096u * nfull, dst + 4096u * nfull);
+        const uint32_t nfull = X.nchunks / NT, ntail = X.nchunks - nfull * NT;
+        for (uint32_t l = 0; l < nfull; ++l) lds_dma16(src + (16u * NT) * l, dst + (16u * NT) * l);
+        if (tid < ntail) lds_dma16(src + (16u * NT) * nfull, dst + (16u * NT) * nfull);
     } else {
-        stage_slow(L, X, smem, tid);
+        stage_slow<NT>(L, X, smem, tid);
     }
     if (FMD_ABLATE(3)) {                                     // ablation: staging skeleton only
         __syncthreads();
@@ -280,7 +347,9 @@ __global__ void __launch_bounds__(FMD_BLOCK_THREADS) fmd_demod_tile_kernel(const
         return;
     }
     __syncthreads();
-    tile_body<DH>(L, X, smem);
+    // (Measured and rejected: touching the lines of a tile 512..3584 dispatch slots ahead to pre-warm
+    //  L2 / Infinity Cache made the launch 4..40 % SLOWER -- the stream is bandwidth-, not latency-bound.)
+    tile_body<DH, NT>(L, X, smem);
 }
 
 // ---- persistent blocks, next tile's loads in flight during compute ---------------------------------------
@@ -291,7 +360,10 @@ static_assert(FMD_PERSIST_LOADS == 5, "TileRegs holds five 16-byte chunks per la
 
 __device__ __forceinline__ TileRegs issue_loads(const TileCtx& X, uint32_t tid)
 {
-    const uint4* src = reinterpret_cast<const uint4*>((uintptr_t)X.a0);
+    // address_space(1): a pointer rebuilt from an integer is "flat" to hipcc, and flat loads also tick
+    // lgkmcnt, so the first LDS wait of the compute phase would drain the prefetch; global loads do not.
+    typedef const FMD_AS_GLOBAL uint4* gptr_t;
+    const gptr_t src = (gptr_t)(uintptr_t)X.a0;
     const uint32_t lastc = X.nchunks - 1u;                   // surplus lanes re-read the last chunk (in bounds)
     TileRegs v;
     uint32_t i;
@@ -341,7 +413,7 @@ __global__ void __launch_bounds__(FMD_BLOCK_THREADS) fmd_demod_persist_kernel(co
         const bool more = lin < total;
         if (cur.valid) {
             if (cur.whole && cur.nchunks <= kMaxChunks) write_loads(cur, v, smem, tid);   // loads issued a tile ago
-            else stage_slow(L, cur, smem, tid);
+            else stage_slow<FMD_BLOCK_THREADS>(L, cur, smem, tid);
         }
         if (more) {
             const TileCtx nxt = tile_setup(L, c, t);
@@ -349,7 +421,7 @@ __global__ void __launch_bounds__(FMD_BLOCK_THREADS) fmd_demod_persist_kernel(co
         }
         if (cur.valid) {
             __syncthreads();
-            if (!FMD_ABLATE(3)) tile_body<DH>(L, cur, smem);
+            if (!FMD_ABLATE(3)) tile_body<DH, FMD_BLOCK_THREADS>(L, cur, smem);
             __syncthreads();                                          // LDS free for the next tile
         }
         if (!more) break;
@@ -359,7 +431,11 @@ __global__ void __launch_bounds__(FMD_BLOCK_THREADS) fmd_demod_persist_kernel(co
 template <int DH>
 void launch_one(const FmdLaunch& L, dim3 g, size_t lds, hipStream_t stream)
 {
-    hipLaunchKernelGGL(fmd_demod_tile_kernel<DH>, g, dim3(FMD_BLOCK_THREADS), lds, stream, L);
+    switch (L.block_threads) {
+        case 128: hipLaunchKernelGGL((fmd_demod_tile_kernel<DH, 128>), g, dim3(128), lds, stream, L); break;
+        case 512: hipLaunchKernelGGL((fmd_demod_tile_kernel<DH, 512>), g, dim3(512), lds, stream, L); break;
+        default:  hipLaunchKernelGGL((fmd_demod_tile_kernel<DH, 256>), g, dim3(256), lds, stream, L); break;
+    }
 }
 
 template <int DH>
