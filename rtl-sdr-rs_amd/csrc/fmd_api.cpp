@@ -91,7 +91,7 @@ int choose_tiling(fmd_demod* d, uint32_t kt_req)
         // ~19 KiB of raw IQ per tile (bytes per audio sample = 2 * D * fast / slow), rounded to a
         // multiple of sr so that the division-free tile kernel applies.
         const double per = 2.0 * r.D * (double)r.fr / (double)r.sr;
-        double k = 19456.0 * (double)d->block_threads / 256.0 / per;
+        double k = 18000.0 * (double)d->block_threads / 256.0 / per;   // tile + discriminator buffer <= 20 KiB: 8 blocks/CU
         kt = k < 1.0 ? 1u : (k > 1024.0 ? 1024u : (uint32_t)k);
         if (kt >= r.sr) kt -= kt % r.sr;
     }
