@@ -151,7 +151,7 @@ def main():
     try:
         with open(os.path.join(ROOT, "profiles", "r01_pmc_summary.json")) as f:
             pmc = json.load(f)
-        if nch == CHANNELS and pmc["hbm_traffic"]["algorithmic_bytes_per_launch"] == alg_bytes:
+        if nch == CHANNELS and abs(pmc["hbm_traffic"]["algorithmic_bytes_per_launch"] - alg_bytes) < 1e-3 * alg_bytes:
             traffic = int(pmc["hbm_traffic"]["bytes_per_launch"])
     except (OSError, KeyError, ValueError):
         pass

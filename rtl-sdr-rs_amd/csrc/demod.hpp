@@ -1,0 +1,93 @@
+// demod.hpp -- C++ host-side mirror of the reference's interface for this path, over the C ABI.
+//
+// The reference is Rust (ccostes/rtl-sdr-rs v0.3.1); this image has no rustc, so the host side above
+// include/fmd.h is C++ with the reference's names and argument meaning (examples/simple_fm.rs):
+//   optimal_settings(freq, rate)              :189-214  -> std::pair<RadioConfig, DemodConfig>
+//   Demod::new(config)                        :243-252  -> fm::Demod(config)
+//   Demod::demodulate(&mut self, Vec<u8>)     :256-269  -> fm::Demod::demodulate(const std::vector<uint8_t>&)
+//   output(Vec<i16>)                          :430-438  -> fm::output(const std::vector<int16_t>&, FILE*)
+// Where the reference panics (len % 8, < 2 decimated samples, rate_out < rate_resample) these throw
+// fm::Error carrying the fmd_status.  Header-only; link with libfmd_hip.so.
+#ifndef FMD_DEMOD_HPP
+#define FMD_DEMOD_HPP
+
+#include <cstdint>
+#include <cstdio>
+#include <stdexcept>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "../../include/fmd.h"
+
+namespace fm {
+
+using RadioConfig = fmd_radio_config;   // simple_fm.rs:173-176
+using DemodConfig = fmd_demod_config;   // simple_fm.rs:179-185
+
+constexpr size_t DEFAULT_BUF_LENGTH = FMD_DEFAULT_BUF_LENGTH;   // src/lib.rs:25
+
+struct Error : std::runtime_error {
+    int status;
+    explicit Error(int s)
+        : std::runtime_error(std::string(fmd_strerror(s)) + ": " + fmd_last_error()), status(s) {}
+};
+
+inline void check(int status) { if (status != FMD_OK) throw Error(status); }
+
+// optimal_settings(freq, rate), simple_fm.rs:189-214 (rate_resample = RATE_RESAMPLE, :27).
+inline std::pair<RadioConfig, DemodConfig> optimal_settings(uint32_t freq, uint32_t rate, uint32_t rate_resample = 32000)
+{
+    RadioConfig r{};
+    DemodConfig d{};
+    check(fmd_optimal_settings(freq, rate, rate_resample, &r, &d));
+    return {r, d};
+}
+
+// struct Demod + impl, simple_fm.rs:232-269: one IQ stream, state carried across calls.
+class Demod {
+public:
+    explicit Demod(const DemodConfig& config, int device_id = -1) : config_(config)
+    {
+        fmd_device_config dev{1u, device_id, 0u};
+        check(fmd_demod_new(&config_, &dev, &h_));
+    }
+    ~Demod() { fmd_demod_free(h_); }
+    Demod(const Demod&) = delete;
+    Demod& operator=(const Demod&) = delete;
+
+    // demodulate(&mut self, buf: Vec<u8>) -> Vec<i16>
+    std::vector<int16_t> demodulate(const std::vector<uint8_t>& buf) { return demodulate(buf.data(), buf.size()); }
+    std::vector<int16_t> demodulate(const uint8_t* buf, size_t len)
+    {
+        std::vector<int16_t> out(fmd_out_cap(&config_, len) + 1);
+        size_t n = 0;
+        check(fmd_demod_demodulate(h_, buf, len, out.data(), out.size(), &n));
+        out.resize(n);
+        return out;
+    }
+
+    fmd_demod_state state()
+    {
+        fmd_demod_state s{};
+        check(fmd_demod_get_state(h_, 0, &s));
+        return s;
+    }
+    void set_state(const fmd_demod_state& s) { check(fmd_demod_set_state(h_, 0, &s)); }
+    const DemodConfig& config() const { return config_; }
+
+private:
+    DemodConfig config_;
+    fmd_demod* h_ = nullptr;
+};
+
+// output(buf: Vec<i16>), simple_fm.rs:430-438: raw native-endian s16 to stdout, flushed.
+inline void output(const std::vector<int16_t>& buf, FILE* f = stdout)
+{
+    if (!buf.empty()) fwrite(buf.data(), sizeof(int16_t), buf.size(), f);
+    fflush(f);
+}
+
+}  // namespace fm
+
+#endif

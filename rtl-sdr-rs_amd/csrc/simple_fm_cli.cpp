@@ -1,0 +1,70 @@
+// simple_fm_cli.cpp -- file mode of the reference's simple_fm example on the GPU path.
+//
+// Mirrors main() of examples/simple_fm.rs with READ_FROM_FILE = true (:65-84): read DEFAULT_BUF_LENGTH
+// (src/lib.rs:25) byte blocks of interleaved u8 IQ from a file (or stdin with "-"), demodulate, write raw
+// s16 mono at the resample rate to stdout -- so the documented pipeline still works:
+//     simple_fm_gpu capture.bin | play -r 32k -t raw -e s -b 16 -c 1 -V1 -      (readme.md:13,17)
+// Defaults are the example's constants: FREQUENCY 94.9 MHz (unused here), SAMPLE_RATE 170 kHz, RATE_RESAMPLE 32 kHz
+// (:25-27) through optimal_settings (:48,189-214).
+//
+// EOF policy (the reference ignores the read count and never terminates at EOF): only COMPLETE
+// blocks are demodulated; a trailing partial block is dropped with a note on stderr.  Logging goes to stderr
+// because stdout carries audio (:37-38).
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#include "demod.hpp"
+
+int main(int argc, char** argv)
+{
+    uint32_t rate = 170000, resample = 32000, freq = 94900000;
+    const char* path = nullptr;
+    for (int i = 1; i < argc; ++i) {
+        if (!strcmp(argv[i], "-s") && i + 1 < argc) rate = (uint32_t)strtoul(argv[++i], nullptr, 10);
+        else if (!strcmp(argv[i], "-r") && i + 1 < argc) resample = (uint32_t)strtoul(argv[++i], nullptr, 10);
+        else if (!strcmp(argv[i], "-f") && i + 1 < argc) freq = (uint32_t)strtoul(argv[++i], nullptr, 10);
+        else if (!strcmp(argv[i], "-h") || !strcmp(argv[i], "--help")) {
+            fprintf(stderr, "usage: %s [-f freq_hz] [-s sample_rate_hz] [-r resample_hz] <capture.bin | ->\n", argv[0]);
+            return 0;
+        } else path = argv[i];
+    }
+    if (!path) { fprintf(stderr, "missing input file (use - for stdin)\n"); return 2; }
+    FILE* in = strcmp(path, "-") ? fopen(path, "rb") : stdin;
+    if (!in) { perror(path); return 2; }
+    try {
+        const auto settings = fm::optimal_settings(freq, rate, resample);
+        const fm::DemodConfig& dc = settings.second;
+        fprintf(stderr, "Oversampling input by: %ux\n", dc.downsample);             // simple_fm.rs:138
+        fprintf(stderr, "Output at %u Hz\n", dc.rate_in);                           // :139
+        fprintf(stderr, "Output scale: %u\n", dc.output_scale);                     // :140
+        fprintf(stderr, "capture_rate: %u capture_freq: %u\n", settings.first.capture_rate, settings.first.capture_freq);
+        fm::Demod demod(dc);
+        std::vector<uint8_t> buf(fm::DEFAULT_BUF_LENGTH);
+        size_t fill = 0, loops = 0;
+        std::chrono::duration<double> total(0);
+        for (;;) {
+            const size_t n = fread(buf.data() + fill, 1, buf.size() - fill, in);
+            fill += n;
+            if (fill < buf.size()) {
+                if (n == 0) break;      // EOF (or error) before a complete block
+                continue;
+            }
+            const auto t0 = std::chrono::steady_clock::now();
+            const std::vector<int16_t> audio = demod.demodulate(buf);              // :80
+            total += std::chrono::steady_clock::now() - t0;
+            fm::output(audio);                                                      // :82
+            ++loops;
+            fill = 0;
+        }
+        if (fill) fprintf(stderr, "dropped %zu trailing bytes (not a complete %zu-byte block)\n", fill, buf.size());
+        if (loops)                                                                  // :162-168
+            fprintf(stderr, "Average processing time: %.2fms (%zu loops)\n", 1e3 * total.count() / (double)loops, loops);
+    } catch (const fm::Error& e) {
+        fprintf(stderr, "error: %s\n", e.what());
+        return 1;
+    }
+    return 0;
+}

@@ -1,0 +1,148 @@
+//! Thin `extern "C"` binding + safe wrapper over `include/fmd.h` (libfmd_hip.so).
+//!
+//! NOT COMPILED IN THIS REPOSITORY'S CI: the build image has no rustc/cargo.  It is the
+//! binding a maintainer of ccostes/rtl-sdr-rs would add so that `examples/simple_fm.rs` can swap its CPU
+//! `Demod` (examples/simple_fm.rs:232-427) for the GPU one without touching `receive()`/`process()`:
+//! the buffers are exactly what `RtlSdr::read_sync` (src/lib.rs:153) fills.
+#![allow(non_camel_case_types)]
+
+use std::ffi::CStr;
+use std::os::raw::{c_char, c_int, c_void};
+
+/// `struct DemodConfig`, examples/simple_fm.rs:179-185 (same field order as `fmd_demod_config`).
+#[repr(C)]
+#[derive(Clone, Copy, Debug, Default)]
+pub struct DemodConfig {
+    pub rate_in: u32,
+    pub rate_out: u32,
+    pub rate_resample: u32,
+    pub downsample: u32,
+    pub output_scale: u32,
+}
+
+/// `struct RadioConfig`, examples/simple_fm.rs:173-176.
+#[repr(C)]
+#[derive(Clone, Copy, Debug, Default)]
+pub struct RadioConfig {
+    pub capture_freq: u32,
+    pub capture_rate: u32,
+}
+
+#[repr(C)]
+#[derive(Clone, Copy, Debug, Default)]
+pub struct DeviceConfig {
+    pub n_channels: u32,
+    pub device_id: i32,
+    pub flags: u32,
+}
+
+/// Mutable fields of `struct Demod`, examples/simple_fm.rs:232-239.
+#[repr(C)]
+#[derive(Clone, Copy, Debug, Default, PartialEq, Eq)]
+pub struct DemodState {
+    pub prev_index: u32,
+    pub now_lpr: i32,
+    pub prev_lpr_index: i32,
+    pub lp_now_re: i32,
+    pub lp_now_im: i32,
+    pub demod_pre_re: i32,
+    pub demod_pre_im: i32,
+}
+
+#[repr(C)]
+pub struct fmd_demod {
+    _private: [u8; 0],
+}
+
+extern "C" {
+    pub fn fmd_optimal_settings(freq: u32, rate: u32, rate_resample: u32, radio: *mut RadioConfig, demod: *mut DemodConfig) -> c_int;
+    pub fn fmd_demod_new(config: *const DemodConfig, dev: *const DeviceConfig, out: *mut *mut fmd_demod) -> c_int;
+    pub fn fmd_demod_free(d: *mut fmd_demod);
+    pub fn fmd_demod_reset(d: *mut fmd_demod) -> c_int;
+    pub fn fmd_demod_demodulate(d: *mut fmd_demod, iq: *const u8, nbytes: usize, out: *mut i16, out_cap: usize, out_len: *mut usize) -> c_int;
+    pub fn fmd_demod_demodulate_batch(d: *mut fmd_demod, iq: *const u8, nbytes: usize, out: *mut i16, out_cap: usize, out_len: *mut usize) -> c_int;
+    pub fn fmd_demod_demodulate_device(d: *mut fmd_demod, d_iq: *const c_void, nbytes: usize, d_out: *mut c_void, out_cap: usize, d_out_len: *mut c_void, stream: *mut c_void) -> c_int;
+    pub fn fmd_demod_last_out_len(d: *const fmd_demod, out_len: *mut usize) -> c_int;
+    pub fn fmd_out_cap(config: *const DemodConfig, nbytes: usize) -> usize;
+    pub fn fmd_demod_get_state(d: *mut fmd_demod, channel: u32, state: *mut DemodState) -> c_int;
+    pub fn fmd_demod_set_state(d: *mut fmd_demod, channel: u32, state: *const DemodState) -> c_int;
+    pub fn fmd_strerror(status: c_int) -> *const c_char;
+    pub fn fmd_last_error() -> *const c_char;
+    pub fn fmd_device_count(count: *mut c_int) -> c_int;
+    pub fn fmd_version() -> c_int;
+}
+
+/// Error in the crate's convention (`src/error.rs:8,40-44`: a Result, never a panic).
+#[derive(Debug)]
+pub struct FmdError {
+    pub status: i32,
+    pub message: String,
+}
+
+impl std::fmt::Display for FmdError {
+    fn fmt(&self, f: &mut std::fmt::Formatter<'_>) -> std::fmt::Result {
+        write!(f, "fmd error {}: {}", self.status, self.message)
+    }
+}
+impl std::error::Error for FmdError {}
+
+pub type Result<T> = std::result::Result<T, FmdError>;
+
+fn check(status: c_int) -> Result<()> {
+    if status == 0 {
+        return Ok(());
+    }
+    let msg = unsafe {
+        format!("{}: {}", CStr::from_ptr(fmd_strerror(status)).to_string_lossy(), CStr::from_ptr(fmd_last_error()).to_string_lossy())
+    };
+    Err(FmdError { status, message: msg })
+}
+
+/// `optimal_settings(freq, rate)`, examples/simple_fm.rs:189-214.
+pub fn optimal_settings(freq: u32, rate: u32, rate_resample: u32) -> Result<(RadioConfig, DemodConfig)> {
+    let (mut r, mut d) = (RadioConfig::default(), DemodConfig::default());
+    check(unsafe { fmd_optimal_settings(freq, rate, rate_resample, &mut r, &mut d) })?;
+    Ok((r, d))
+}
+
+/// Drop-in for the example's `Demod`: `Demod::new(config)` / `demod.demodulate(buf)`.
+pub struct Demod {
+    handle: *mut fmd_demod,
+    pub config: DemodConfig,
+}
+
+// One caller at a time, like `&mut self` in the reference; the handle may move between threads.
+unsafe impl Send for Demod {}
+
+impl Demod {
+    /// examples/simple_fm.rs:243-252
+    pub fn new(config: DemodConfig) -> Result<Self> {
+        let dev = DeviceConfig { n_channels: 1, device_id: -1, flags: 0 };
+        let mut handle: *mut fmd_demod = std::ptr::null_mut();
+        check(unsafe { fmd_demod_new(&config, &dev, &mut handle) })?;
+        Ok(Demod { handle, config })
+    }
+
+    /// examples/simple_fm.rs:256-269.  Where the reference panics (len % 8 != 0, < 2 decimated samples) this
+    /// returns Err.
+    pub fn demodulate(&mut self, buf: Vec<u8>) -> Result<Vec<i16>> {
+        let cap = unsafe { fmd_out_cap(&self.config, buf.len()) } + 1;
+        let mut out = vec![0i16; cap];
+        let mut n: usize = 0;
+        check(unsafe { fmd_demod_demodulate(self.handle, buf.as_ptr(), buf.len(), out.as_mut_ptr(), cap, &mut n) })?;
+        out.truncate(n);
+        Ok(out)
+    }
+
+    pub fn state(&mut self) -> Result<DemodState> {
+        let mut s = DemodState::default();
+        check(unsafe { fmd_demod_get_state(self.handle, 0, &mut s) })?;
+        Ok(s)
+    }
+}
+
+impl Drop for Demod {
+    fn drop(&mut self) {
+        unsafe { fmd_demod_free(self.handle) }
+    }
+}

@@ -1,0 +1,44 @@
+"""GPU check of the simple_fm file-mode equivalent (rtl-sdr-rs_amd/simple_fm_gpu):
+stdout bytes must equal the oracle's file mode over the complete DEFAULT_BUF_LENGTH blocks."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CLI = os.path.join(ROOT, "rtl-sdr-rs_amd", "simple_fm_gpu")
+
+
+def oracle_file_mode(oracle, cfg, data, block):
+    d = oracle.new(cfg)
+    out = np.empty(data.size // 2 + 64, dtype=np.int16)
+    n = oracle.lib.fmo_file_mode(C.byref(d), data.ctypes.data_as(C.POINTER(C.c_uint8)), data.size, block,
+                                 out.ctypes.data_as(C.POINTER(C.c_int16)), out.size)
+    assert n >= 0
+    return out[:n]
+
+
+def test_cli_file_mode_matches_oracle(fmd, oracle, tmp_path):
+    if not os.path.exists(CLI):
+        pytest.fail("simple_fm_gpu not built (run __graft_entry__.build())")
+    N = fmd.DEFAULT_BUF_LENGTH
+    # the synthetic capture at the example's own rate: 1.02 Msps, 170 kHz channel, 75 kHz deviation, 1 kHz tone
+    data = fmd.synth.synth_iq(1, 5 * N + 4096, amplitude=60, dev_q32=int(75000 / 1020000 * 2**32), mod_period=1020)[0]
+    path = tmp_path / "capture.bin"
+    data.tofile(path)
+    p = subprocess.run([CLI, str(path)], capture_output=True, timeout=120)
+    assert p.returncode == 0, p.stderr.decode()
+    got = np.frombuffer(p.stdout, dtype=np.int16)
+    _, cfg = oracle.optimal_settings(94_900_000, 170_000)       # the example's constants, simple_fm.rs:25-27
+    exp = oracle_file_mode(oracle, cfg, data, N)
+    assert got.size == exp.size and np.array_equal(got, exp)
+    assert b"dropped 4096 trailing bytes" in p.stderr           # EOF policy: complete blocks only
+    # and through stdin with other rates
+    p2 = subprocess.run([CLI, "-s", "240000", "-r", "48000", "-"], input=data.tobytes(), capture_output=True, timeout=120)
+    assert p2.returncode == 0, p2.stderr.decode()
+    _, cfg2 = oracle.optimal_settings(94_900_000, 240_000, 48_000)
+    assert np.array_equal(np.frombuffer(p2.stdout, dtype=np.int16), oracle_file_mode(oracle, cfg2, data, N))
