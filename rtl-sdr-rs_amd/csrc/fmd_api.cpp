@@ -65,6 +65,8 @@ struct fmd_demod {
     int device = 0;
     uint32_t lp_cap = 0, raw_cap = 0;
     bool force_generic = false;
+    bool stream_mode = false;             // register-streaming kernel: tiling = its round size
+    uint32_t rounds_per_wave = 7;         // FMD_RPW
     int n_cus = 0;                        // compute units of the device
     uint32_t block_threads = 256;         // FMD_NT: workgroup size of the one-block-per-tile kernel
     int persist_mode = 1;                 // FMD_PERSIST: 1 = persistent kernel when eligible, 0 = one block per tile
@@ -231,6 +233,16 @@ int enqueue(fmd_demod* d, const void* d_iq, size_t nbytes, void* d_out, size_t o
             L.chan_class = d->d_chan_class;
         }
         L.block_threads = d->block_threads;
+        bool even_phases = true;                              // whole-dword windows in every class
+        for (const PhaseClass& pc : d->classes) even_phases &= (pc.p0 % 2 == 0);
+        if (d->stream_mode && even_phases && fmd_stream_kernel_supports(r)) {
+            L.rounds_per_wave = d->rounds_per_wave;
+            L.group_rounds = fmd_stream_group_rounds(r);
+            HIP_TRY(fmd_launch_stream(L, stream));
+            d->cur ^= 1;
+            advance_classes(d, nbytes, plans);
+            return FMD_OK;
+        }
         if (d->persist_mode && fmd_persist_supports(d->raw_cap)) {
             if (!d->persist_blocks) {
                 int bpc = (int)env_u32("FMD_BPC", 0);
@@ -341,7 +353,16 @@ int fmd_demod_new(const fmd_demod_config* config, const fmd_device_config* dev, 
     d->force_generic = env_u32("FMD_FORCE_GENERIC", 0) != 0;
     d->block_threads = env_u32("FMD_NT", 256);
     if (d->block_threads != 128 && d->block_threads != 512) d->block_threads = 256;
-    int rc = choose_tiling(d, env_u32("FMD_KT", 0));
+    // Default data movement: the LDS-tile kernel.  FMD_STREAM=1 selects the register-streaming kernel with the
+    // largest round these rates allow (same results; measured 5-10 % slower in round 1, kept for A/B).
+    uint32_t kt_env = env_u32("FMD_KT", 0);
+    d->rounds_per_wave = env_u32("FMD_RPW", 4);
+    if (d->rounds_per_wave == 0) d->rounds_per_wave = 1;
+    if (kt_env == 0 && env_u32("FMD_STREAM", 0) != 0 && !d->force_generic) {
+        const uint32_t skt = fmd_stream_round_kt(r);
+        if (skt) { kt_env = skt; d->stream_mode = true; }
+    }
+    int rc = choose_tiling(d, kt_env);
     if (rc) { delete d; return rc; }
 
     int ndev = 0;

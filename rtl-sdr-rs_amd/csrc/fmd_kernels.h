@@ -34,6 +34,8 @@ struct FmdLaunch {
     uint32_t dbg;             // ablation bits, honoured only by -DFMD_EXPERIMENT builds (tuning; never shipped)
     uint32_t persist_blocks;  // > 0: persistent kernel with this many blocks; 0: one block per tile
     uint32_t block_threads;   // one-block-per-tile kernel: 128, 256 (default) or 512 threads
+    uint32_t rounds_per_wave; // streaming kernel: consecutive rounds (tiles of kt audio samples) one wave walks
+    uint32_t group_rounds;    // streaming kernel: rounds whose audio samples are produced together (<= 64 / kt)
     // ---- tile kernel only (phase-class plans; see fmd_index.h) ----
     uint32_t Qt;              // decimated samples per full tile = kt * fr / sr
     uint32_t fa, fb;          // fr = fa * sr + fb
@@ -63,6 +65,11 @@ size_t fmd_generic_lds_bytes(const FmdLaunch& L);
 size_t fmd_tile_lds_bytes(const FmdLaunch& L);
 hipError_t fmd_launch_generic(const FmdLaunch& L, hipStream_t stream);
 hipError_t fmd_launch_tile(const FmdLaunch& L, hipStream_t stream);
+// Register-streaming kernel (fmd_stream_kernel.hip): no LDS staging, a wave walks consecutive rounds.
+bool fmd_stream_kernel_supports(const FmdRates& r);       // for r.kt = the round size
+uint32_t fmd_stream_round_kt(const FmdRates& r);          // largest supported round size, 0 = none
+uint32_t fmd_stream_group_rounds(const FmdRates& r);      // rounds per audio group for r.kt
+hipError_t fmd_launch_stream(const FmdLaunch& L, hipStream_t stream);
 hipError_t fmd_launch_synth(const FmdSynthLaunch& S, hipStream_t stream);
 
 #endif

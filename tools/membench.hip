@@ -56,6 +56,42 @@ __global__ void __launch_bounds__(256) k_tile_dma(const unsigned char* __restric
     if (acc == 0x12345678u) sink[0] = acc;
 }
 
+// (d) window-shaped register loads: every lane reads its own two 20-byte windows (stride 20 B across lanes,
+// 64 windows apart) as dwordx4 + dword, `rounds` consecutive 2400-byte rounds per wave, next round's loads
+// issued before the current round is consumed.  No LDS, no barriers.
+template <int DEPTH>
+__global__ void __launch_bounds__(256) k_window_regs(const unsigned char* __restrict__ p, size_t total_rounds, int rounds, unsigned* sink)
+{
+    typedef const __attribute__((address_space(1))) unsigned char* gp;
+    const unsigned lane = threadIdx.x & 63u;
+    const size_t wave = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    size_t r = wave * (size_t)rounds;
+    if (r + (size_t)rounds > total_rounds) return;          // whole spans only (the bench tolerates the missing tail)
+    const gp base = (gp)p + r * 2400 + 20u * lane;
+    const unsigned offB = lane < 57u ? 1280u : 1280u - 20u * (lane - 56u);
+    unsigned acc = 0;
+    typedef unsigned v4u __attribute__((ext_vector_type(4))); v4u a[DEPTH], b[DEPTH]; unsigned a4[DEPTH], b4[DEPTH];
+#pragma unroll
+    for (int d = 0; d < DEPTH; ++d) {
+        const gp q = base + 2400u * d;
+        a[d] = *(const __attribute__((address_space(1))) v4u*)q; a4[d] = *(const __attribute__((address_space(1))) unsigned*)(q + 16);
+        b[d] = *(const __attribute__((address_space(1))) v4u*)(q + offB); b4[d] = *(const __attribute__((address_space(1))) unsigned*)(q + offB + 16);
+    }
+    for (int it = 0; it < rounds; it += DEPTH) {
+#pragma unroll
+        for (int d = 0; d < DEPTH; ++d) {
+            const v4u ca = a[d], cb = b[d]; const unsigned c4 = a4[d], d4 = b4[d];
+            if (it + d + DEPTH < rounds) {
+                const gp q = base + 2400u * (unsigned)(it + d + DEPTH);
+                a[d] = *(const __attribute__((address_space(1))) v4u*)q; a4[d] = *(const __attribute__((address_space(1))) unsigned*)(q + 16);
+                b[d] = *(const __attribute__((address_space(1))) v4u*)(q + offB); b4[d] = *(const __attribute__((address_space(1))) unsigned*)(q + offB + 16);
+            }
+            acc ^= ca.x ^ ca.y ^ ca.z ^ ca.w ^ c4 ^ cb.x ^ cb.y ^ cb.z ^ cb.w ^ d4;
+        }
+    }
+    if (acc == 0x12345678u) sink[0] = acc;
+}
+
 template <typename F>
 static double time_ms(F launch, int iters)
 {
@@ -98,5 +134,17 @@ int main(int argc, char** argv)
     report("tile LDS-DMA 5 x 16 B/lane + barrier", time_ms([&](int i) { hipLaunchKernelGGL(k_tile_dma<5>, dim3(bytes / 20480), dim3(256), 20480, 0, bufs[i % nbuf], sink); }, iters));
     report("tile LDS-DMA 8 x 16 B/lane + barrier", time_ms([&](int i) { hipLaunchKernelGGL(k_tile_dma<8>, dim3(bytes / 32768), dim3(256), 32768, 0, bufs[i % nbuf], sink); }, iters));
     report("tile LDS-DMA 2 x 16 B/lane + barrier", time_ms([&](int i) { hipLaunchKernelGGL(k_tile_dma<2>, dim3(bytes / 8192), dim3(256), 8192, 0, bufs[i % nbuf], sink); }, iters));
+    {
+        const size_t total_rounds = bytes / 2400 - 2;
+        for (int rounds : {8, 16, 32, 110}) {
+            const size_t waves = (total_rounds + rounds - 1) / rounds;
+            const unsigned blocks = (unsigned)((waves + 3) / 4);
+            char nm[80];
+            snprintf(nm, sizeof nm, "window regs stride-20, depth 1, %d rounds/wave", rounds);
+            report(nm, time_ms([&](int i) { hipLaunchKernelGGL(k_window_regs<1>, dim3(blocks), dim3(256), 0, 0, bufs[i % nbuf], total_rounds, rounds, sink); }, iters));
+            snprintf(nm, sizeof nm, "window regs stride-20, depth 2, %d rounds/wave", rounds);
+            report(nm, time_ms([&](int i) { hipLaunchKernelGGL(k_window_regs<2>, dim3(blocks), dim3(256), 0, 0, bufs[i % nbuf], total_rounds, rounds, sink); }, iters));
+        }
+    }
     return 0;
 }
