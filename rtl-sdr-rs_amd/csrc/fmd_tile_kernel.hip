@@ -50,6 +50,11 @@ using namespace fmd_dev;
 
 typedef short fmd_s2 __attribute__((ext_vector_type(2)));
 
+// Cache policy of the staging loads (aux of global_load_lds): 0 = default, 2 = nt (read once, do not keep).
+#ifndef FMD_DMA_AUX
+#define FMD_DMA_AUX 0
+#endif
+
 __device__ __forceinline__ uint32_t wave_shr1(uint32_t v)
 {
     return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
@@ -109,7 +114,7 @@ __device__ __forceinline__ uint32_t pack_lp_perm(int re, int im)
 __device__ __forceinline__ void lds_dma16(const unsigned char* g, unsigned char* lds_wave_base)
 {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
-                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, FMD_DMA_AUX);
 }
 
 // Where a tile's bytes are and where they land in LDS (all wave-uniform).
@@ -166,7 +171,6 @@ __device__ __forceinline__ void tile_body(const FmdLaunch& L, const TileCtx& X, 
     const FmdRates& r = L.r;
     const FmdClassPlan& P = L.cls[X.cls];
     const FmdTile& T = X.T;
-    const uint32_t glen = L.fa + 1u;           // a resampler group spans fa or fa+1 discriminator samples
     const uint32_t* const raw_w = reinterpret_cast<const uint32_t*>(smem);
     int16_t* const d16 = reinterpret_cast<int16_t*>(smem + L.raw_cap);
 
@@ -283,9 +287,16 @@ __device__ __forceinline__ void tile_body(const FmdLaunch& L, const TileCtx& X, 
                              : (int)(T.eq + (q - 1) * L.fa + fmd_udiv_small(T.er + (q - 1) * L.fb, r.sr, L.inv_sr)) + 1;
         int sum = (T.k0 + q == 0) ? st.now_lpr : 0;
         const int16_t* dp = d16 + (s - jfirst);
-        const int n = e - s + 1;                             // <= glen
+        const int n = e - s + 1;                             // fa or fa + 1; only the call's first group can be shorter
+        if (T.k0 == 0 && n < (int)L.fa) {
 #pragma clang loop vectorize(disable)
-        for (int u = 0; u < (int)glen; ++u) { const int v = dp[u]; sum += u < n ? v : 0; }
+            for (int u = 0; u < n; ++u) sum += dp[u];
+        } else {                                             // fa unconditional terms + one optional
+#pragma clang loop vectorize(disable)
+            for (int u = 0; u < (int)L.fa; ++u) sum += dp[u];
+            const int v = dp[L.fa];
+            sum += n > (int)L.fa ? v : 0;
+        }
         outc[T.k0 + q] = (int16_t)fmd_sdiv_small(sum, r.R, L.inv_R);
     }
 
@@ -325,6 +336,9 @@ __global__ void __launch_bounds__(NT) fmd_demod_tile_kernel(const FmdLaunch L)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const uint32_t tid = threadIdx.x, wave = tid >> 6;
+    // A freshly dispatched block's only job is to get its loads out: let it win issue arbitration against the
+    // computing waves of the other resident blocks until the DMAs are queued (measured -1.8 % launch time).
+    __builtin_amdgcn_s_setprio(3);
     const uint32_t c = blockIdx.z * 65535u + blockIdx.y;
     if (c >= L.n_channels) return;
     const TileCtx X = tile_setup(L, c, blockIdx.x);
@@ -349,6 +363,7 @@ __global__ void __launch_bounds__(NT) fmd_demod_tile_kernel(const FmdLaunch L)
     __syncthreads();
     // (Measured and rejected: touching the lines of a tile 512..3584 dispatch slots ahead to pre-warm
     //  L2 / Infinity Cache made the launch 4..40 % SLOWER -- the stream is bandwidth-, not latency-bound.)
+    __builtin_amdgcn_s_setprio(0);
     tile_body<DH, NT>(L, X, smem);
 }
 
