@@ -146,6 +146,31 @@ typedef struct fmd_synth_params {
 int fmd_synth_fill_device(int device_id, void *d_iq, uint32_t n_channels, size_t nbytes,
                           uint64_t sample_offset, const fmd_synth_params *p, void *stream);
 
+/* ---- generalised tapped decimating FIR (SURVEY 8a row G', BASELINE config 4) ----------- */
+/* NOT a reference interface: the reference's only tapped FIR lives in the RTL2832U chip
+ * (src/rtlsdr.rs:525-558).  Definition (also oracle/fm_oracle.h):
+ *     y[m] = sum_{t < n_taps} taps[t] * x[decim * m + t]
+ * over the stream x[n] of rotated (rotate_90, simple_fm.rs:276-299) and centred (`- 127`, :258)
+ * complex samples of one channel, counted from the first sample fed after fmd_fir_new /
+ * fmd_fir_reset; y[m] is produced by the call in which x[decim*m + n_taps - 1] arrives.
+ * With taps = 1...1 and n_taps == decim == downsample it is Demod::low_pass_complex (:337-352).
+ * decim must be even (whole-dword windows), 1 <= n_taps <= 1024, |taps| <= 2047. */
+typedef struct fmd_fir fmd_fir;
+int fmd_fir_new(const int16_t *taps, uint32_t n_taps, uint32_t decim, const fmd_device_config *dev,
+                fmd_fir **out);
+void fmd_fir_free(fmd_fir *f);
+int fmd_fir_reset(fmd_fir *f);
+/* Complex outputs one call of nbytes can produce per channel (upper bound). */
+size_t fmd_fir_out_cap(uint32_t n_taps, uint32_t decim, size_t nbytes);
+/* HOST buffers: iq [n_channels][nbytes]; out [n_channels][out_cap][2] int32 (re, im);
+ * out_len [n_channels] complex samples written. */
+int fmd_fir_filter_batch(fmd_fir *f, const uint8_t *iq, size_t nbytes, int32_t *out, size_t out_cap,
+                         size_t *out_len);
+/* DEVICE buffers with the same layouts, enqueued on `stream` without synchronising; the
+ * per-channel count (identical for all channels) is returned in *out_len_each. */
+int fmd_fir_filter_device(fmd_fir *f, const void *d_iq, size_t nbytes, void *d_out, size_t out_cap,
+                          size_t *out_len_each, void *stream);
+
 /* ---- diagnostics ---------------------------------------------------------------------- */
 const char *fmd_strerror(int status);
 const char *fmd_last_error(void);          /* thread-local detail of the last failure          */

@@ -378,3 +378,63 @@ int fmo_demodulate_batch(fmo_demod *demods, const uint8_t *iq, size_t n_channels
     free(th); free(jobs);
     return err;
 }
+
+/* ---- Row G': generalised tapped decimating FIR (no reference symbol; see fm_oracle.h) ------------- */
+struct fmo_fir {
+    int32_t *taps; uint32_t n_taps, decim;
+    fmo_cplx *hist;       /* the last n_taps - 1 stream samples */
+    uint64_t pos;         /* samples consumed so far */
+};
+
+fmo_fir *fmo_fir_new(const int16_t *taps, uint32_t n_taps, uint32_t decim)
+{
+    if (!taps || n_taps == 0 || decim == 0) return NULL;
+    fmo_fir *f = (fmo_fir *)calloc(1, sizeof(*f));
+    if (!f) return NULL;
+    f->taps = (int32_t *)malloc(n_taps * sizeof(int32_t));
+    f->hist = (fmo_cplx *)calloc(n_taps, sizeof(fmo_cplx));
+    if (!f->taps || !f->hist) { fmo_fir_free(f); return NULL; }
+    for (uint32_t t = 0; t < n_taps; t++) f->taps[t] = taps[t];
+    f->n_taps = n_taps; f->decim = decim; f->pos = 0;
+    return f;
+}
+
+void fmo_fir_free(fmo_fir *f)
+{
+    if (!f) return;
+    free(f->taps); free(f->hist); free(f);
+}
+
+long fmo_fir_filter(fmo_fir *f, const uint8_t *buf_in, size_t len, fmo_cplx *out, size_t out_cap)
+{
+    if (len % 8 != 0) return -1;
+    const size_t ns = len / 2, H = f->n_taps - 1;
+    uint8_t *buf = (uint8_t *)malloc(len ? len : 1);
+    int16_t *sig = (int16_t *)malloc((len ? len : 1) * sizeof(int16_t));
+    fmo_cplx *v = (fmo_cplx *)malloc((H + ns + 1) * sizeof(fmo_cplx));   /* history ++ this call */
+    long n = -5;
+    if (!buf || !sig || !v) goto done;
+    memcpy(buf, buf_in, len);
+    fmo_rotate_90(buf, len);                       /* the rotation phase restarts per call; calls are multiples of */
+    fmo_center(buf, len, sig);                     /* 4 samples, so it equals the stream position mod 4            */
+    memcpy(v, f->hist, H * sizeof(fmo_cplx));
+    fmo_buf_to_complex(sig, len, v + H);
+    {
+        const uint64_t S = f->pos, T = f->n_taps, M = f->decim;
+        const uint64_t m0 = S >= T ? (S - T) / M + 1 : 0;
+        const uint64_t m1 = S + ns >= T ? (S + ns - T) / M + 1 : 0;
+        n = 0;
+        for (uint64_t m = m0; m < m1; m++) {
+            if ((size_t)n >= out_cap) { n = -3; goto done; }
+            const size_t base = (size_t)(M * m + H - S);         /* virtual index of stream sample M*m */
+            int32_t re = 0, im = 0;
+            for (uint32_t t = 0; t < f->n_taps; t++) { re += f->taps[t] * v[base + t].re; im += f->taps[t] * v[base + t].im; }
+            out[n].re = re; out[n].im = im; n++;
+        }
+        memmove(f->hist, v + ns, H * sizeof(fmo_cplx));          /* last H samples of history ++ call */
+        f->pos = S + ns;
+    }
+done:
+    free(buf); free(sig); free(v);
+    return n;
+}

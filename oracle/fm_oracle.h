@@ -118,6 +118,19 @@ double fmo_bench_batch(const fmo_demod_config *config, const uint8_t *iq, size_t
                        size_t calls, size_t block_len, int n_threads, uint64_t *checksum,
                        uint32_t *out_len);
 
+/* ---- Row G' of SURVEY 8a: generalised tapped decimating FIR (BASELINE config 4) -------------------
+ * NOT IN THE REFERENCE (its only tapped FIR is programmed into the RTL2832U, src/rtlsdr.rs:525-558, and
+ * never runs on the host); this is the builder's definition, "parity unpinned" by construction:
+ *     y[m] = sum_{t < n_taps} taps[t] * x[decim * m + t]
+ * over the stream x[n] of rotated + centred complex samples (rotate_90 :276-299, `- 127` :258) counted from
+ * the first sample ever fed; y[m] is emitted by the call in which x[decim*m + n_taps - 1] arrives.  With
+ * taps = 1...1, n_taps = decim = D it is exactly Demod::low_pass_complex (:337-352) -- tested. */
+typedef struct fmo_fir fmo_fir;
+fmo_fir *fmo_fir_new(const int16_t *taps, uint32_t n_taps, uint32_t decim);
+void fmo_fir_free(fmo_fir *f);
+/* Returns the number of complex outputs written (capacity out_cap), -1 len % 8, -3 capacity. */
+long fmo_fir_filter(fmo_fir *f, const uint8_t *buf, size_t len, fmo_cplx *out, size_t out_cap);
+
 /* Test helper: demods[c].demodulate(iq[c]) for c in [0, n_channels), channel-major buffers
  * iq[n_channels][len], out[n_channels][out_cap], out_len[n_channels], over n_threads pthreads.
  * Returns 0 or the first negative fmo_demodulate code. */

@@ -262,6 +262,9 @@ int enqueue(fmd_demod* d, const void* d_iq, size_t nbytes, void* d_out, size_t o
 
 }  // namespace
 
+// Error text for the other translation units of the library (fmd_fir.hip).
+void fmd_internal_set_err(const char* msg) { set_err("%s", msg); }
+
 extern "C" {
 
 int fmd_version(void) { return FMD_VERSION_MAJOR * 1000 + FMD_VERSION_MINOR; }

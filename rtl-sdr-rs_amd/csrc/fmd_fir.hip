@@ -1,0 +1,337 @@
+// fmd_fir.hip -- generalised tapped decimating FIR over the rotated + centred IQ stream (SURVEY 8a row G',
+// BASELINE config 4), gfx950.  Not a reference interface: see include/fmd.h for the definition
+//     y[m] = sum_{t < T} h[t] * x[M*m + t].
+//
+// Data path.  rotate_90 (simple_fm.rs:276-299) + `- 127` (:258) are folded into the taps: for an aligned
+// dword (bytes b0..b3 = two complex samples) whose first sample has stream index = 0 mod 4 ("even" dword)
+//     re = h0*(b0 - 127) + h1*(128 - b3)      im = h0*(b1 - 127) + h1*(b2 - 127)
+// and for the "odd" dword (first sample = 2 mod 4) every sign flips and 127 <-> 128 swap.  So with the bytes
+// zero-extended into 16-bit pairs (one v_perm_b32 each: (b0, b3) and (b1, b2)) a dword costs two
+// v_dot2_i32_i16 against packed tap pairs that already carry the alternating sign, plus one constant per
+// window parity.  Bound: VALU (about 2.5 instructions per tap per output), not HBM -- this kernel exists for
+// LDS-window / tap-table sizing, not for the 70 % HBM target.
+//
+// Streaming state: the last T-1 samples (rounded up to an even count) of every channel live in HBM as raw
+// bytes, double-buffered; the stream position is the same for all channels and is kept on the host.
+#include "../../include/fmd.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <vector>
+
+void fmd_internal_set_err(const char* msg);
+
+namespace {
+
+#if defined(__HIP_DEVICE_COMPILE__)
+#define FMD_AS_GLOBAL __attribute__((address_space(1)))
+#define FMD_AS_CONSTANT __attribute__((address_space(4)))
+#else
+#define FMD_AS_GLOBAL
+#define FMD_AS_CONSTANT
+#endif
+
+constexpr int kFirThreads = 256;
+typedef short fir_s2 __attribute__((ext_vector_type(2)));
+
+struct FirLaunch {
+    const uint32_t* iq;        // [C][stride_w] dwords
+    uint64_t stride_w;         // dwords per channel in this call (= nbytes / 4)
+    const uint32_t* hist_in;   // [C][Hw]
+    uint32_t* hist_out;        // [C][Hw]
+    uint32_t Hw;               // history dwords per channel
+    const uint32_t* wre;       // [NP] packed (h[2i], -h[2i+1]) * (-1)^i
+    const uint32_t* wim;       // [NP] packed (h[2i],  h[2i+1]) * (-1)^i
+    int32_t cre[2], cim[2];    // additive constants by window parity
+    uint32_t NP;               // tap pairs = ceil(T / 2)
+    uint32_t half_M;           // decim / 2 (dwords between consecutive windows)
+    uint32_t out_tile;         // outputs per block
+    uint32_t n_out;            // outputs this call (per channel)
+    uint32_t wd_first;         // virtual dword index of the first output's window
+    uint32_t par_first;        // stream-dword parity of the first output's window (0/1)
+    uint32_t par_step;         // parity step per output: (decim / 2) & 1
+    uint32_t n_channels;
+    int32_t* out;              // [C][out_cap][2]
+    uint64_t out_cap;
+};
+
+__device__ __forceinline__ int sdot2(uint32_t a, uint32_t b, int c)
+{
+    return __builtin_amdgcn_sdot2(__builtin_bit_cast(fir_s2, a), __builtin_bit_cast(fir_s2, b), c, false);
+}
+
+// virtual stream of one channel: history dwords followed by this call's dwords
+__device__ __forceinline__ uint32_t virt_dword(const FirLaunch& L, uint32_t c, uint32_t w)
+{
+    typedef const FMD_AS_GLOBAL uint32_t* gw;
+    if (w < L.Hw) return ((gw)(uintptr_t)L.hist_in)[(uint64_t)c * L.Hw + w];
+    uint64_t k = w - L.Hw;
+    if (k >= L.stride_w) k = L.stride_w - 1;              // the zero-weighted pad sample of an odd tap count
+    return ((gw)(uintptr_t)L.iq)[(uint64_t)c * L.stride_w + k];
+}
+
+__global__ void __launch_bounds__(kFirThreads) fmd_fir_kernel(const FirLaunch L)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+    const uint32_t tid = threadIdx.x;
+    const uint32_t c = blockIdx.y + 65535u * blockIdx.z;
+    if (c >= L.n_channels) return;
+    const uint32_t o0 = blockIdx.x * L.out_tile;
+    if (o0 >= L.n_out) return;
+    const uint32_t no = L.n_out - o0 < L.out_tile ? L.n_out - o0 : L.out_tile;
+    const uint32_t w0 = L.wd_first + o0 * L.half_M;       // first virtual dword of the tile
+    const uint32_t nd = (no - 1) * L.half_M + L.NP;       // dwords the tile's windows cover
+    for (uint32_t i = tid; i < nd; i += kFirThreads) lds[i] = virt_dword(L, c, w0 + i);
+    __syncthreads();
+
+    typedef const FMD_AS_CONSTANT uint32_t* cw;
+    const cw wre = (cw)(uintptr_t)L.wre, wim = (cw)(uintptr_t)L.wim;
+    for (uint32_t o = tid; o < no; o += kFirThreads) {
+        const uint32_t* p = lds + o * L.half_M;
+        int are = 0, aim = 0;
+        for (uint32_t i = 0; i < L.NP; ++i) {
+            const uint32_t w = p[i];
+            const uint32_t pre = __builtin_amdgcn_perm(w, w, 0x0C030C00u);   // (b0, b3) zero-extended to 16 bit
+            const uint32_t pim = __builtin_amdgcn_perm(w, w, 0x0C020C01u);   // (b1, b2)
+            are = sdot2(pre, wre[i], are);
+            aim = sdot2(pim, wim[i], aim);
+        }
+        const uint32_t par = (L.par_first + (o0 + o) * L.par_step) & 1u;
+        const int re = (par ? -are : are) + L.cre[par];
+        const int im = (par ? -aim : aim) + L.cim[par];
+        int2* dst = reinterpret_cast<int2*>(L.out) + ((uint64_t)c * L.out_cap + o0 + o);
+        *dst = make_int2(re, im);
+    }
+}
+
+// hist_out[c][k] = virtual dword (stride_w + k): the last Hw dwords of history ++ call
+__global__ void __launch_bounds__(kFirThreads) fmd_fir_hist_kernel(const FirLaunch L)
+{
+    const uint64_t gid = (uint64_t)blockIdx.x * kFirThreads + threadIdx.x;
+    if (gid >= (uint64_t)L.n_channels * L.Hw) return;
+    const uint32_t c = (uint32_t)(gid / L.Hw), k = (uint32_t)(gid - (uint64_t)c * L.Hw);
+    const uint64_t w = L.stride_w + k;                    // < Hw + stride_w
+    typedef const FMD_AS_GLOBAL uint32_t* gw;
+    uint32_t v;
+    if (w < L.Hw) v = ((gw)(uintptr_t)L.hist_in)[(uint64_t)c * L.Hw + w];
+    else v = ((gw)(uintptr_t)L.iq)[(uint64_t)c * L.stride_w + (w - L.Hw)];
+    L.hist_out[(uint64_t)c * L.Hw + k] = v;
+}
+
+#define FIR_TRY(expr)                                                                       \
+    do {                                                                                    \
+        hipError_t e_ = (expr);                                                             \
+        if (e_ != hipSuccess) {                                                             \
+            char m_[256];                                                                   \
+            snprintf(m_, sizeof m_, "%s failed: %s", #expr, hipGetErrorString(e_));         \
+            fmd_internal_set_err(m_);                                                       \
+            return FMD_ERR_HIP;                                                             \
+        }                                                                                   \
+    } while (0)
+
+}  // namespace
+
+struct fmd_fir {
+    uint32_t T = 0, M = 0, C = 0, NP = 0, Hw = 0;
+    int device = 0;
+    uint64_t pos = 0;                                     // samples consumed per channel
+    uint32_t* d_wre = nullptr; uint32_t* d_wim = nullptr;
+    uint32_t* d_hist[2] = {nullptr, nullptr};
+    int cur = 0;
+    int32_t cre[2] = {0, 0}, cim[2] = {0, 0};
+    hipStream_t stream = nullptr;
+    uint8_t* d_iq = nullptr; size_t d_iq_cap = 0;
+    int32_t* d_out = nullptr; size_t d_out_cap = 0;
+};
+
+namespace {
+
+void fir_counts(const fmd_fir* f, uint64_t ns, uint64_t* m0, uint64_t* m1)
+{
+    const uint64_t S = f->pos, T = f->T, M = f->M;
+    *m0 = S >= T ? (S - T) / M + 1 : 0;
+    *m1 = S + ns >= T ? (S + ns - T) / M + 1 : 0;
+}
+
+int fir_enqueue(fmd_fir* f, const void* d_iq, size_t nbytes, void* d_out, size_t out_cap, size_t* n_each, hipStream_t stream)
+{
+    if (nbytes % 8 != 0) { fmd_internal_set_err("nbytes % 8 != 0"); return FMD_ERR_BAD_LENGTH; }
+    if (nbytes == 0 || nbytes > (1ull << 31)) { fmd_internal_set_err("nbytes out of range"); return FMD_ERR_UNSUPPORTED; }
+    if (((uintptr_t)d_iq & 3u) != 0 || ((uintptr_t)d_out & 7u) != 0) { fmd_internal_set_err("misaligned device buffer"); return FMD_ERR_INVALID_ARG; }
+    const uint64_t ns = nbytes / 2;
+    uint64_t m0, m1;
+    fir_counts(f, ns, &m0, &m1);
+    const uint64_t n_out = m1 - m0;
+    if (n_out > out_cap) { fmd_internal_set_err("out_cap too small"); return FMD_ERR_CAPACITY; }
+    FirLaunch L{};
+    L.iq = static_cast<const uint32_t*>(d_iq);
+    L.stride_w = nbytes / 4;
+    L.hist_in = f->d_hist[f->cur]; L.hist_out = f->d_hist[f->cur ^ 1];
+    L.Hw = f->Hw;
+    L.wre = f->d_wre; L.wim = f->d_wim;
+    L.cre[0] = f->cre[0]; L.cre[1] = f->cre[1]; L.cim[0] = f->cim[0]; L.cim[1] = f->cim[1];
+    L.NP = f->NP; L.half_M = f->M / 2;
+    L.n_out = (uint32_t)n_out; L.n_channels = f->C;
+    L.out = static_cast<int32_t*>(d_out); L.out_cap = out_cap;
+    // first window: stream sample M*m0; virtual sample index = M*m0 - (S - 2*Hw); both even
+    const uint64_t vs0 = f->M * m0 + 2ull * f->Hw - f->pos;
+    L.wd_first = (uint32_t)(vs0 / 2);
+    L.par_first = (uint32_t)((f->M * m0 / 2) & 1u);
+    L.par_step = (f->M / 2) & 1u;
+    // ~18 KB of LDS per tile
+    uint64_t ot = (4500 > L.NP ? (4500 - L.NP) / (L.half_M ? L.half_M : 1) + 1 : 1);
+    if (ot > 1024) ot = 1024;
+    if (ot < 1) ot = 1;
+    L.out_tile = (uint32_t)ot;
+    if (n_out) {
+        const size_t lds = (((size_t)(L.out_tile - 1) * L.half_M + L.NP) * 4 + 15) & ~(size_t)15;
+        const uint32_t gy = f->C < 65535u ? f->C : 65535u, gz = (f->C + 65534u) / 65535u;
+        hipLaunchKernelGGL(fmd_fir_kernel, dim3((uint32_t)((n_out + ot - 1) / ot), gy, gz), dim3(kFirThreads), lds, stream, L);
+        FIR_TRY(hipGetLastError());
+    }
+    if (f->Hw) {
+        const uint64_t th = (uint64_t)f->C * f->Hw;
+        hipLaunchKernelGGL(fmd_fir_hist_kernel, dim3((uint32_t)((th + kFirThreads - 1) / kFirThreads)), dim3(kFirThreads), 0, stream, L);
+        FIR_TRY(hipGetLastError());
+        f->cur ^= 1;
+    }
+    f->pos += ns;
+    if (n_each) *n_each = (size_t)n_out;
+    return FMD_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t fmd_fir_out_cap(uint32_t n_taps, uint32_t decim, size_t nbytes)
+{
+    if (!decim) return 0;
+    (void)n_taps;
+    return nbytes / 2 / decim + 2;
+}
+
+int fmd_fir_new(const int16_t* taps, uint32_t n_taps, uint32_t decim, const fmd_device_config* dev, fmd_fir** out)
+{
+    if (!taps || !dev || !out || dev->n_channels == 0) { fmd_internal_set_err("null / empty argument"); return FMD_ERR_INVALID_ARG; }
+    *out = nullptr;
+    if (n_taps == 0 || n_taps > 1024 || decim == 0 || decim % 2 != 0 || decim > 4096) {
+        fmd_internal_set_err("need 1 <= n_taps <= 1024 and an even 2 <= decim <= 4096");
+        return FMD_ERR_UNSUPPORTED;
+    }
+    for (uint32_t t = 0; t < n_taps; ++t)
+        if (taps[t] > 2047 || taps[t] < -2047) { fmd_internal_set_err("|tap| > 2047"); return FMD_ERR_UNSUPPORTED; }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) { fmd_internal_set_err("no HIP device (this library has no CPU path)"); return FMD_ERR_NO_DEVICE; }
+    int device = dev->device_id;
+    if (device < 0) { if (hipGetDevice(&device) != hipSuccess) device = 0; }
+    hipDeviceProp_t prop;
+    if (device >= ndev || hipGetDeviceProperties(&prop, device) != hipSuccess || strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+        fmd_internal_set_err("device is not a gfx950");
+        return FMD_ERR_NO_DEVICE;
+    }
+    fmd_fir* f = new (std::nothrow) fmd_fir();
+    if (!f) return FMD_ERR_NOMEM;
+    f->T = n_taps; f->M = decim; f->C = dev->n_channels; f->device = device;
+    f->NP = (n_taps + 1) / 2;
+    const uint32_t H = n_taps - 1, Hp = H + (H & 1u);     // history samples, rounded up to whole dwords
+    f->Hw = Hp / 2;
+    // tap pairs with the alternating dword sign folded in, and the additive constants of both window parities
+    std::vector<uint32_t> wre(f->NP), wim(f->NP);
+    int64_t cre[2] = {0, 0}, cim[2] = {0, 0};
+    for (uint32_t i = 0; i < f->NP; ++i) {
+        const int h0 = taps[2 * i], h1 = 2 * i + 1 < n_taps ? taps[2 * i + 1] : 0;
+        const int s = (i & 1u) ? -1 : 1;
+        wre[i] = (uint32_t)(uint16_t)(int16_t)(s * h0) | ((uint32_t)(uint16_t)(int16_t)(-s * h1) << 16);
+        wim[i] = (uint32_t)(uint16_t)(int16_t)(s * h0) | ((uint32_t)(uint16_t)(int16_t)(s * h1) << 16);
+        for (int par = 0; par < 2; ++par) {
+            const bool even = ((i + par) & 1u) == 0;      // stream parity of this dword when the window starts at `par`
+            if (even) { cre[par] += -127 * h0 + 128 * h1; cim[par] += -127 * (h0 + h1); }
+            else      { cre[par] += 128 * h0 - 127 * h1;  cim[par] += 128 * (h0 + h1); }
+        }
+    }
+    for (int par = 0; par < 2; ++par) { f->cre[par] = (int32_t)cre[par]; f->cim[par] = (int32_t)cim[par]; }
+    auto fail = [&](const char* what) { fmd_internal_set_err(what); fmd_fir_free(f); return FMD_ERR_HIP; };
+    if (hipSetDevice(device) != hipSuccess) return fail("hipSetDevice");
+    if (hipMalloc(&f->d_wre, f->NP * 4) != hipSuccess || hipMalloc(&f->d_wim, f->NP * 4) != hipSuccess) return fail("hipMalloc(taps)");
+    if (hipMemcpy(f->d_wre, wre.data(), f->NP * 4, hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(f->d_wim, wim.data(), f->NP * 4, hipMemcpyHostToDevice) != hipSuccess) return fail("hipMemcpy(taps)");
+    const size_t hb = (size_t)f->C * (f->Hw ? f->Hw : 1) * 4;
+    for (int i = 0; i < 2; ++i) {
+        if (hipMalloc(&f->d_hist[i], hb) != hipSuccess) return fail("hipMalloc(history)");
+        if (hipMemset(f->d_hist[i], 0, hb) != hipSuccess) return fail("hipMemset(history)");
+    }
+    if (hipStreamCreateWithFlags(&f->stream, hipStreamNonBlocking) != hipSuccess) return fail("hipStreamCreate");
+    if (hipDeviceSynchronize() != hipSuccess) return fail("hipDeviceSynchronize");
+    *out = f;
+    return FMD_OK;
+}
+
+void fmd_fir_free(fmd_fir* f)
+{
+    if (!f) return;
+    (void)hipSetDevice(f->device);
+    (void)hipDeviceSynchronize();
+    if (f->d_wre) (void)hipFree(f->d_wre);
+    if (f->d_wim) (void)hipFree(f->d_wim);
+    for (int i = 0; i < 2; ++i) if (f->d_hist[i]) (void)hipFree(f->d_hist[i]);
+    if (f->d_iq) (void)hipFree(f->d_iq);
+    if (f->d_out) (void)hipFree(f->d_out);
+    if (f->stream) (void)hipStreamDestroy(f->stream);
+    delete f;
+}
+
+int fmd_fir_reset(fmd_fir* f)
+{
+    if (!f) return FMD_ERR_INVALID_ARG;
+    FIR_TRY(hipSetDevice(f->device));
+    FIR_TRY(hipDeviceSynchronize());
+    const size_t hb = (size_t)f->C * (f->Hw ? f->Hw : 1) * 4;
+    FIR_TRY(hipMemset(f->d_hist[0], 0, hb));
+    FIR_TRY(hipMemset(f->d_hist[1], 0, hb));
+    FIR_TRY(hipDeviceSynchronize());
+    f->pos = 0; f->cur = 0;
+    return FMD_OK;
+}
+
+int fmd_fir_filter_device(fmd_fir* f, const void* d_iq, size_t nbytes, void* d_out, size_t out_cap, size_t* out_len_each,
+                          void* stream)
+{
+    if (!f || !d_iq || !d_out) { fmd_internal_set_err("null argument"); return FMD_ERR_INVALID_ARG; }
+    FIR_TRY(hipSetDevice(f->device));
+    return fir_enqueue(f, d_iq, nbytes, d_out, out_cap, out_len_each, static_cast<hipStream_t>(stream));
+}
+
+int fmd_fir_filter_batch(fmd_fir* f, const uint8_t* iq, size_t nbytes, int32_t* out, size_t out_cap, size_t* out_len)
+{
+    if (!f || !iq || !out || !out_len) { fmd_internal_set_err("null argument"); return FMD_ERR_INVALID_ARG; }
+    FIR_TRY(hipSetDevice(f->device));
+    if (nbytes % 8 != 0) { fmd_internal_set_err("nbytes % 8 != 0"); return FMD_ERR_BAD_LENGTH; }
+    uint64_t m0, m1;
+    fir_counts(f, nbytes / 2, &m0, &m1);
+    if (m1 - m0 > out_cap) { fmd_internal_set_err("out_cap too small"); return FMD_ERR_CAPACITY; }
+    const size_t in_bytes = nbytes * (size_t)f->C, out_elems = out_cap * (size_t)f->C * 2;
+    if (in_bytes > f->d_iq_cap) {
+        if (f->d_iq) { FIR_TRY(hipFree(f->d_iq)); f->d_iq = nullptr; f->d_iq_cap = 0; }
+        FIR_TRY(hipMalloc(&f->d_iq, in_bytes ? in_bytes : 1));
+        f->d_iq_cap = in_bytes;
+    }
+    if (out_elems > f->d_out_cap) {
+        if (f->d_out) { FIR_TRY(hipFree(f->d_out)); f->d_out = nullptr; f->d_out_cap = 0; }
+        FIR_TRY(hipMalloc(&f->d_out, (out_elems ? out_elems : 1) * sizeof(int32_t)));
+        f->d_out_cap = out_elems;
+    }
+    FIR_TRY(hipMemcpyAsync(f->d_iq, iq, in_bytes, hipMemcpyHostToDevice, f->stream));
+    size_t n = 0;
+    int rc = fir_enqueue(f, f->d_iq, nbytes, f->d_out, out_cap, &n, f->stream);
+    if (rc) return rc;
+    if (n) FIR_TRY(hipMemcpy2DAsync(out, out_cap * 8, f->d_out, out_cap * 8, n * 8, f->C, hipMemcpyDeviceToHost, f->stream));
+    FIR_TRY(hipStreamSynchronize(f->stream));
+    for (uint32_t c = 0; c < f->C; ++c) out_len[c] = n;
+    return FMD_OK;
+}
+
+}  // extern "C"

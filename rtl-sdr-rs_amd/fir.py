@@ -1,0 +1,49 @@
+"""Host-side wrapper of the generalised tapped decimating FIR (include/fmd.h, SURVEY 8a row G').
+
+Not a reference interface (the reference's only tapped FIR runs inside the RTL2832U, src/rtlsdr.rs:525-558):
+y[m] = sum_t taps[t] * x[decim*m + t] over the rotated + centred IQ stream of each channel.
+"""
+import ctypes as C
+
+import numpy as np
+
+from ._ffi import DeviceConfig, check, lib
+
+
+class FirBank:
+    def __init__(self, taps, decim, n_channels=1, device_id=-1):
+        self.taps = np.ascontiguousarray(taps, dtype=np.int16)
+        self.decim, self.n_channels = int(decim), int(n_channels)
+        self._h = C.c_void_p()
+        dev = DeviceConfig(self.n_channels, device_id, 0)
+        check(lib().fmd_fir_new(self.taps.ctypes.data_as(C.POINTER(C.c_int16)), self.taps.size, self.decim,
+                                C.byref(dev), C.byref(self._h)))
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h:
+            lib().fmd_fir_free(self._h)
+            self._h = C.c_void_p()
+
+    __del__ = close
+
+    def reset(self):
+        check(lib().fmd_fir_reset(self._h))
+
+    def out_cap(self, nbytes):
+        return int(lib().fmd_fir_out_cap(self.taps.size, self.decim, nbytes))
+
+    def filter_batch(self, iq):
+        """iq uint8 [n_channels, nbytes] -> int32 array [n_channels, n_out, 2] (re, im)."""
+        iq = np.ascontiguousarray(iq, dtype=np.uint8)
+        if iq.ndim != 2 or iq.shape[0] != self.n_channels:
+            raise ValueError("iq must be [n_channels, nbytes]")
+        cap = max(1, self.out_cap(iq.shape[1]))
+        out = np.empty((self.n_channels, cap, 2), dtype=np.int32)
+        lens = (C.c_size_t * self.n_channels)()
+        check(lib().fmd_fir_filter_batch(self._h, iq.ctypes.data, iq.shape[1], out.ctypes.data, cap, lens))
+        return out[:, :lens[0], :].copy()
+
+    def filter_device(self, d_iq, nbytes, d_out, out_cap, stream=None):
+        n = C.c_size_t(0)
+        check(lib().fmd_fir_filter_device(self._h, d_iq, nbytes, d_out, out_cap, C.byref(n), stream))
+        return n.value

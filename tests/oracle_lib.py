@@ -81,6 +81,12 @@ class Oracle:
         lib.fmo_demodulate_batch.argtypes = [C.POINTER(Demod), u8p, C.c_size_t, C.c_size_t, i16p, C.c_size_t,
                                              C.POINTER(C.c_uint32), C.c_int]
         lib.fmo_demodulate_batch.restype = C.c_int
+        lib.fmo_fir_new.argtypes = [i16p, C.c_uint32, C.c_uint32]
+        lib.fmo_fir_new.restype = C.c_void_p
+        lib.fmo_fir_free.argtypes = [C.c_void_p]
+        lib.fmo_fir_free.restype = None
+        lib.fmo_fir_filter.argtypes = [C.c_void_p, u8p, C.c_size_t, C.POINTER(Cplx), C.c_size_t]
+        lib.fmo_fir_filter.restype = C.c_long
         lib.fmcf_demodulate.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(ChanState),
                                         u8p, C.c_size_t, i16p, C.c_size_t]
         lib.fmcf_demodulate.restype = C.c_long
@@ -122,6 +128,21 @@ class Oracle:
         outs = [self.demodulate(d, data[o:o + block_len])
                 for o in range(0, data.size - block_len + 1, block_len)]
         return (np.concatenate(outs) if outs else np.empty(0, np.int16)), d
+
+    def fir_new(self, taps, decim):
+        taps = np.ascontiguousarray(taps, dtype=np.int16)
+        h = self.lib.fmo_fir_new(taps.ctypes.data_as(C.POINTER(C.c_int16)), taps.size, decim)
+        assert h
+        return h
+
+    def fir_filter(self, h, buf):
+        """-> int32 array [n_out, 2]"""
+        buf = np.ascontiguousarray(buf, dtype=np.uint8)
+        out = (Cplx * (buf.size // 2 + 8))()
+        n = self.lib.fmo_fir_filter(h, buf.ctypes.data_as(C.POINTER(C.c_uint8)), buf.size, out, len(out))
+        if n < 0:
+            raise ValueError("fmo_fir_filter -> %d" % n)
+        return np.array([[out[i].re, out[i].im] for i in range(n)], dtype=np.int32).reshape(-1, 2)
 
     def new_bank(self, cfg, n):
         bank = (Demod * n)()

@@ -1,0 +1,113 @@
+"""Row G' (SURVEY 8a): generalised tapped decimating FIR.  No reference counterpart exists, so the anchor is the
+reduction the survey demands: with taps = 1...1 and n_taps == decim == downsample the FIR must reproduce
+Demod::low_pass_complex (simple_fm.rs:337-352) exactly, including its phase/partial-sum carry across calls.
+CPU: the oracle FIR against the oracle boxcar and against a numpy convolution.  GPU: HIP FIR against the oracle FIR."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import oracle_lib
+
+
+def rotated_stream(oracle, data):
+    """rotate_90 + centre + pair of a whole stream (call lengths are multiples of 8 bytes, so per-call rotation
+    equals whole-stream rotation)."""
+    buf = np.ascontiguousarray(data, dtype=np.uint8).copy()
+    assert oracle.lib.fmo_rotate_90(buf.ctypes.data_as(C.POINTER(C.c_uint8)), buf.size) == 0
+    s = buf.astype(np.int64) - 127
+    return s[0::2], s[1::2]
+
+
+def boxcar_oracle(oracle, D, chunks):
+    d = oracle.new(oracle.config(D, 48000, 48000))
+    outs = []
+    for ch in chunks:
+        buf = np.ascontiguousarray(ch, dtype=np.uint8).copy()
+        oracle.lib.fmo_rotate_90(buf.ctypes.data_as(C.POINTER(C.c_uint8)), buf.size)
+        sig = np.empty(buf.size, dtype=np.int16)
+        oracle.lib.fmo_center(buf.ctypes.data_as(C.POINTER(C.c_uint8)), buf.size, sig.ctypes.data_as(C.POINTER(C.c_int16)))
+        cplx = (oracle_lib.Cplx * (buf.size // 2))()
+        n = oracle.lib.fmo_buf_to_complex(sig.ctypes.data_as(C.POINTER(C.c_int16)), sig.size, cplx)
+        out = (oracle_lib.Cplx * (n // D + 2))()
+        m = oracle.lib.fmo_low_pass_complex(C.byref(d), cplx, n, out)
+        outs.extend([out[i].re, out[i].im] for i in range(m))
+    return np.array(outs, dtype=np.int64).reshape(-1, 2)
+
+
+@pytest.mark.parametrize("D", [2, 6, 10, 16])
+def test_oracle_fir_all_ones_is_low_pass_complex(oracle, D):
+    rng = np.random.default_rng(D)
+    chunks = [rng.integers(0, 256, int(n) * 8, dtype=np.uint8) for n in rng.integers(1, 60, 6)]
+    h = oracle.fir_new(np.ones(D, np.int16), D)
+    got = np.concatenate([oracle.fir_filter(h, ch) for ch in chunks])
+    oracle.lib.fmo_fir_free(h)
+    exp = boxcar_oracle(oracle, D, chunks)
+    assert got.shape == exp.shape and np.array_equal(got, exp)
+
+
+@pytest.mark.parametrize("T,M", [(127, 8), (5, 2), (16, 16), (33, 4), (1, 2), (64, 6)])
+def test_oracle_fir_equals_numpy_convolution(oracle, T, M):
+    rng = np.random.default_rng(T * 100 + M)
+    taps = rng.integers(-2047, 2048, T).astype(np.int16)
+    chunks = [rng.integers(0, 256, int(n) * 8, dtype=np.uint8) for n in rng.integers(1, 120, 5)]
+    h = oracle.fir_new(taps, M)
+    got = np.concatenate([oracle.fir_filter(h, ch) for ch in chunks] + [np.empty((0, 2), np.int32)])
+    oracle.lib.fmo_fir_free(h)
+    re, im = rotated_stream(oracle, np.concatenate(chunks))
+    n_out = (re.size - T) // M + 1 if re.size >= T else 0
+    exp = np.array([[int(np.dot(taps.astype(np.int64), re[M * m: M * m + T])),
+                     int(np.dot(taps.astype(np.int64), im[M * m: M * m + T]))] for m in range(n_out)], dtype=np.int64).reshape(-1, 2)
+    assert got.shape == exp.shape and np.array_equal(got, exp)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("T,M", [(127, 8), (6, 6), (10, 10), (5, 2), (16, 16), (33, 4), (1, 2), (64, 6), (255, 32)])
+def test_gpu_fir_matches_oracle(fmd, oracle, T, M):
+    rng = np.random.default_rng(T * 7 + M)
+    taps = np.ones(T, np.int16) if T == M else rng.integers(-2047, 2048, T).astype(np.int16)
+    nch = 5
+    bank = fmd.FirBank(taps, M, nch)
+    hs = [oracle.fir_new(taps, M) for _ in range(nch)]
+    for call in range(5):
+        n = int(rng.integers(1, 400)) * 8 if call else 8          # a first call too short to emit anything
+        iq = rng.integers(0, 256, (nch, n), dtype=np.uint8)
+        if call == 2:
+            iq[:] = np.where(rng.integers(0, 2, (nch, n)) > 0, 255, 0)   # full scale
+        got = bank.filter_batch(iq)
+        for c in range(nch):
+            exp = oracle.fir_filter(hs[c], iq[c])
+            assert got[c].shape == exp.shape, (call, c, got[c].shape, exp.shape)
+            assert np.array_equal(got[c], exp), (call, c)
+    for h in hs:
+        oracle.lib.fmo_fir_free(h)
+    bank.reset()
+    assert bank.filter_batch(np.zeros((nch, 8), np.uint8)).shape[1] == ((4 - T) // M + 1 if T <= 4 else 0)   # after reset
+
+
+@pytest.mark.gpu
+def test_gpu_fir_config4_shape(fmd, oracle):
+    """BASELINE configs[3] shape: 127 taps, decimate by 8, 2 MiB per channel-call (52.4 ms at 20 Msps); 8 of the
+    256 channels here, compared exactly."""
+    rng = np.random.default_rng(4)
+    taps = rng.integers(-2047, 2048, 127).astype(np.int16)
+    nch, n = 8, 2 << 20
+    bank = fmd.FirBank(taps, 8, nch)
+    iq = fmd.synth.synth_iq(nch, n)
+    got = bank.filter_batch(iq)
+    h = oracle.fir_new(taps, 8)
+    exp = oracle.fir_filter(h, iq[3])
+    oracle.lib.fmo_fir_free(h)
+    assert np.array_equal(got[3], exp)
+
+
+@pytest.mark.gpu
+def test_gpu_fir_errors(fmd):
+    with pytest.raises(fmd.FmdError):
+        fmd.FirBank(np.ones(4, np.int16), 3)                       # odd decimation
+    with pytest.raises(fmd.FmdError):
+        fmd.FirBank(np.full(4, 4000, np.int16), 2)                 # |tap| > 2047
+    b = fmd.FirBank(np.ones(4, np.int16), 2)
+    with pytest.raises(fmd.FmdError) as ei:
+        b.filter_batch(np.zeros((1, 12), np.uint8))
+    assert ei.value.status == -2
