@@ -67,6 +67,8 @@ def main():
     ap.add_argument("--nbuf", type=int, default=3, help="distinct input batches rotated through (defeats the 256 MiB L3)")
     ap.add_argument("--kt", type=int, default=0, help="tiling override (audio samples per tile)")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="torch.distributed backend for the barrier / max-over-ranks timing (nccl = RCCL)")
     ap.add_argument("--settle", type=int, default=150,
                     help="untimed steps before the W warm-up steps: the first ~10 ms after an idle period run at "
                          "ramping clocks (measured 0.21-0.23 ms/step vs 0.193 settled); reported in config")
@@ -79,15 +81,22 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     dist = None
+    # one rank per GPU; `--backend gloo` (ranks may then share a GPU) exists to exercise this launch path on a
+    # single-GPU box -- the driver's multi-GPU runs use the default, RCCL ("nccl")
+    dev_index = local_rank % max(1, torch.cuda.device_count())
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        torch.cuda.set_device(dev_index)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", dev_index))
+        else:
+            dist.init_process_group(args.backend, rank=rank, world_size=world)
     if fmd.device_count() < 1:
         raise RuntimeError("bench.py: no gfx950 device; the product has no CPU path")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
+    local_rank = dev_index
 
     cfg = fmd.DemodConfig(FAST, FAST, SLOW, D, max(1, (1 << 15) // (128 * D)))
     nch = args.channels
@@ -129,7 +138,7 @@ def main():
     t1 = time.perf_counter()
     elapsed = t1 - t0
     if dist is not None:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
     kern_ms_region = ev0.elapsed_time(ev1) / args.steps            # HIP events on the launch stream
