@@ -89,15 +89,28 @@ __global__ void __launch_bounds__(kFirThreads) fmd_fir_kernel(const FirLaunch L)
 
     typedef const FMD_AS_CONSTANT uint32_t* cw;
     const cw wre = (cw)(uintptr_t)L.wre, wim = (cw)(uintptr_t)L.wim;
+    const bool aligned = (L.half_M & 3u) == 0u;           // windows start on 16-byte LDS boundaries: ds_read_b128
     for (uint32_t o = tid; o < no; o += kFirThreads) {
         const uint32_t* p = lds + o * L.half_M;
         int are = 0, aim = 0;
-        for (uint32_t i = 0; i < L.NP; ++i) {
-            const uint32_t w = p[i];
-            const uint32_t pre = __builtin_amdgcn_perm(w, w, 0x0C030C00u);   // (b0, b3) zero-extended to 16 bit
-            const uint32_t pim = __builtin_amdgcn_perm(w, w, 0x0C020C01u);   // (b1, b2)
-            are = sdot2(pre, wre[i], are);
-            aim = sdot2(pim, wim[i], aim);
+        // L.NP is a multiple of 4 (zero-padded taps): four tap pairs per step, taps by s_load_dwordx4
+        for (uint32_t i = 0; i < L.NP; i += 4) {
+            uint32_t w[4];
+            if (aligned) {
+                const uint4 q = *reinterpret_cast<const uint4*>(p + i);
+                w[0] = q.x; w[1] = q.y; w[2] = q.z; w[3] = q.w;
+            } else {
+                w[0] = p[i]; w[1] = p[i + 1]; w[2] = p[i + 2]; w[3] = p[i + 3];
+            }
+            typedef uint32_t t4 __attribute__((ext_vector_type(4)));
+            const t4 tr = *(const FMD_AS_CONSTANT t4*)(wre + i), ti = *(const FMD_AS_CONSTANT t4*)(wim + i);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const uint32_t pre = __builtin_amdgcn_perm(w[u], w[u], 0x0C030C00u);   // (b0, b3) zero-extended to 16 bit
+                const uint32_t pim = __builtin_amdgcn_perm(w[u], w[u], 0x0C020C01u);   // (b1, b2)
+                are = sdot2(pre, tr[u], are);
+                aim = sdot2(pim, ti[u], aim);
+            }
         }
         const uint32_t par = (L.par_first + (o0 + o) * L.par_step) & 1u;
         const int re = (par ? -are : are) + L.cre[par];
@@ -236,14 +249,14 @@ int fmd_fir_new(const int16_t* taps, uint32_t n_taps, uint32_t decim, const fmd_
     fmd_fir* f = new (std::nothrow) fmd_fir();
     if (!f) return FMD_ERR_NOMEM;
     f->T = n_taps; f->M = decim; f->C = dev->n_channels; f->device = device;
-    f->NP = (n_taps + 1) / 2;
+    f->NP = ((n_taps + 1) / 2 + 3u) & ~3u;                // tap pairs, zero-padded to a multiple of 4
     const uint32_t H = n_taps - 1, Hp = H + (H & 1u);     // history samples, rounded up to whole dwords
     f->Hw = Hp / 2;
     // tap pairs with the alternating dword sign folded in, and the additive constants of both window parities
     std::vector<uint32_t> wre(f->NP), wim(f->NP);
     int64_t cre[2] = {0, 0}, cim[2] = {0, 0};
     for (uint32_t i = 0; i < f->NP; ++i) {
-        const int h0 = taps[2 * i], h1 = 2 * i + 1 < n_taps ? taps[2 * i + 1] : 0;
+        const int h0 = 2 * i < n_taps ? taps[2 * i] : 0, h1 = 2 * i + 1 < n_taps ? taps[2 * i + 1] : 0;
         const int s = (i & 1u) ? -1 : 1;
         wre[i] = (uint32_t)(uint16_t)(int16_t)(s * h0) | ((uint32_t)(uint16_t)(int16_t)(-s * h1) << 16);
         wim[i] = (uint32_t)(uint16_t)(int16_t)(s * h0) | ((uint32_t)(uint16_t)(int16_t)(s * h1) << 16);
