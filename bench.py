@@ -53,7 +53,17 @@ def cpu_baseline(fmd, torch, cfg, iq_dev, target_s=12.0):
         total += t
         passes += 1
     samples = passes * chans * calls * (BLOCK // 2)
+    # one thread, one channel, same blocks -- about 1 s
+    one_t, one_n = 0.0, 0
+    while one_t < 1.0 and one_n < 200:
+        t = o.lib.fmo_bench_batch(C.byref(ocfg), data.ctypes.data_as(u8p), 1, calls, BLOCK, 1, C.byref(chk), None)
+        if t <= 0:
+            break
+        one_t += t
+        one_n += 1
+    single = round(one_n * calls * (BLOCK // 2) / one_t / 1e6, 2) if one_t > 0 else None
     return {"value": round(samples / total / 1e6, 2), "unit": "Msamples/s", "cores": cores, "kind": "port",
+            "single_thread_value": single,
             "sample": "%d passes x %d channels x %d calls x %d B of the same synthetic workload, %d threads, "
                       "%.1f s of oracle time" % (passes, chans, calls, BLOCK, cores, total)}
 

@@ -69,6 +69,14 @@ def test_fails_loudly_without_device(fmd):
         assert p.returncode == 1 and b"no usable gfx950 device" in p.stderr
 
 
+def test_missing_library_is_an_error_not_a_fallback():
+    """Without the built HIP library the package must raise, never compute on the CPU."""
+    code = "import rtl_sdr_rs_amd as f\ntry:\n    f.lib()\nexcept ImportError as e:\n    print('IMPORTERROR', e)\n"
+    env = dict(os.environ, FMD_LIB="/nonexistent/libfmd_hip.so", PYTHONPATH=ROOT)
+    p = subprocess.run([sys.executable, "-c", code], capture_output=True, env=env, timeout=120)
+    assert p.returncode == 0 and b"IMPORTERROR" in p.stdout and b"no CPU fallback" in p.stdout.replace(b"There is ", b"")
+
+
 def test_synth_is_deterministic_and_channel_offsettable(fmd):
     a = fmd.synth.synth_iq(3, 2048, sample_offset=1000)
     b = fmd.synth.synth_iq(3, 2048, sample_offset=1000)
