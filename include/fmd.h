@@ -108,7 +108,8 @@ int fmd_demod_demodulate(fmd_demod *d, const uint8_t *iq, size_t nbytes,
 /* The same for every channel of the bank, HOST buffers:
  *   iq      [n_channels][nbytes]   channel-major, contiguous
  *   out     [n_channels][out_cap]
- *   out_len [n_channels] */
+ *   out_len [n_channels]
+ * Elements of a row beyond its out_len (up to out_cap) are unspecified after the call. */
 int fmd_demod_demodulate_batch(fmd_demod *d, const uint8_t *iq, size_t nbytes,
                                int16_t *out, size_t out_cap, size_t *out_len);
 
@@ -125,6 +126,13 @@ int fmd_demod_last_out_len(const fmd_demod *d, size_t *out_len /* [n_channels] *
 
 /* Upper bound of samples one call can produce per channel for nbytes of input. */
 size_t fmd_out_cap(const fmd_demod_config *config, size_t nbytes);
+
+/* Page-locked host buffers for the HOST entry points above.  The reference reads into a pageable
+ * heap buffer and sends a copy of it per block (simple_fm.rs:114,127 `buf.to_vec()`); a binding that takes
+ * its read buffers from here instead lets the copy engine DMA straight out of them (no staging
+ * copy through the runtime's bounce buffers).  Plain pageable pointers keep working. */
+int fmd_host_alloc(size_t nbytes, void **ptr);
+int fmd_host_free(void *ptr);
 
 /* ---- state (checkpoint / resume; simple_fm.rs:232-239) -------------------------------- */
 int fmd_demod_get_state(fmd_demod *d, uint32_t channel, fmd_demod_state *state);

@@ -70,6 +70,8 @@ PROTOTYPES = {
     "fmd_demod_demodulate_batch": (C.c_int, [_vp, _vp, _sz, _vp, _sz, _szp]),
     "fmd_demod_demodulate_device": (C.c_int, [_vp, _vp, _sz, _vp, _sz, _vp, _vp]),
     "fmd_demod_last_out_len": (C.c_int, [_vp, _szp]),
+    "fmd_host_alloc": (C.c_int, [_sz, C.POINTER(_vp)]),
+    "fmd_host_free": (C.c_int, [_vp]),
     "fmd_out_cap": (_sz, [C.POINTER(DemodConfig), _sz]),
     "fmd_demod_get_state": (C.c_int, [_vp, C.c_uint32, C.POINTER(DemodState)]),
     "fmd_demod_set_state": (C.c_int, [_vp, C.c_uint32, C.POINTER(DemodState)]),

@@ -477,7 +477,10 @@ int fmd_demod_demodulate_batch(fmd_demod* d, const uint8_t* iq, size_t nbytes, i
         out_len[c] = K;
         if (K > kmax) kmax = K;
     }
-    if (kmax) {
+    if (kmax && (size_t)kmax * 2 >= out_cap) {
+        // rows are (nearly) full: one linear copy of the whole block beats a strided one by an order of magnitude
+        HIP_TRY(hipMemcpyAsync(out, d->d_out, out_elems * sizeof(int16_t), hipMemcpyDeviceToHost, d->stream));
+    } else if (kmax) {
         HIP_TRY(hipMemcpy2DAsync(out, out_cap * sizeof(int16_t), d->d_out, out_cap * sizeof(int16_t),
                                  (size_t)kmax * sizeof(int16_t), d->C, hipMemcpyDeviceToHost, d->stream));
     }
@@ -494,6 +497,27 @@ int fmd_demod_demodulate(fmd_demod* d, const uint8_t* iq, size_t nbytes, int16_t
     if (!d) { set_err("null argument"); return FMD_ERR_INVALID_ARG; }
     if (d->C != 1) { set_err("fmd_demod_demodulate needs a 1-channel handle (this one has %u)", d->C); return FMD_ERR_INVALID_ARG; }
     return fmd_demod_demodulate_batch(d, iq, nbytes, out, out_cap, out_len);
+}
+
+int fmd_host_alloc(size_t nbytes, void** ptr)
+{
+    if (!ptr || nbytes == 0) { set_err("null pointer or zero size"); return FMD_ERR_INVALID_ARG; }
+    *ptr = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) {
+        set_err("no HIP device (this library has no CPU path)");
+        return FMD_ERR_NO_DEVICE;
+    }
+    // portable: usable by every device of the node (one handle per GPU may share a reader thread's buffers)
+    HIP_TRY(hipHostMalloc(ptr, nbytes, hipHostMallocPortable));
+    return FMD_OK;
+}
+
+int fmd_host_free(void* ptr)
+{
+    if (!ptr) return FMD_OK;
+    HIP_TRY(hipHostFree(ptr));
+    return FMD_OK;
 }
 
 int fmd_demod_last_out_len(const fmd_demod* d, size_t* out_len)

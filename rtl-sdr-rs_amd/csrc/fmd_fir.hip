@@ -341,7 +341,9 @@ int fmd_fir_filter_batch(fmd_fir* f, const uint8_t* iq, size_t nbytes, int32_t* 
     size_t n = 0;
     int rc = fir_enqueue(f, f->d_iq, nbytes, f->d_out, out_cap, &n, f->stream);
     if (rc) return rc;
-    if (n) FIR_TRY(hipMemcpy2DAsync(out, out_cap * 8, f->d_out, out_cap * 8, n * 8, f->C, hipMemcpyDeviceToHost, f->stream));
+    if (n && n * 2 >= out_cap)      // nearly full rows: one linear copy instead of a strided one
+        FIR_TRY(hipMemcpyAsync(out, f->d_out, out_cap * 8 * (size_t)f->C, hipMemcpyDeviceToHost, f->stream));
+    else if (n) FIR_TRY(hipMemcpy2DAsync(out, out_cap * 8, f->d_out, out_cap * 8, n * 8, f->C, hipMemcpyDeviceToHost, f->stream));
     FIR_TRY(hipStreamSynchronize(f->stream));
     for (uint32_t c = 0; c < f->C; ++c) out_len[c] = n;
     return FMD_OK;

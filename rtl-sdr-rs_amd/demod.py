@@ -24,6 +24,28 @@ def out_cap(config, nbytes):
     return int(lib().fmd_out_cap(C.byref(config), nbytes))
 
 
+class PinnedBuffer:
+    """Page-locked host memory from fmd_host_alloc, viewed as a numpy array (`.array`): read buffers taken from
+    here let the host entry points DMA without the runtime's staging copy."""
+
+    def __init__(self, shape, dtype=np.uint8):
+        self.shape = tuple(int(x) for x in (shape if isinstance(shape, (tuple, list)) else (shape,)))
+        self.dtype = np.dtype(dtype)
+        self.nbytes = int(np.prod(self.shape)) * self.dtype.itemsize
+        self._p = C.c_void_p()
+        check(lib().fmd_host_alloc(self.nbytes, C.byref(self._p)))
+        raw = (C.c_uint8 * self.nbytes).from_address(self._p.value)
+        self.array = np.frombuffer(raw, dtype=self.dtype).reshape(self.shape)
+
+    def close(self):
+        if getattr(self, "_p", None) is not None and self._p:
+            self.array = None
+            check(lib().fmd_host_free(self._p))
+            self._p = C.c_void_p()
+
+    __del__ = close
+
+
 class DemodBank:
     """n_channels independent reference `Demod`s living on one MI355X."""
 
@@ -58,6 +80,17 @@ class DemodBank:
         lens = (C.c_size_t * self.n_channels)()
         check(lib().fmd_demod_demodulate_batch(self._h, iq.ctypes.data, nbytes, out.ctypes.data, cap, lens))
         return [out[c, :lens[c]].copy() for c in range(self.n_channels)]
+
+    def demodulate_batch_into(self, iq, out):
+        """No-copy form: iq uint8 [n_channels, nbytes], out int16 [n_channels, cap] (both C-contiguous host arrays,
+        e.g. PinnedBuffer.array).  Returns the per-channel sample counts."""
+        if iq.dtype != np.uint8 or out.dtype != np.int16 or not iq.flags.c_contiguous or not out.flags.c_contiguous:
+            raise ValueError("need C-contiguous uint8 input and int16 output")
+        if iq.ndim != 2 or out.ndim != 2 or iq.shape[0] != self.n_channels or out.shape[0] != self.n_channels:
+            raise ValueError("iq / out must be [n_channels, *]")
+        lens = (C.c_size_t * self.n_channels)()
+        check(lib().fmd_demod_demodulate_batch(self._h, iq.ctypes.data, iq.shape[1], out.ctypes.data, out.shape[1], lens))
+        return np.array(lens[:], dtype=np.int64)
 
     def demodulate_device(self, d_iq, nbytes, d_out, out_cap_, d_out_len=None, stream=None):
         """Enqueue on device pointers (ints).  Returns immediately."""

@@ -327,3 +327,58 @@ def test_phase_classes(fmd, oracle, nclasses):
             assert np.array_equal(got[c], exp[c, :lens[c]]), c
     for c in range(nch):
         assert gpu_state(bank, c) == oracle.state_of(obank[c])
+
+
+@pytest.mark.parametrize("force_generic", [False, True])
+def test_more_than_65535_channels(fmd, oracle, monkeypatch, force_generic):
+    """Maximum-size edge: 70 001 channels in one bank (beyond one grid dimension), two small calls; a strided
+    sample of channels incl. both sides of the 65535 boundary and the last one is compared with the oracle, and
+    every channel that was given channel 5's input must reproduce channel 5's audio."""
+    import torch
+    if force_generic:
+        monkeypatch.setenv("FMD_FORCE_GENERIC", "1")
+    nch, N = 70001, 4096
+    cfg = mkcfg(fmd, *CFG_24)
+    bank = fmd.DemodBank(cfg, nch)
+    cap = bank.out_cap(N)
+    iq = torch.empty((nch, N), dtype=torch.uint8, device="cuda")
+    out = torch.zeros((nch, cap), dtype=torch.int16, device="cuda")
+    stream = torch.cuda.current_stream().cuda_stream
+    picks = sorted(set(list(range(0, nch, 997)) + [65534, 65535, 65536, 65537, nch - 1]))
+    obank = oracle.new_bank(oracle.config(*CFG_24), len(picks))
+    for call in range(2):
+        fmd.synth.fill_device(iq.data_ptr(), nch, N, sample_offset=call * (N // 2), stream=stream)
+        iq[60000:] = iq[5]                              # 10 001 copies of channel 5 across the boundary
+        bank.demodulate_device(iq.data_ptr(), N, out.data_ptr(), cap, None, stream)
+        torch.cuda.synchronize()
+        lens = bank.last_out_len()
+        exp, elens = oracle.demodulate_batch(obank, iq[picks].cpu().numpy())
+        o = out.cpu().numpy()
+        for j, c in enumerate(picks):
+            assert lens[c] == elens[j]
+            assert np.array_equal(o[c, :elens[j]], exp[j, :elens[j]]), c
+        assert (lens[60000:] == lens[5]).all()
+        assert (o[60000:, :lens[5]] == o[5, :lens[5]][None, :]).all()
+    assert gpu_state(bank, nch - 1) == oracle.state_of(obank[len(picks) - 1])
+    bank.close()
+
+
+def test_pinned_host_buffers(fmd, oracle):
+    """fmd_host_alloc / fmd_host_free: page-locked read buffers through the host entry point give the same audio."""
+    nch, N = 5, 32768
+    cfg = mkcfg(fmd, *CFG_REF)
+    bank = fmd.DemodBank(cfg, nch)
+    obank = oracle.new_bank(oracle.config(*CFG_REF), nch)
+    cap = bank.out_cap(N)
+    pin_in, pin_out = fmd.PinnedBuffer((nch, N), np.uint8), fmd.PinnedBuffer((nch, cap), np.int16)
+    rng = np.random.default_rng(77)
+    for _ in range(3):
+        pin_in.array[:] = rng.integers(0, 256, (nch, N), dtype=np.uint8)
+        lens = bank.demodulate_batch_into(pin_in.array, pin_out.array)
+        exp, elens = oracle.demodulate_batch(obank, pin_in.array)
+        assert np.array_equal(lens.astype(np.uint32), elens)
+        for c in range(nch):
+            assert np.array_equal(pin_out.array[c, :elens[c]], exp[c, :elens[c]])
+    pin_in.close(); pin_out.close()
+    p = C.c_void_p()
+    assert fmd.lib().fmd_host_alloc(0, C.byref(p)) == -1 and fmd.lib().fmd_host_free(None) == 0
