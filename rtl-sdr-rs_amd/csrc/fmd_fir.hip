@@ -11,6 +11,15 @@
 // window parity.  Bound: VALU (about 2.5 instructions per tap per output), not HBM -- this kernel exists for
 // LDS-window / tap-table sizing, not for the 70 % HBM target.
 //
+// MFMA form (the default whenever decim <= 64): the filter IS a contraction, so it runs on the matrix cores.
+// Four consecutive outputs (i = 0..3) x {re, im} x {low, high tap digit} are the 16 rows of a banded Toeplitz
+// matrix A over the BYTES of their common window (rotation signs and the re/im byte selection folded in, taps
+// split as h = 128*hi + lo with |lo| <= 64, |hi| <= 16 so both digits are i8); 16 such output quads, 8*decim
+// bytes apart, are the 16 columns of B, which is nothing but the channel's byte stream (xor 0x80 -> s8) read
+// straight out of LDS: lane (col j, k-group q) of K-chunk k reads the 16 bytes at 8*decim*j + 64*k + 16*q.
+// v_mfma_i32_16x16x64_i8 accumulates; lane (j, q) ends up with exactly (re_lo, re_hi, im_lo, im_hi) of output
+// 4*j + q and combines them.  127 taps / decimate 8: 5 MFMAs per KiB of input per wave -- HBM-bound.
+//
 // Streaming state: the last T-1 samples (rounded up to an even count) of every channel live in HBM as raw
 // bytes, double-buffered; the stream position is the same for all channels and is kept on the host.
 #include "../../include/fmd.h"
@@ -18,6 +27,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <vector>
@@ -56,7 +66,15 @@ struct FirLaunch {
     uint32_t n_channels;
     int32_t* out;              // [C][out_cap][2]
     uint64_t out_cap;
+    // MFMA form
+    const uint32_t* amat;      // [n_pass * nku][64 lanes][4 dwords]: A fragments of the banded tap matrix
+    uint32_t n_pass, nku;      // K-chunks of 64 bytes = n_pass * nku
+    uint32_t groups;           // 16-column groups (64 outputs each) per tile
+    uint32_t col_bytes;        // 8 * decim: byte distance between consecutive columns
+    int32_t mre[2], mim[2];    // additive constants (s8 domain) by window parity
 };
+
+typedef int fir_i4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ int sdot2(uint32_t a, uint32_t b, int c)
 {
@@ -120,6 +138,97 @@ __global__ void __launch_bounds__(kFirThreads) fmd_fir_kernel(const FirLaunch L)
     }
 }
 
+
+// ---- MFMA form ------------------------------------------------------------------------------------------------
+// 16 bytes of the virtual stream starting at dword w, as s8 (xor 0x80); dwords past the end are never weighted
+__device__ __forceinline__ fir_i4 virt_chunk(const FirLaunch& L, uint32_t c, uint32_t w, bool fast)
+{
+    fir_i4 v;
+    if (fast && w >= L.Hw && (uint64_t)(w - L.Hw) + 4 <= L.stride_w) {
+        typedef const FMD_AS_GLOBAL fir_i4* gq;
+        v = *(gq)(uintptr_t)(L.iq + (uint64_t)c * L.stride_w + (w - L.Hw));
+    } else {
+        v.x = (int)virt_dword(L, c, w);     v.y = (int)virt_dword(L, c, w + 1);
+        v.z = (int)virt_dword(L, c, w + 2); v.w = (int)virt_dword(L, c, w + 3);
+    }
+    return v ^ (int)0x80808080;
+}
+
+template <int NKU>
+__global__ void __launch_bounds__(kFirThreads) fmd_fir_mfma_kernel(const FirLaunch L)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+    const uint32_t tid = threadIdx.x;
+    const uint32_t c = blockIdx.y + 65535u * blockIdx.z;
+    if (c >= L.n_channels) return;
+    const uint32_t o0 = blockIdx.x * L.out_tile;
+    if (o0 >= L.n_out) return;
+    const uint32_t no = L.n_out - o0 < L.out_tile ? L.n_out - o0 : L.out_tile;
+    const uint32_t w0 = L.wd_first + o0 * L.half_M;                 // first virtual dword of the tile
+    const uint32_t nq = ((no - 1) * L.half_M + L.NP + 3u) >> 2;     // 16-byte chunks the valid windows cover
+    // 16-byte global loads when this tile's chunks are 16-byte aligned in the caller's buffer
+    const bool fast = ((((uintptr_t)L.iq + ((uint64_t)c * L.stride_w + (uint64_t)w0 - L.Hw) * 4u)) & 15u) == 0u;
+    fir_i4* lq = reinterpret_cast<fir_i4*>(lds);
+    for (uint32_t base = 0; base < nq; base += 4u * kFirThreads) {
+        const uint32_t i0 = base + tid, i1 = i0 + kFirThreads, i2 = i1 + kFirThreads, i3 = i2 + kFirThreads;
+        fir_i4 a = {0, 0, 0, 0}, b = a, d = a, e = a;               // four loads in flight per lane
+        if (i0 < nq) a = virt_chunk(L, c, w0 + 4u * i0, fast);
+        if (i1 < nq) b = virt_chunk(L, c, w0 + 4u * i1, fast);
+        if (i2 < nq) d = virt_chunk(L, c, w0 + 4u * i2, fast);
+        if (i3 < nq) e = virt_chunk(L, c, w0 + 4u * i3, fast);
+        if (i0 < nq) lq[i0] = a;
+        if (i1 < nq) lq[i1] = b;
+        if (i2 < nq) lq[i2] = d;
+        if (i3 < nq) lq[i3] = e;
+    }
+    __syncthreads();
+
+    const uint32_t lane = tid & 63u, wave = tid >> 6, j = lane & 15u, q = lane >> 4;
+    const uint8_t* lb = reinterpret_cast<const uint8_t*>(lds);
+    typedef const FMD_AS_GLOBAL fir_i4* gq;
+    const gq amat = (gq)(uintptr_t)L.amat + lane;
+    fir_i4 acc[4];
+#pragma unroll
+    for (int gi = 0; gi < 4; ++gi) acc[gi] = fir_i4{0, 0, 0, 0};
+    for (uint32_t pass = 0; pass < L.n_pass; ++pass) {
+        fir_i4 A[NKU];
+#pragma unroll
+        for (int k = 0; k < NKU; ++k) A[k] = amat[(pass * NKU + k) * 64u];
+#pragma unroll
+        for (int gi = 0; gi < 4; ++gi) {
+            const uint32_t g = wave + 4u * gi;
+            if (g < L.groups && 64u * g < no) {                     // wave-uniform
+                const uint8_t* col = lb + (16u * g + j) * L.col_bytes + 16u * q + 64u * NKU * pass;
+#pragma unroll
+                for (int k = 0; k < NKU; ++k) {
+                    const fir_i4 B = *reinterpret_cast<const fir_i4*>(col + 64 * k);
+                    acc[gi] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A[k], B, acc[gi], 0, 0, 0);
+                }
+            }
+        }
+    }
+    // lane (j, q) holds rows 4q..4q+3 of column j: (re_lo, re_hi, im_lo, im_hi) of output 4j + q
+    const uint32_t par = (L.par_first ^ (L.half_M * q)) & 1u;
+    const int cre = L.mre[par], cim = L.mim[par];
+#pragma unroll
+    for (int gi = 0; gi < 4; ++gi) {
+        const uint32_t g = wave + 4u * gi;
+        const uint32_t o = 64u * g + 4u * j + q;
+        if (g < L.groups && o < no) {
+            int re = acc[gi].x + (acc[gi].y << 7), im = acc[gi].z + (acc[gi].w << 7);
+            if (L.par_first) { re = -re; im = -im; }
+            int2* dst = reinterpret_cast<int2*>(L.out) + ((uint64_t)c * L.out_cap + o0 + o);
+            *dst = make_int2(re + cre, im + cim);
+        }
+    }
+}
+
+template <int NKU>
+void launch_mfma(const FirLaunch& L, dim3 g, size_t lds, hipStream_t stream)
+{
+    hipLaunchKernelGGL(fmd_fir_mfma_kernel<NKU>, g, dim3(kFirThreads), lds, stream, L);
+}
+
 // hist_out[c][k] = virtual dword (stride_w + k): the last Hw dwords of history ++ call
 __global__ void __launch_bounds__(kFirThreads) fmd_fir_hist_kernel(const FirLaunch L)
 {
@@ -152,6 +261,9 @@ struct fmd_fir {
     int device = 0;
     uint64_t pos = 0;                                     // samples consumed per channel
     uint32_t* d_wre = nullptr; uint32_t* d_wim = nullptr;
+    uint32_t* d_amat = nullptr;                           // MFMA form: banded tap matrix, fragment order
+    uint32_t n_pass = 0, nku = 0, groups = 0;             // n_pass == 0: VALU kernel only
+    int32_t mre[2] = {0, 0}, mim[2] = {0, 0};
     uint32_t* d_hist[2] = {nullptr, nullptr};
     int cur = 0;
     int32_t cre[2] = {0, 0}, cim[2] = {0, 0};
@@ -199,7 +311,28 @@ int fir_enqueue(fmd_fir* f, const void* d_iq, size_t nbytes, void* d_out, size_t
     if (ot > 1024) ot = 1024;
     if (ot < 1) ot = 1;
     L.out_tile = (uint32_t)ot;
-    if (n_out) {
+    if (n_out && f->n_pass) {
+        L.amat = f->d_amat; L.n_pass = f->n_pass; L.nku = f->nku; L.groups = f->groups; L.col_bytes = 8u * f->M;
+        L.mre[0] = f->mre[0]; L.mre[1] = f->mre[1]; L.mim[0] = f->mim[0]; L.mim[1] = f->mim[1];
+        L.out_tile = 64u * f->groups;
+        // staged bytes of a full tile, and the furthest byte any fragment read touches
+        const size_t staged = (((size_t)(L.out_tile - 1) * L.half_M + L.NP + 3) / 4) * 16;
+        const size_t touched = (size_t)16 * f->groups * L.col_bytes + (size_t)64 * f->n_pass * f->nku;
+        const size_t lds = staged > touched ? staged : touched;
+        const uint32_t gy = f->C < 65535u ? f->C : 65535u, gz = (f->C + 65534u) / 65535u;
+        const dim3 g((uint32_t)((n_out + L.out_tile - 1) / L.out_tile), gy, gz);
+        switch (f->nku) {
+            case 1: launch_mfma<1>(L, g, lds, stream); break;
+            case 2: launch_mfma<2>(L, g, lds, stream); break;
+            case 3: launch_mfma<3>(L, g, lds, stream); break;
+            case 4: launch_mfma<4>(L, g, lds, stream); break;
+            case 5: launch_mfma<5>(L, g, lds, stream); break;
+            case 6: launch_mfma<6>(L, g, lds, stream); break;
+            case 7: launch_mfma<7>(L, g, lds, stream); break;
+            default: launch_mfma<8>(L, g, lds, stream); break;
+        }
+        FIR_TRY(hipGetLastError());
+    } else if (n_out) {
         const size_t lds = (((size_t)(L.out_tile - 1) * L.half_M + L.NP) * 4 + 15) & ~(size_t)15;
         const uint32_t gy = f->C < 65535u ? f->C : 65535u, gz = (f->C + 65534u) / 65535u;
         hipLaunchKernelGGL(fmd_fir_kernel, dim3((uint32_t)((n_out + ot - 1) / ot), gy, gz), dim3(kFirThreads), lds, stream, L);
@@ -267,8 +400,52 @@ int fmd_fir_new(const int16_t* taps, uint32_t n_taps, uint32_t decim, const fmd_
         }
     }
     for (int par = 0; par < 2; ++par) { f->cre[par] = (int32_t)cre[par]; f->cim[par] = (int32_t)cim[par]; }
+    // MFMA form: see the header comment.  Rows r = 4*i + reg (reg: re_lo, re_hi, im_lo, im_hi), K index = byte
+    // offset v from the window start of output i = 0; fragment order [chunk][lane = row + 16*q][16 bytes].
+    std::vector<uint32_t> amat;
+    const char* env_mfma = getenv("FMD_FIR_MFMA");
+    const uint32_t nk_tot = (2u * (3u * decim + n_taps) + 63u) / 64u;
+    if (decim <= 64 && nk_tot <= 64 && !(env_mfma && env_mfma[0] == '0')) {
+        f->n_pass = (nk_tot + 7u) / 8u;
+        f->nku = (nk_tot + f->n_pass - 1u) / f->n_pass;
+        uint32_t groups = 16384u / (128u * decim);
+        f->groups = groups < 1u ? 1u : (groups > 16u ? 16u : groups);
+        const uint32_t chunks = f->n_pass * f->nku;
+        amat.assign((size_t)chunks * 64 * 4, 0u);
+        uint8_t* ab = reinterpret_cast<uint8_t*>(amat.data());
+        for (uint32_t kk = 0; kk < chunks; ++kk)
+            for (uint32_t lane = 0; lane < 64; ++lane)
+                for (uint32_t b = 0; b < 16; ++b) {
+                    const uint32_t r = lane & 15u, i = r >> 2, reg = r & 3u;
+                    const int64_t rel = (int64_t)(64u * kk + 16u * (lane >> 4) + b) - 2ll * decim * i;
+                    if (rel < 0 || rel >= 2ll * n_taps) continue;
+                    const uint32_t t = (uint32_t)rel >> 1, sg = (uint32_t)rel & 1u;
+                    const uint32_t phase = (t + 2u * ((decim / 2u * i) & 1u)) & 3u;
+                    int sign;
+                    if ((reg >> 1) == 0) sign = (phase == 0 && sg == 0) || (phase == 3 && sg == 1) ? 1
+                                              : (phase == 1 && sg == 1) || (phase == 2 && sg == 0) ? -1 : 0;
+                    else sign = (phase == 0 && sg == 1) || (phase == 1 && sg == 0) ? 1
+                              : (phase == 2 && sg == 1) || (phase == 3 && sg == 0) ? -1 : 0;
+                    const int h = taps[t];
+                    const int lo = ((h + 64) & 127) - 64, hi = (h - lo) / 128;      // h = 128*hi + lo, both i8
+                    ab[((size_t)kk * 64 + lane) * 16 + b] = (uint8_t)(int8_t)(sign * ((reg & 1u) ? hi : lo));
+                }
+        for (int par = 0; par < 2; ++par) {
+            int64_t sr = 0, si = 0;
+            for (uint32_t t = 0; t < n_taps; ++t) {
+                const uint32_t phase = (t + 2u * par) & 3u;
+                if (phase == 0 || phase == 3) sr += taps[t];
+                if (phase == 0 || phase == 1) si += taps[t];
+            }
+            f->mre[par] = (int32_t)sr; f->mim[par] = (int32_t)si;
+        }
+    }
     auto fail = [&](const char* what) { fmd_internal_set_err(what); fmd_fir_free(f); return FMD_ERR_HIP; };
     if (hipSetDevice(device) != hipSuccess) return fail("hipSetDevice");
+    if (!amat.empty()) {
+        if (hipMalloc(&f->d_amat, amat.size() * 4) != hipSuccess) return fail("hipMalloc(tap matrix)");
+        if (hipMemcpy(f->d_amat, amat.data(), amat.size() * 4, hipMemcpyHostToDevice) != hipSuccess) return fail("hipMemcpy(tap matrix)");
+    }
     if (hipMalloc(&f->d_wre, f->NP * 4) != hipSuccess || hipMalloc(&f->d_wim, f->NP * 4) != hipSuccess) return fail("hipMalloc(taps)");
     if (hipMemcpy(f->d_wre, wre.data(), f->NP * 4, hipMemcpyHostToDevice) != hipSuccess ||
         hipMemcpy(f->d_wim, wim.data(), f->NP * 4, hipMemcpyHostToDevice) != hipSuccess) return fail("hipMemcpy(taps)");
@@ -290,6 +467,7 @@ void fmd_fir_free(fmd_fir* f)
     (void)hipDeviceSynchronize();
     if (f->d_wre) (void)hipFree(f->d_wre);
     if (f->d_wim) (void)hipFree(f->d_wim);
+    if (f->d_amat) (void)hipFree(f->d_amat);
     for (int i = 0; i < 2; ++i) if (f->d_hist[i]) (void)hipFree(f->d_hist[i]);
     if (f->d_iq) (void)hipFree(f->d_iq);
     if (f->d_out) (void)hipFree(f->d_out);

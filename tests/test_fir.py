@@ -62,8 +62,14 @@ def test_oracle_fir_equals_numpy_convolution(oracle, T, M):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("T,M", [(127, 8), (6, 6), (10, 10), (5, 2), (16, 16), (33, 4), (1, 2), (64, 6), (255, 32)])
-def test_gpu_fir_matches_oracle(fmd, oracle, T, M):
+@pytest.mark.parametrize("form", ["mfma", "valu"])
+@pytest.mark.parametrize("T,M", [(127, 8), (6, 6), (10, 10), (5, 2), (16, 16), (33, 4), (1, 2), (64, 6), (255, 32),
+                                 (300, 8), (1024, 2), (129, 64), (77, 66), (31, 128)])
+def test_gpu_fir_matches_oracle(fmd, oracle, monkeypatch, form, T, M):
+    """Both kernel forms (matrix-core form = default for decim <= 64; FMD_FIR_MFMA=0 forces the VALU form),
+    streaming over ragged calls; shapes cover one and several K passes, both window parities, decim > 64."""
+    if form == "valu":
+        monkeypatch.setenv("FMD_FIR_MFMA", "0")
     rng = np.random.default_rng(T * 7 + M)
     taps = np.ones(T, np.int16) if T == M else rng.integers(-2047, 2048, T).astype(np.int16)
     nch = 5
@@ -71,6 +77,8 @@ def test_gpu_fir_matches_oracle(fmd, oracle, T, M):
     hs = [oracle.fir_new(taps, M) for _ in range(nch)]
     for call in range(5):
         n = int(rng.integers(1, 400)) * 8 if call else 8          # a first call too short to emit anything
+        if call == 3:
+            n = 8 * int(rng.integers(6000, 9000))                 # several tiles per channel
         iq = rng.integers(0, 256, (nch, n), dtype=np.uint8)
         if call == 2:
             iq[:] = np.where(rng.integers(0, 2, (nch, n)) > 0, 255, 0)   # full scale
