@@ -72,7 +72,14 @@ struct FirLaunch {
     uint32_t groups;           // 16-column groups (64 outputs each) per tile
     uint32_t col_bytes;        // 8 * decim: byte distance between consecutive columns
     int32_t mre[2], mim[2];    // additive constants (s8 domain) by window parity
+    uint32_t dbg;              // ablation bits, honoured by -DFMD_EXPERIMENT builds only
 };
+
+#ifdef FMD_EXPERIMENT
+#define FIR_ABLATE(bit) ((L.dbg >> (bit)) & 1u)
+#else
+#define FIR_ABLATE(bit) false
+#endif
 
 typedef int fir_i4 __attribute__((ext_vector_type(4)));
 
@@ -140,7 +147,7 @@ __global__ void __launch_bounds__(kFirThreads) fmd_fir_kernel(const FirLaunch L)
 
 
 // ---- MFMA form ------------------------------------------------------------------------------------------------
-// 16 bytes of the virtual stream starting at dword w, as s8 (xor 0x80); dwords past the end are never weighted
+// 16 raw bytes of the virtual stream starting at dword w; dwords past the end are never weighted
 __device__ __forceinline__ fir_i4 virt_chunk(const FirLaunch& L, uint32_t c, uint32_t w, bool fast)
 {
     fir_i4 v;
@@ -151,7 +158,13 @@ __device__ __forceinline__ fir_i4 virt_chunk(const FirLaunch& L, uint32_t c, uin
         v.x = (int)virt_dword(L, c, w);     v.y = (int)virt_dword(L, c, w + 1);
         v.z = (int)virt_dword(L, c, w + 2); v.w = (int)virt_dword(L, c, w + 3);
     }
-    return v ^ (int)0x80808080;
+    return v;
+}
+
+__device__ __forceinline__ void fir_dma16(const unsigned char* g, unsigned char* lds_wave_base)
+{
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
 
 template <int NKU>
@@ -159,6 +172,7 @@ __global__ void __launch_bounds__(kFirThreads) fmd_fir_mfma_kernel(const FirLaun
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     const uint32_t tid = threadIdx.x;
+    __builtin_amdgcn_s_setprio(3);                                  // get the loads out first (see fmd_tile_kernel.hip)
     const uint32_t c = blockIdx.y + 65535u * blockIdx.z;
     if (c >= L.n_channels) return;
     const uint32_t o0 = blockIdx.x * L.out_tile;
@@ -168,32 +182,54 @@ __global__ void __launch_bounds__(kFirThreads) fmd_fir_mfma_kernel(const FirLaun
     const uint32_t nq = ((no - 1) * L.half_M + L.NP + 3u) >> 2;     // 16-byte chunks the valid windows cover
     // 16-byte global loads when this tile's chunks are 16-byte aligned in the caller's buffer
     const bool fast = ((((uintptr_t)L.iq + ((uint64_t)c * L.stride_w + (uint64_t)w0 - L.Hw) * 4u)) & 15u) == 0u;
-    fir_i4* lq = reinterpret_cast<fir_i4*>(lds);
-    for (uint32_t base = 0; base < nq; base += 4u * kFirThreads) {
-        const uint32_t i0 = base + tid, i1 = i0 + kFirThreads, i2 = i1 + kFirThreads, i3 = i2 + kFirThreads;
-        fir_i4 a = {0, 0, 0, 0}, b = a, d = a, e = a;               // four loads in flight per lane
-        if (i0 < nq) a = virt_chunk(L, c, w0 + 4u * i0, fast);
-        if (i1 < nq) b = virt_chunk(L, c, w0 + 4u * i1, fast);
-        if (i2 < nq) d = virt_chunk(L, c, w0 + 4u * i2, fast);
-        if (i3 < nq) e = virt_chunk(L, c, w0 + 4u * i3, fast);
-        if (i0 < nq) lq[i0] = a;
-        if (i1 < nq) lq[i1] = b;
-        if (i2 < nq) lq[i2] = d;
-        if (i3 < nq) lq[i3] = e;
-    }
-    __syncthreads();
-
     const uint32_t lane = tid & 63u, wave = tid >> 6, j = lane & 15u, q = lane >> 4;
-    const uint8_t* lb = reinterpret_cast<const uint8_t*>(lds);
     typedef const FMD_AS_GLOBAL fir_i4* gq;
     const gq amat = (gq)(uintptr_t)L.amat + lane;
+    fir_i4 A[NKU];                                                  // first pass' tap fragments: in flight with the data
+#pragma unroll
+    for (int k = 0; k < NKU; ++k) A[k] = amat[k * 64];
+
+    // Interior tiles (whole tile inside this call's buffer, 16-byte aligned): global_load_lds_dwordx4, 1 KiB per
+    // wave-instruction straight into LDS, no VGPR round trip.  Tiles that touch the history, the end of the
+    // stream or an unaligned buffer go through registers.
+    const bool whole = fast && w0 >= L.Hw && (uint64_t)(w0 - L.Hw) + 4ull * nq <= L.stride_w;
+    fir_i4* lq = reinterpret_cast<fir_i4*>(lds);
+    if (FIR_ABLATE(1)) {
+    } else if (whole) {
+        const unsigned char* src = reinterpret_cast<const unsigned char*>(L.iq + (uint64_t)c * L.stride_w + (w0 - L.Hw)) + 16u * tid;
+        unsigned char* dst = reinterpret_cast<unsigned char*>(lds) + 1024u * wave;
+        const uint32_t nfull = nq / kFirThreads, ntail = nq - nfull * kFirThreads;
+        for (uint32_t l = 0; l < nfull; ++l) fir_dma16(src + (16u * kFirThreads) * l, dst + (16u * kFirThreads) * l);
+        if (tid < ntail) fir_dma16(src + (16u * kFirThreads) * nfull, dst + (16u * kFirThreads) * nfull);
+    } else {
+        for (uint32_t base = 0; base < nq; base += 5u * kFirThreads) {  // one trip for tiles up to 20 KiB
+            const uint32_t i0 = base + tid, i1 = i0 + kFirThreads, i2 = i1 + kFirThreads, i3 = i2 + kFirThreads,
+                           i4 = i3 + kFirThreads;
+            fir_i4 a = {0, 0, 0, 0}, b = a, d = a, e = a, h = a;        // five loads in flight per lane
+            if (i0 < nq) a = virt_chunk(L, c, w0 + 4u * i0, fast);
+            if (i1 < nq) b = virt_chunk(L, c, w0 + 4u * i1, fast);
+            if (i2 < nq) d = virt_chunk(L, c, w0 + 4u * i2, fast);
+            if (i3 < nq) e = virt_chunk(L, c, w0 + 4u * i3, fast);
+            if (i4 < nq) h = virt_chunk(L, c, w0 + 4u * i4, fast);
+            if (i0 < nq) lq[i0] = a;
+            if (i1 < nq) lq[i1] = b;
+            if (i2 < nq) lq[i2] = d;
+            if (i3 < nq) lq[i3] = e;
+            if (i4 < nq) lq[i4] = h;
+        }
+    }
+    __builtin_amdgcn_s_setprio(0);
+    __syncthreads();
+
+    const uint8_t* lb = reinterpret_cast<const uint8_t*>(lds);
     fir_i4 acc[4];
 #pragma unroll
     for (int gi = 0; gi < 4; ++gi) acc[gi] = fir_i4{0, 0, 0, 0};
-    for (uint32_t pass = 0; pass < L.n_pass; ++pass) {
-        fir_i4 A[NKU];
+    for (uint32_t pass = 0; pass < L.n_pass && !FIR_ABLATE(0); ++pass) {
+        if (pass) {
 #pragma unroll
-        for (int k = 0; k < NKU; ++k) A[k] = amat[(pass * NKU + k) * 64u];
+            for (int k = 0; k < NKU; ++k) A[k] = amat[(pass * NKU + k) * 64u];
+        }
 #pragma unroll
         for (int gi = 0; gi < 4; ++gi) {
             const uint32_t g = wave + 4u * gi;
@@ -201,10 +237,19 @@ __global__ void __launch_bounds__(kFirThreads) fmd_fir_mfma_kernel(const FirLaun
                 const uint8_t* col = lb + (16u * g + j) * L.col_bytes + 16u * q + 64u * NKU * pass;
 #pragma unroll
                 for (int k = 0; k < NKU; ++k) {
-                    const fir_i4 B = *reinterpret_cast<const fir_i4*>(col + 64 * k);
+                    const fir_i4 B = *reinterpret_cast<const fir_i4*>(col + 64 * k) ^ (int)0x80808080;   // u8 -> s8
                     acc[gi] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A[k], B, acc[gi], 0, 0, 0);
                 }
             }
+        }
+    }
+    // the channel's last tile also writes the next call's history (saves the separate launch)
+    if (blockIdx.x == gridDim.x - 1u && !FIR_ABLATE(3)) {
+        typedef const FMD_AS_GLOBAL uint32_t* gw;
+        for (uint32_t k = tid; k < L.Hw; k += kFirThreads) {
+            const uint64_t w = L.stride_w + k;                      // virtual dword (history ++ call), < Hw + stride_w
+            L.hist_out[(uint64_t)c * L.Hw + k] = w < L.Hw ? ((gw)(uintptr_t)L.hist_in)[(uint64_t)c * L.Hw + w]
+                                                         : ((gw)(uintptr_t)L.iq)[(uint64_t)c * L.stride_w + (w - L.Hw)];
         }
     }
     // lane (j, q) holds rows 4q..4q+3 of column j: (re_lo, re_hi, im_lo, im_hi) of output 4j + q
@@ -214,7 +259,7 @@ __global__ void __launch_bounds__(kFirThreads) fmd_fir_mfma_kernel(const FirLaun
     for (int gi = 0; gi < 4; ++gi) {
         const uint32_t g = wave + 4u * gi;
         const uint32_t o = 64u * g + 4u * j + q;
-        if (g < L.groups && o < no) {
+        if (g < L.groups && o < no && !FIR_ABLATE(2)) {
             int re = acc[gi].x + (acc[gi].y << 7), im = acc[gi].z + (acc[gi].w << 7);
             if (L.par_first) { re = -re; im = -im; }
             int2* dst = reinterpret_cast<int2*>(L.out) + ((uint64_t)c * L.out_cap + o0 + o);
@@ -311,6 +356,9 @@ int fir_enqueue(fmd_fir* f, const void* d_iq, size_t nbytes, void* d_out, size_t
     if (ot > 1024) ot = 1024;
     if (ot < 1) ot = 1;
     L.out_tile = (uint32_t)ot;
+#ifdef FMD_EXPERIMENT
+    { const char* e = getenv("FMD_DBG"); L.dbg = e ? (uint32_t)atoi(e) : 0u; }
+#endif
     if (n_out && f->n_pass) {
         L.amat = f->d_amat; L.n_pass = f->n_pass; L.nku = f->nku; L.groups = f->groups; L.col_bytes = 8u * f->M;
         L.mre[0] = f->mre[0]; L.mre[1] = f->mre[1]; L.mim[0] = f->mim[0]; L.mim[1] = f->mim[1];
@@ -338,12 +386,12 @@ int fir_enqueue(fmd_fir* f, const void* d_iq, size_t nbytes, void* d_out, size_t
         hipLaunchKernelGGL(fmd_fir_kernel, dim3((uint32_t)((n_out + ot - 1) / ot), gy, gz), dim3(kFirThreads), lds, stream, L);
         FIR_TRY(hipGetLastError());
     }
-    if (f->Hw) {
+    if (f->Hw && !(n_out && f->n_pass)) {               // the MFMA kernel's last tiles wrote it already
         const uint64_t th = (uint64_t)f->C * f->Hw;
         hipLaunchKernelGGL(fmd_fir_hist_kernel, dim3((uint32_t)((th + kFirThreads - 1) / kFirThreads)), dim3(kFirThreads), 0, stream, L);
         FIR_TRY(hipGetLastError());
-        f->cur ^= 1;
     }
+    if (f->Hw) f->cur ^= 1;
     f->pos += ns;
     if (n_each) *n_each = (size_t)n_out;
     return FMD_OK;

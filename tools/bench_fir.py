@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """BASELINE configs[3] measurement (not the headline bench): 127-tap FIR + 8x decimate, 256 channels at
 20 Msps -- one call = 2 MiB per channel (52.4 ms of signal), inputs resident in HBM.  Prints one JSON line.
-This kernel is VALU-bound by design (about 2.5 instructions per tap per output), see DESIGN.md."""
+FMD_FIR_MFMA=0 times the VALU form instead of the matrix-core form."""
 import json
 import os
 import sys
@@ -26,10 +26,10 @@ def main():
         bufs.append(t)
     cap = bank.out_cap(n)
     out = torch.zeros((nch, cap, 2), dtype=torch.int32, device=dev)
-    for i in range(3):
+    for i in range(int(os.environ.get('FIR_SETTLE', '150'))):     # untimed: clock ramp after idle
         bank.filter_device(bufs[i % 2].data_ptr(), n, out.data_ptr(), cap, stream)
     torch.cuda.synchronize()
-    steps = 20
+    steps = 100
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for i in range(steps):
@@ -45,7 +45,7 @@ def main():
         "ms_per_call": round(ms, 4), "iq_msamples_per_s": round(samples / ms / 1e3, 1),
         "realtime_factor_vs_256x20Msps": round(samples / ms / 1e3 / (256 * 20.0), 1),
         "algorithmic_GBps": round(alg / ms / 1e6, 1), "hbm_frac_of_8TBps": round(alg / ms / 1e6 / 8000.0, 4),
-        "int_mac_per_s": round(macs / ms * 1e3, 0), "bound": "VALU (2 x v_perm_b32 + 2 x v_dot2_i32_i16 + ds_read per tap pair)",
+        "int_mac_per_s": round(macs / ms * 1e3, 0), "form": "valu" if os.environ.get("FMD_FIR_MFMA") == "0" else "mfma (v_mfma_i32_16x16x64_i8)",
         "outputs_per_channel": int(nout)}))
 
 
