@@ -167,7 +167,14 @@ __device__ __forceinline__ void fir_dma16(const unsigned char* g, unsigned char*
                                      (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
 
-template <int NKU>
+// SWZ (decim == 8, columns 64 bytes apart): a fragment read puts lanes (j, q) at 64*j + 16*q, and the four
+// 16-lane groups ds_read_b128 is serviced in ({0-3,12-15,20-27}, ...) then hit every 16-byte slot of the 256-byte
+// bank row twice.  Swapping the 32-byte halves of each 64-byte chunk in every other bank row (address bit 5 ^=
+// bit 8) makes all four groups conflict-free for every K-chunk; the LDS-DMA applies it for free by permuting
+// which lane fetches which 16 bytes.  (PMC: SQ_LDS_BANK_CONFLICT 10.5 M cycles per launch without it.)
+__device__ __forceinline__ uint32_t fir_swz_slot(uint32_t slot) { return slot ^ (((slot >> 4) & 1u) << 1); }
+
+template <int NKU, bool SWZ>
 __global__ void __launch_bounds__(kFirThreads) fmd_fir_mfma_kernel(const FirLaunch L)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
@@ -179,7 +186,8 @@ __global__ void __launch_bounds__(kFirThreads) fmd_fir_mfma_kernel(const FirLaun
     if (o0 >= L.n_out) return;
     const uint32_t no = L.n_out - o0 < L.out_tile ? L.n_out - o0 : L.out_tile;
     const uint32_t w0 = L.wd_first + o0 * L.half_M;                 // first virtual dword of the tile
-    const uint32_t nq = ((no - 1) * L.half_M + L.NP + 3u) >> 2;     // 16-byte chunks the valid windows cover
+    // 16-byte slots the valid windows cover, in whole 64-byte chunks (the swizzle permutes within a chunk)
+    const uint32_t nq = ((((no - 1) * L.half_M + L.NP + 3u) >> 2) + 3u) & ~3u;
     // 16-byte global loads when this tile's chunks are 16-byte aligned in the caller's buffer
     const bool fast = ((((uintptr_t)L.iq + ((uint64_t)c * L.stride_w + (uint64_t)w0 - L.Hw) * 4u)) & 15u) == 0u;
     const uint32_t lane = tid & 63u, wave = tid >> 6, j = lane & 15u, q = lane >> 4;
@@ -196,7 +204,7 @@ __global__ void __launch_bounds__(kFirThreads) fmd_fir_mfma_kernel(const FirLaun
     fir_i4* lq = reinterpret_cast<fir_i4*>(lds);
     if (FIR_ABLATE(1)) {
     } else if (whole) {
-        const unsigned char* src = reinterpret_cast<const unsigned char*>(L.iq + (uint64_t)c * L.stride_w + (w0 - L.Hw)) + 16u * tid;
+        const unsigned char* src = reinterpret_cast<const unsigned char*>(L.iq + (uint64_t)c * L.stride_w + (w0 - L.Hw)) + 16u * (SWZ ? fir_swz_slot(tid) : tid);
         unsigned char* dst = reinterpret_cast<unsigned char*>(lds) + 1024u * wave;
         const uint32_t nfull = nq / kFirThreads, ntail = nq - nfull * kFirThreads;
         for (uint32_t l = 0; l < nfull; ++l) fir_dma16(src + (16u * kFirThreads) * l, dst + (16u * kFirThreads) * l);
@@ -211,11 +219,11 @@ __global__ void __launch_bounds__(kFirThreads) fmd_fir_mfma_kernel(const FirLaun
             if (i2 < nq) d = virt_chunk(L, c, w0 + 4u * i2, fast);
             if (i3 < nq) e = virt_chunk(L, c, w0 + 4u * i3, fast);
             if (i4 < nq) h = virt_chunk(L, c, w0 + 4u * i4, fast);
-            if (i0 < nq) lq[i0] = a;
-            if (i1 < nq) lq[i1] = b;
-            if (i2 < nq) lq[i2] = d;
-            if (i3 < nq) lq[i3] = e;
-            if (i4 < nq) lq[i4] = h;
+            if (i0 < nq) lq[SWZ ? fir_swz_slot(i0) : i0] = a;
+            if (i1 < nq) lq[SWZ ? fir_swz_slot(i1) : i1] = b;
+            if (i2 < nq) lq[SWZ ? fir_swz_slot(i2) : i2] = d;
+            if (i3 < nq) lq[SWZ ? fir_swz_slot(i3) : i3] = e;
+            if (i4 < nq) lq[SWZ ? fir_swz_slot(i4) : i4] = h;
         }
     }
     __builtin_amdgcn_s_setprio(0);
@@ -234,10 +242,12 @@ __global__ void __launch_bounds__(kFirThreads) fmd_fir_mfma_kernel(const FirLaun
         for (int gi = 0; gi < 4; ++gi) {
             const uint32_t g = wave + 4u * gi;
             if (g < L.groups && 64u * g < no) {                     // wave-uniform
-                const uint8_t* col = lb + (16u * g + j) * L.col_bytes + 16u * q + 64u * NKU * pass;
+                const uint8_t* col = lb + (16u * g + j) * L.col_bytes + 64u * NKU * pass;
 #pragma unroll
                 for (int k = 0; k < NKU; ++k) {
-                    const fir_i4 B = *reinterpret_cast<const fir_i4*>(col + 64 * k) ^ (int)0x80808080;   // u8 -> s8
+                    // SWZ: col is a multiple of 64, so only the low part (16q) sees the bit-5 flip of chunk j + kk
+                    const uint32_t low = SWZ ? (16u * q) ^ ((((j + pass * NKU + k) >> 2) & 1u) << 5) : 16u * q;
+                    const fir_i4 B = *reinterpret_cast<const fir_i4*>(col + 64 * k + low) ^ (int)0x80808080;   // u8 -> s8
                     acc[gi] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A[k], B, acc[gi], 0, 0, 0);
                 }
             }
@@ -271,7 +281,8 @@ __global__ void __launch_bounds__(kFirThreads) fmd_fir_mfma_kernel(const FirLaun
 template <int NKU>
 void launch_mfma(const FirLaunch& L, dim3 g, size_t lds, hipStream_t stream)
 {
-    hipLaunchKernelGGL(fmd_fir_mfma_kernel<NKU>, g, dim3(kFirThreads), lds, stream, L);
+    if (L.col_bytes == 64u) hipLaunchKernelGGL((fmd_fir_mfma_kernel<NKU, true>), g, dim3(kFirThreads), lds, stream, L);
+    else hipLaunchKernelGGL((fmd_fir_mfma_kernel<NKU, false>), g, dim3(kFirThreads), lds, stream, L);
 }
 
 // hist_out[c][k] = virtual dword (stride_w + k): the last Hw dwords of history ++ call
@@ -364,7 +375,7 @@ int fir_enqueue(fmd_fir* f, const void* d_iq, size_t nbytes, void* d_out, size_t
         L.mre[0] = f->mre[0]; L.mre[1] = f->mre[1]; L.mim[0] = f->mim[0]; L.mim[1] = f->mim[1];
         L.out_tile = 64u * f->groups;
         // staged bytes of a full tile, and the furthest byte any fragment read touches
-        const size_t staged = (((size_t)(L.out_tile - 1) * L.half_M + L.NP + 3) / 4) * 16;
+        const size_t staged = (((((size_t)(L.out_tile - 1) * L.half_M + L.NP + 3) / 4) + 3) & ~(size_t)3) * 16;
         const size_t touched = (size_t)16 * f->groups * L.col_bytes + (size_t)64 * f->n_pass * f->nku;
         const size_t lds = staged > touched ? staged : touched;
         const uint32_t gy = f->C < 65535u ? f->C : 65535u, gz = (f->C + 65534u) / 65535u;
