@@ -129,23 +129,23 @@ long fmcf_demodulate(uint32_t D, uint32_t fast, uint32_t slow, uint32_t kt, FmdC
     return (long)K;
 }
 
-// The division-free tile form used by the production kernel (phase-class plans) must describe
-// exactly the same tiles as fmd_tile().  Returns 0, or a positive code naming the first mismatch.
+// The planned tile form used by the production kernel (phase-class plans + tiling constants; one small
+// division per tile, none when kt is a multiple of sr) must describe exactly the same tiles as fmd_tile().  Returns 0, or a positive code naming the first mismatch.
 int fmcf_check_plan(uint32_t D, uint32_t fast, uint32_t slow, uint32_t kt, uint32_t p0, uint32_t i0r, uint32_t ns)
 {
     FmdRates r;
     r.D = D; r.fast = fast; r.slow = slow;
     r.g = fmd_gcd(fast, slow); r.fr = fast / r.g; r.sr = slow / r.g; r.R = (int32_t)(fast / slow); r.kt = kt;
-    if (!fmd_plan_possible(r) || !fmd_ranges_fit32(r, ns)) return -1;
+    if (!fmd_ranges_fit32(r, ns)) return -1;
     const FmdClassPlan P = fmd_make_plan(r, p0, i0r, ns);
     const uint32_t M = fmd_num_decimated(D, p0, ns), K = fmd_num_audio(r, i0r, M), nt = fmd_num_tiles(r, K);
     if (P.M != M || P.K != K || P.nt != nt) return 1;
-    const uint32_t Qt = fmd_plan_Qt(r);
+    const FmdTiling tl = fmd_make_tiling(r);
     const uint32_t fa = r.fr / r.sr, fb = r.fr % r.sr;
     const float inv_sr = 1.0f / (float)r.sr;
     for (uint32_t t = 0; t < nt; t++) {
         const FmdTile A = fmd_tile(r, p0, i0r, ns, M, K, nt, t);
-        const FmdTile B = fmd_tile_fast(r, P, Qt, ns, t);
+        const FmdTile B = fmd_tile_fast(r, P, tl, ns, t);
         if (A.k0 != B.k0 || A.k1 != B.k1) return 2;
         if (A.jA != B.jA) return 3;
         if (A.jB != B.jB) return 4;

@@ -90,12 +90,30 @@ int choose_tiling(fmd_demod* d, uint32_t kt_req)
     FmdRates& r = d->r;
     uint32_t kt = kt_req;
     if (kt == 0) {
-        // ~19 KiB of raw IQ per tile (bytes per audio sample = 2 * D * fast / slow), rounded to a
-        // multiple of sr so that the division-free tile kernel applies.
-        const double per = 2.0 * r.D * (double)r.fr / (double)r.sr;
-        double k = 18000.0 * (double)d->block_threads / 256.0 / per;   // tile + discriminator buffer <= 20 KiB: 8 blocks/CU
-        kt = k < 1.0 ? 1u : (k > 1024.0 ? 1024u : (uint32_t)k);
-        if (kt >= r.sr) kt -= kt % r.sr;
+        // Largest tiles that keep 8 blocks per CU resident (160 KiB LDS / 8), then, among those, the tiling
+        // with the least issue work per input byte.  The work of one tile is quantised: a wave handles whole
+        // rounds of 127 decimated samples (4 waves share the rounds) and the resampler runs in passes of one
+        // audio sample per thread, so e.g. 272 audio samples per tile (a second pass for 16 of them) measured
+        // 10 % slower than 256 at the reference's own rates.  Weights are instruction counts of the kernel.
+        const uint32_t nt_threads = d->block_threads, waves = nt_threads / 64u;
+        const double budget = 20480.0 * (double)nt_threads / 256.0;
+        const uint32_t dh = r.D % 2 == 0 && r.D / 2 <= 5 ? r.D / 2 : r.D;   // dwords per window (odd / large D: byte loop)
+        const double c_round = 64.0 + 12.0 * dh, c_audio = 70.0 + 6.0 * (double)(r.fr / r.sr), c_fixed = 150.0;
+        double best = 0.0;
+        kt = 1;
+        for (uint32_t k = 1; k <= 1024u; ++k) {
+            r.kt = k;
+            if ((uint64_t)r.sr * (k + 2) >= (1u << 24)) break;
+            const uint32_t lp = fmd_tile_lp_cap(r), raw = fmd_tile_raw_cap(r);
+            const double lds = (double)raw + 2.0 * (lp + r.fr / r.sr + 2) + 32.0;
+            if (lds > budget && k > 1) break;
+            const uint64_t cnt = ((uint64_t)k * r.fr + r.sr - 1) / r.sr + 1;            // decimated samples formed
+            const uint64_t rounds = (cnt + 126) / 127, per_wave = (rounds + waves - 1) / waves;
+            const uint64_t passes = (k + nt_threads - 1) / nt_threads;
+            const double work = per_wave * c_round + passes * c_audio + c_fixed + (((uint64_t)k * r.fr) % r.sr ? 25.0 : 0.0);
+            const double per_byte = work / (2.0 * r.D * (double)cnt);
+            if (k == 1 || per_byte < best) { best = per_byte; kt = k; }
+        }
     }
     r.kt = kt;
     d->persist_blocks = 0;
@@ -216,7 +234,8 @@ int enqueue(fmd_demod* d, const void* d_iq, size_t nbytes, void* d_out, size_t o
 #endif
     if (tile_kernel_ok(d)) {
         const FmdRates& r = d->r;
-        L.Qt = fmd_plan_Qt(r);
+        L.tl = fmd_make_tiling(r);
+        L.Qt = L.tl.Qt;
         L.fa = r.fr / r.sr; L.fb = r.fr % r.sr;
         L.inv_sr = 1.0f / (float)r.sr; L.inv_R = 1.0f / (float)r.R;
         for (size_t k = 0; k < plans.size(); ++k) L.cls[k] = plans[k];
@@ -356,6 +375,8 @@ int fmd_demod_new(const fmd_demod_config* config, const fmd_device_config* dev, 
     d->force_generic = env_u32("FMD_FORCE_GENERIC", 0) != 0;
     d->block_threads = env_u32("FMD_NT", 256);
     if (d->block_threads != 128 && d->block_threads != 512) d->block_threads = 256;
+    // two waves per block step 2*127 windows per round: an odd downsample would flip a lane's rotation phase
+    if (d->block_threads == 128 && (config->downsample & 1u)) d->block_threads = 256;
     // Default data movement: the LDS-tile kernel.  FMD_STREAM=1 selects the register-streaming kernel with the
     // largest round these rates allow (same results; measured 5-10 % slower in round 1, kept for A/B).
     uint32_t kt_env = env_u32("FMD_KT", 0);

@@ -140,22 +140,35 @@ FMD_HD FmdTile fmd_tile(const FmdRates& r, uint32_t p0, uint32_t i0r, uint32_t n
     return T;
 }
 
-// ---- phase classes and the division-free tile form ------------------------------------------
-// Channels that share (p0, i0r) share every index of the call.  When kt is a multiple of sr,
-// kt*fr = Qt*sr exactly and all tiles of a class have the same internal structure shifted by
-// t*Qt decimated samples, so a tile needs only multiply-adds of the per-class constants below
-// (computed once per call on the host).
+// ---- phase classes and the planned tile form -------------------------------------------------
+// Channels that share (p0, i0r) share every index of the call.  With a0 = fr - i0r - 1 = eq0*sr + er0
+// (per class and call, host) and the tiling constants below (per handle, host),
+//     (t*kt + 1)*fr - i0r - 1 = a0 + t*kt*fr = (eq0 + t*Qt)*sr + (er0 + t*Rt),
+// so tile t needs ONE small division, (er0 + t*Rt) / sr, and none at all when kt is a multiple of sr
+// (Rt == 0: every tile of a class has the same structure shifted by t*Qt decimated samples).  jA and jB
+// follow from (eq, er) by comparisons against host constants.
 struct FmdClassPlan {
     uint32_t p0, i0r;   // call-start phases of the class
     uint32_t M, K, nt;  // decimated / audio samples and tiles of this call
-    uint32_t eq0, er0;  // fr - i0r - 1 = eq0*sr + er0          (tile 0's eq, every tile's er)
-    uint32_t c1;        // ceil((i0r + 1) / sr):  jA(t >= 1) = t*Qt - c1 + 1
-    uint32_t jBrel;     // jB(non-last tile t) = t*Qt + jBrel
-    uint32_t pad[3];
+    uint32_t eq0, er0;  // fr - i0r - 1 = eq0*sr + er0
+    uint32_t pad[5];
 };
 
-inline bool fmd_plan_possible(const FmdRates& r) { return r.kt % r.sr == 0; }
-inline uint32_t fmd_plan_Qt(const FmdRates& r) { return (uint32_t)((uint64_t)r.kt * r.fr / r.sr); }
+struct FmdTiling {
+    uint32_t Qt, Rt;    // kt*fr       = Qt*sr + Rt
+    uint32_t fq, frr;   // fr          = fq*sr + frr
+    uint32_t Bq, Br;    // (kt - 1)*fr = Bq*sr + Br
+};
+
+inline FmdTiling fmd_make_tiling(const FmdRates& r)
+{
+    FmdTiling g;
+    const uint64_t a = (uint64_t)r.kt * r.fr, b = (uint64_t)(r.kt - 1) * r.fr;
+    g.Qt = (uint32_t)(a / r.sr); g.Rt = (uint32_t)(a % r.sr);
+    g.fq = r.fr / r.sr;          g.frr = r.fr % r.sr;
+    g.Bq = (uint32_t)(b / r.sr); g.Br = (uint32_t)(b % r.sr);
+    return g;
+}
 
 inline FmdClassPlan fmd_make_plan(const FmdRates& r, uint32_t p0, uint32_t i0r, uint32_t ns)
 {
@@ -167,22 +180,26 @@ inline FmdClassPlan fmd_make_plan(const FmdRates& r, uint32_t p0, uint32_t i0r, 
     const uint32_t a0 = r.fr - i0r - 1;
     P.eq0 = a0 / r.sr;
     P.er0 = a0 % r.sr;
-    P.c1 = (i0r + r.sr) / r.sr;
-    P.jBrel = P.eq0 + (uint32_t)(((uint64_t)P.er0 + (uint64_t)(r.kt - 1) * r.fr) / r.sr);
     return P;
 }
 
-FMD_HD FmdTile fmd_tile_fast(const FmdRates& r, const FmdClassPlan& P, uint32_t Qt, uint32_t ns, uint32_t t)
+FMD_HD FmdTile fmd_tile_fast(const FmdRates& r, const FmdClassPlan& P, const FmdTiling& g, uint32_t ns, uint32_t t)
 {
     FmdTile T;
     T.last = (t + 1 == P.nt);
     T.k0 = t * r.kt;
     T.k1 = T.k0 + r.kt < P.K ? T.k0 + r.kt : P.K;
     if (T.k1 < T.k0) T.k1 = T.k0;
-    T.eq = t * Qt + P.eq0;
+    T.eq = t * g.Qt + P.eq0;
     T.er = P.er0;
-    T.jA = t == 0 ? 0 : (int32_t)(t * Qt - P.c1 + 1);
-    T.jB = T.last ? (int32_t)P.M - 1 : (int32_t)(t * Qt + P.jBrel);
+    if (g.Rt) {                                          // t*Rt < t*kt*fr, which fmd_ranges_fit32 bounds
+        const uint32_t x = P.er0 + t * g.Rt, qx = x / r.sr;
+        T.eq += qx;
+        T.er = x - qx * r.sr;
+    }
+    // jA = e(k0 - 1) + 1 = floor((eq*sr + er - fr) / sr) + 1;  jB = e(k1 - 1) = eq + (er + (kt-1)*fr) / sr
+    T.jA = t == 0 ? 0 : (int32_t)(T.eq - g.fq + (T.er >= g.frr ? 1u : 0u));
+    T.jB = T.last ? (int32_t)P.M - 1 : (int32_t)(T.eq + g.Bq + (T.er + g.Br >= r.sr ? 1u : 0u));
     T.nLo = T.jA >= 1 ? fmd_win_begin(r.D, P.p0, T.jA - 1) : 0;
     T.nHi = T.last ? (int32_t)ns : fmd_win_end(r.D, P.p0, T.jB);
     if (T.nHi < T.nLo) T.nHi = T.nLo;
@@ -195,19 +212,19 @@ FMD_HD uint32_t fmd_udiv_small(uint32_t t, uint32_t d, float inv_d)
 {
     uint32_t q = (uint32_t)((float)t * inv_d);
     const int32_t rem = (int32_t)t - (int32_t)(q * d);
-    if (rem < 0) --q;
-    else if (rem >= (int32_t)d) ++q;
+    // sign-mask arithmetic instead of selects (VCC-masked v_cndmask_b32 issues ~4x slower than an add on gfx950,
+    // tools/valubench.hip): -1 when rem < 0, +1 when rem >= d
+    q += (uint32_t)(rem >> 31);
+    q -= (uint32_t)(((int32_t)d - 1 - rem) >> 31);
     return q;
 }
 
 // Truncating s / d (Rust `/` on i32, simple_fm.rs:421) for |s| < 2^24, 1 <= d < 2^24.
 FMD_HD int32_t fmd_sdiv_small(int32_t s, int32_t d, float inv_d)
 {
-    int32_t q = (int32_t)((float)s * inv_d);            // conversion truncates toward zero
-    const int32_t rem = s - q * d;
-    if (s >= 0) { if (rem < 0) --q; else if (rem >= d) ++q; }
-    else        { if (rem > 0) ++q; else if (rem <= -d) --q; }
-    return q;
+    const uint32_t m = (uint32_t)(s >> 31);              // (v ^ m) - m = m ? -v : v
+    const uint32_t q = fmd_udiv_small(((uint32_t)s ^ m) - m, (uint32_t)d, inv_d);
+    return (int32_t)((q ^ m) - m);
 }
 
 // Truncating num / den for den > 0, |num / den| <= 4097 (the fast_atan2 quotient): f32 estimate

@@ -37,7 +37,8 @@ struct FmdLaunch {
     uint32_t rounds_per_wave; // streaming kernel: consecutive rounds (tiles of kt audio samples) one wave walks
     uint32_t group_rounds;    // streaming kernel: rounds whose audio samples are produced together (<= 64 / kt)
     // ---- tile kernel only (phase-class plans; see fmd_index.h) ----
-    uint32_t Qt;              // decimated samples per full tile = kt * fr / sr
+    uint32_t Qt;              // decimated samples per full tile = kt * fr / sr (== tl.Qt)
+    FmdTiling tl;             // tiling constants of fmd_tile_fast
     uint32_t fa, fb;          // fr = fa * sr + fb
     float    inv_sr, inv_R;
     const uint8_t* chan_class;// [n_channels] class id, or nullptr when every channel is class 0

@@ -139,7 +139,7 @@ struct Round {
 
 __device__ __forceinline__ Round round_setup(const FmdLaunch& L, const FmdClassPlan& P, uint32_t t)
 {
-    const FmdTile T = fmd_tile_fast(L.r, P, L.Qt, L.ns, t);
+    const FmdTile T = fmd_tile_fast(L.r, P, L.tl, L.ns, t);
     Round R;
     R.jfirst = T.jA - 1;
     R.hi = T.jB - R.jfirst;

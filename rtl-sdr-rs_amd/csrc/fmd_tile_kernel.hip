@@ -105,6 +105,34 @@ __device__ __forceinline__ int disc_fast(uint32_t a, uint32_t b)
     return den == 0u ? 0 : (int)res;                                     // x == 0 && y == 0 (:388)
 }
 
+// The same function without a single select, used by the masked-window loop: there hipcc turns disc_fast's
+// `?:` into VCC-masked v_cndmask_b32_e32, which issues ~4x slower than the SGPR-masked e64 form it picks in
+// the whole-dword loop (tools/valubench.hip).  Measured: this form -1.5 % at D = 7 in the masked loop, but
+// +1.2 ... 2.5 % in the whole-dword loop, which therefore keeps disc_fast.
+// With mx / my the sign masks of x / y:  den = |x| + |y| in both branches of :390-400, the numerator is
+// +-(|x| - |y|) with the sign of x, and the base angle is pi/4 + (x < 0 ? pi/2 : 0).
+__device__ __forceinline__ int disc_nosel(uint32_t a, uint32_t b)
+{
+    const uint32_t a_sw = __builtin_amdgcn_alignbit(a, a, 16);          // (im, re)
+    const uint32_t b_cj = (b & 0xFFFFu) | ((0u - (b >> 16)) << 16);      // (re, -im)
+    const int cr = sdot2(a, b);                                          // ar*br + ai*bi
+    const int ci = sdot2(a_sw, b_cj);                                    // ai*br - ar*bi
+    const uint32_t mx = (uint32_t)(cr >> 31), my = (uint32_t)(ci >> 31);
+    const uint32_t xabs = ((uint32_t)cr ^ mx) - mx, yabs = ((uint32_t)ci ^ my) - my;
+    const uint32_t den = xabs + yabs, t = xabs - yabs;
+    const int num = (int)(((t ^ mx) - mx) << 12);                        // the i64 product truncated to i32 (:397,399)
+    const uint32_t mn = (uint32_t)(num >> 31);
+    const uint32_t unum = ((uint32_t)num ^ mn) - mn;
+    uint32_t q = (uint32_t)((float)unum * __builtin_amdgcn_rcpf((float)den));
+    const int rem = (int)(unum - q * den);
+    q += (uint32_t)(rem >> 31);                                          // estimate one too large
+    q -= (uint32_t)(((int)den - 1 - rem) >> 31);                         // estimate one too small (rem >= den)
+    const uint32_t qs = (q ^ mn) - mn;                                   // truncating signed quotient
+    const uint32_t angle = (1u << 12) + (mx & (2u << 12)) - qs;
+    const uint32_t res = (angle ^ my) - my;
+    return (int)(res & (uint32_t)((int)(0u - den) >> 31));               // x == 0 && y == 0 -> 0 (:388)
+}
+
 // (re, im) -> re | im << 16 in one v_perm_b32.
 __device__ __forceinline__ uint32_t pack_lp_perm(int re, int im)
 {
@@ -136,7 +164,7 @@ __device__ __forceinline__ TileCtx tile_setup(const FmdLaunch& L, uint32_t c, ui
     X.cls = L.chan_class ? L.chan_class[c] : 0u;
     const FmdClassPlan& P = L.cls[X.cls];
     X.valid = t < P.nt;
-    X.T = fmd_tile_fast(L.r, P, L.Qt, L.ns, X.valid ? t : 0u);
+    X.T = fmd_tile_fast(L.r, P, L.tl, L.ns, X.valid ? t : 0u);
     X.jfirst = X.T.jA - 1;
     X.cnt = X.T.jB - X.jfirst + 1;
     const uint64_t gbase = (uint64_t)(uintptr_t)L.iq + (uint64_t)c * L.chan_stride;
@@ -235,45 +263,75 @@ __device__ __forceinline__ void tile_body(const FmdLaunch& L, const TileCtx& X, 
             if (lane > 0 && i1 < cnt) d16[i1] = (int16_t)d1;
             if (i2 < cnt) d16[i2] = (int16_t)d2;
         }
-        // Call start (at most once per channel-call, one lane): lp[-1] is demod_pre, lp[0] is the clipped first
-        // window plus lp_now, d[0] takes the f64 path (:359); d[0] and d[1] are rewritten with them.  Same
-        // wave as the loop's own stores to these entries, so program order makes the patch win.
-        if (jfirst <= 0 && tid == 0) {
-            int r0, i0, r1, i1w, cr, ci;
-            lds_window_sum(raw_w, wofs, 0, fmd_win_end(r.D, p0, 0), r0, i0);
-            r0 += st.lp_now_re; i0 += st.lp_now_im;
-            lds_window_sum(raw_w, wofs, fmd_win_begin(r.D, p0, 1), fmd_win_end(r.D, p0, 1), r1, i1w);
-            if (jfirst < 0) {
-                fmd_mul_conj(r0, i0, st.demod_pre_re, st.demod_pre_im, cr, ci);
-                d16[1] = (int16_t)polar_f64(cr, ci);
-            }
-            fmd_mul_conj(r1, i1w, r0, i0, cr, ci);
-            d16[1 - jfirst] = (int16_t)fmd_fast_atan2(ci, cr);
-        }
     } else {
-        // Windows that are not whole dwords (odd downsample or odd phase): the general window sum.
+        // Any downsample, any phase: a window of D samples starting at call sample s covers the dwords
+        // s/2 .. (s + D - 1)/2; the half dwords at its ends are masked out of the byte weights.  s mod 4 (the
+        // rotation phase), hence weights, masks and the additive constants, are again fixed per lane: a lane's
+        // windows are 64 and 4*127 samples apart.  The dword count is the same for every window of the call.
+        const int D = (int)r.D;
+        const int s00 = D * jfirst - (int)p0;                // start sample of window i is s00 + D*i
+        const int sl = s00 + D * ((int)wave * RS + (int)lane);
+        const uint32_t sm = (uint32_t)sl & 3u;               // two's complement: right for the clipped windows too
+        const bool podd = ((sl >> 1) & 1) != 0;              // call-dword parity of the first dword
+        const uint32_t wreA = podd ? FMD_W_RE_ODD : FMD_W_RE_EVEN, wreB = podd ? FMD_W_RE_EVEN : FMD_W_RE_ODD;
+        const uint32_t wimA = podd ? FMD_W_IM_ODD : FMD_W_IM_EVEN, wimB = podd ? FMD_W_IM_EVEN : FMD_W_IM_ODD;
+        const int ndw = (D & 1) ? (D + 1) / 2 : D / 2 + (int)(p0 & 1u);
+        const uint32_t mf = (sm & 1u) ? 0xFFFF0000u : 0xFFFFFFFFu;
+        const uint32_t ml = ((sm + (uint32_t)D) & 1u) ? 0x0000FFFFu : 0xFFFFFFFFu;
+        const bool lastB = ((ndw - 1) & 1) != 0;
+        const uint32_t wreF = wreA & mf & (ndw == 1 ? ml : 0xFFFFFFFFu), wimF = wimA & mf & (ndw == 1 ? ml : 0xFFFFFFFFu);
+        const uint32_t wreL = (lastB ? wreB : wreA) & ml, wimL = (lastB ? wimB : wimA) & ml;
+        const int cre = fmd_const_re((int)sm + D) - fmd_const_re((int)sm);
+        const int cim = fmd_const_im((int)sm + D) - fmd_const_im((int)sm);
         for (int base = (int)wave * RS; base < last; base += NW * RS) {
             const int i1 = base + (int)lane, i2 = i1 + 64;
-            const int j1 = jfirst + (i1 < last ? i1 : last), j2 = jfirst + (i2 < last ? i2 : last);
-            int re1, im1, re2, im2;
-            if (j1 < 0) { re1 = st.demod_pre_re; im1 = st.demod_pre_im; }
-            else {
-                lds_window_sum(raw_w, wofs, fmd_win_begin(r.D, p0, j1), fmd_win_end(r.D, p0, j1), re1, im1);
-                if (j1 == 0) { re1 += st.lp_now_re; im1 += st.lp_now_im; }
+            const uint32_t* __restrict__ pa = raw_w + (uint32_t)(wofs + ((s00 + D * i1) >> 1));
+            const uint32_t* __restrict__ pb = raw_w + (uint32_t)(wofs + ((s00 + D * i2) >> 1));
+            uint32_t wa = pa[0] ^ 0x80808080u, wb = pb[0] ^ 0x80808080u;                 // u8 -> s8 (b - 128)
+            int re1 = sdot4(wa, wreF, cre), im1 = sdot4(wa, wimF, cim);
+            int re2 = sdot4(wb, wreF, cre), im2 = sdot4(wb, wimF, cim);
+            int u = 1;
+            for (; u + 2 < ndw; u += 2) {                    // whole dwords, weights alternate B, A
+                wa = pa[u] ^ 0x80808080u; wb = pb[u] ^ 0x80808080u;
+                re1 = sdot4(wa, wreB, re1); im1 = sdot4(wa, wimB, im1);
+                re2 = sdot4(wb, wreB, re2); im2 = sdot4(wb, wimB, im2);
+                wa = pa[u + 1] ^ 0x80808080u; wb = pb[u + 1] ^ 0x80808080u;
+                re1 = sdot4(wa, wreA, re1); im1 = sdot4(wa, wimA, im1);
+                re2 = sdot4(wb, wreA, re2); im2 = sdot4(wb, wimA, im2);
             }
-            lds_window_sum(raw_w, wofs, fmd_win_begin(r.D, p0, j2), fmd_win_end(r.D, p0, j2), re2, im2);   // j2 >= 63
-            const uint32_t pk1 = pack_lp(re1, im1), pk2 = pack_lp(re2, im2);
+            if (u + 1 < ndw) {
+                wa = pa[u] ^ 0x80808080u; wb = pb[u] ^ 0x80808080u;
+                re1 = sdot4(wa, wreB, re1); im1 = sdot4(wa, wimB, im1);
+                re2 = sdot4(wb, wreB, re2); im2 = sdot4(wb, wimB, im2);
+                ++u;
+            }
+            if (u < ndw) {                                   // last dword (possibly half)
+                wa = pa[u] ^ 0x80808080u; wb = pb[u] ^ 0x80808080u;
+                re1 = sdot4(wa, wreL, re1); im1 = sdot4(wa, wimL, im1);
+                re2 = sdot4(wb, wreL, re2); im2 = sdot4(wb, wimL, im2);
+            }
+            const uint32_t pk1 = pack_lp_perm(re1, im1), pk2 = pack_lp_perm(re2, im2);
             const uint32_t prev1 = wave_shr1(pk1);
             const uint32_t prev2 = wave_shr1_old(wave_ror1(pk1), pk2);
-            int d1 = disc_fast(pk1, prev1), d2 = disc_fast(pk2, prev2);
-            if (jfirst < 0 && base == 0 && i1 == 1) {        // first sample of the call (:359)
-                int cr, ci;
-                fmd_mul_conj(lp_re(pk1), lp_im(pk1), lp_re(prev1), lp_im(prev1), cr, ci);
-                d1 = polar_f64(cr, ci);
-            }
+            const int d1 = disc_nosel(pk1, prev1), d2 = disc_nosel(pk2, prev2);
             if (lane > 0 && i1 < cnt) d16[i1] = (int16_t)d1;
             if (i2 < cnt) d16[i2] = (int16_t)d2;
         }
+    }
+    // Call start (at most once per channel-call, one lane): lp[-1] is demod_pre, lp[0] is the clipped first
+    // window plus lp_now, d[0] takes the f64 path (:359); d[0] and d[1] are rewritten with them.  Same
+    // wave as the loop's own stores to these entries, so program order makes the patch win.
+    if (jfirst <= 0 && tid == 0) {
+        int r0, i0, r1, i1w, cr, ci;
+        lds_window_sum(raw_w, wofs, 0, fmd_win_end(r.D, p0, 0), r0, i0);
+        r0 += st.lp_now_re; i0 += st.lp_now_im;
+        lds_window_sum(raw_w, wofs, fmd_win_begin(r.D, p0, 1), fmd_win_end(r.D, p0, 1), r1, i1w);
+        if (jfirst < 0) {
+            fmd_mul_conj(r0, i0, st.demod_pre_re, st.demod_pre_im, cr, ci);
+            d16[1] = (int16_t)polar_f64(cr, ci);
+        }
+        fmd_mul_conj(r1, i1w, r0, i0, cr, ci);
+        d16[1 - jfirst] = (int16_t)fmd_fast_atan2(ci, cr);
     }
     __syncthreads();
 
@@ -478,7 +536,6 @@ size_t fmd_tile_lds_bytes(const FmdLaunch& L)
 
 bool fmd_tile_kernel_supports(const FmdRates& r, uint32_t raw_cap)
 {
-    if (r.kt % r.sr != 0) return false;                                   // plans need kt*fr = Qt*sr
     if (r.D > 64) return false;                                           // disc_fast: x + |y| < 2^30
     if ((uint64_t)r.sr * (r.kt + 2) >= (1u << 24)) return false;          // fmd_udiv_small operands
     if ((uint64_t)((r.fr + r.sr - 1) / r.sr + 2) * 32768ull >= (1u << 24)) return false;   // |group sum| < 2^24

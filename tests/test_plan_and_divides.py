@@ -30,8 +30,9 @@ def test_plan_tiles_equal_generic_tiles(cf, D, fast, slow):
     g = math.gcd(fast, slow)
     fr, sr = fast // g, slow // g
     rng = np.random.default_rng(D)
-    for mult in [1, 2, 3, 8]:
-        kt = sr * mult
+    # multiples of sr (no in-tile division) and arbitrary tilings (one division per tile)
+    kts = [sr * m for m in (1, 2, 3, 8)] + [1, 2, 7, 30, 120, 198, 246, 317, 1000] + [int(x) for x in rng.integers(1, 1500, 6)]
+    for kt in kts:
         if kt > 4096:
             continue
         for _ in range(12):

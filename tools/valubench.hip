@@ -12,7 +12,7 @@
 #define BODY(INSTR)                                                                                     \
     for (int it = 0; it < iters; ++it) {                                                                \
         asm volatile(REP8(INSTR) : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) \
-                     : "v"(b), "v"(c), "s"(s0) : "vcc");                                                        \
+                     : "v"(b), "v"(c), "s"(s0) : "vcc", "s20", "s21");                                                        \
     }
 
 #define KERNEL(NAME, INSTR)                                                                             \
@@ -40,6 +40,12 @@ KERNEL(k_dot4c,     I8("v_dot4c_i32_i8", "%8, %9"))
 KERNEL(k_dot2c,     I8("v_dot2c_i32_i16", "%8, %9"))
 KERNEL(k_dot4,      I8S("v_dot4_i32_i8", ", %8, ", "%9"))
 KERNEL(k_cndmask,   I8S("v_cndmask_b32", ", %8, ", "vcc"))
+KERNEL(k_cmp_cnd_vcc, "v_cmp_lt_u32 vcc, %8, %9\n" I8S("v_cndmask_b32", ", %8, ", "vcc"))   // 9 instructions per block
+KERNEL(k_cmp_cnd_e64, "v_cmp_lt_u32 s[20:21], %8, %9\n" I8S("v_cndmask_b32_e64", ", %8, ", "s[20:21]"))
+KERNEL(k_cmp_cnd_const, "v_cmp_lt_u32 s[20:21], %8, %9\n" I8S("v_cndmask_b32_e64", ", 0, ", "s[20:21]"))
+KERNEL(k_cmp_cnd_e64vcc, "v_cmp_lt_u32 vcc, %8, %9\n" I8S("v_cndmask_b32_e64", ", %8, ", "vcc"))
+KERNEL(k_cmp8_vcc,  REP8("v_cmp_lt_u32 vcc, %8, %9\n"))
+KERNEL(k_cmp8_sgpr, REP8("v_cmp_lt_u32 s[20:21], %8, %9\n"))
 KERNEL(k_mul_lo,    I8S("v_mul_lo_u32", ", ", "%8"))
 KERNEL(k_mul_i24,   I8S("v_mul_i32_i24", ", ", "%8"))
 KERNEL(k_mad_u24,   I8S("v_mad_u32_u24", ", %8, ", "%9"))
@@ -101,6 +107,7 @@ int main()
     const double base = ms * 1e6 / (3.0 * occ * iters * 8.0);
 #define R(K) run(#K, K, occ, iters, base)
     R(k_add_u32); R(k_xor_b32); R(k_sub_u32); R(k_max_i32); R(k_lshl); R(k_dot4c); R(k_dot2c); R(k_dot4); R(k_cndmask);
+    R(k_cmp_cnd_e64); R(k_cmp_cnd_const); R(k_cmp_cnd_vcc); R(k_cmp8_vcc); R(k_cmp8_sgpr);
     R(k_mul_lo); R(k_mul_i24); R(k_mad_u24); R(k_add3); R(k_lshl_add); R(k_and_or); R(k_alignbit); R(k_perm); R(k_bfe_i32);
     R(k_cvt_f32_u32); R(k_cvt_u32_f32); R(k_rcp_f32); R(k_mul_f32); R(k_fma_f32); R(k_add_f32); R(k_pk_add_u16);
     R(k_pk_mul_lo_u16); R(k_sad_u32); R(k_mov_dpp);
