@@ -11,19 +11,20 @@
 // streaming: no MFMA.
 //
 // A tile is `kt` consecutive audio samples of one channel-call; its geometry comes from host-made
-// per-phase-class plans (FmdClassPlan, fmd_index.h), so the device only does multiply-adds.
+// per-phase-class plans and per-handle tiling constants (FmdClassPlan, FmdTiling, fmd_index.h), so the
+// device does multiply-adds and at most one small division per tile.
 //   tile_body (shared):
-//     * boxcar: for an even downsample a window is DH whole dwords, 3 VALU ops per dword (xor, 2 x dot4)
-//       with per-lane weight registers that already carry the rotation sign of the dword parity;
-//     * predecessor sample from the neighbouring lane (DPP wave_shr:1): a wave-round is 63 new windows
-//       + 1 overlap, so there is no LDS exchange and no barrier between boxcar and discriminator;
+//     * boxcar: for an even downsample <= 10 a window is DH whole dwords, 3 VALU ops per dword (xor, 2 x dot4)
+//       with per-lane weight registers that already carry the rotation sign of the dword parity; any other
+//       downsample / phase runs the same loop with the window's half dwords masked out of the weights;
+//     * predecessor sample from the neighbouring lane (DPP wave_shr:1): a wave-round is 127 new windows
+//       + 1 overlap, two per lane, so there is no LDS exchange and no barrier between boxcar and discriminator;
 //     * discriminator: complex multiply by 2 x v_dot2_i32_i16 on packed (re, im); branch-free
 //       fast_atan2 with an exact f32-reciprocal divide;
 //     * resampler: one audio sample per lane from the tile's discriminator samples in LDS.
-//   fmd_demod_persist_kernel (default): grid = CUs x resident blocks; each block walks tiles
-//     lin, lin + G, ... and keeps the NEXT tile's 16-byte loads in flight in registers while it
-//     computes the current one (issue early / write late), so HBM requests never stop during compute.
-//   fmd_demod_tile_kernel: one block per tile, LDS-DMA staging (global_load_lds_dwordx4); any tile size.
+//   fmd_demod_tile_kernel (default): one block per tile, LDS-DMA staging (global_load_lds_dwordx4).
+//   fmd_demod_persist_kernel (FMD_PERSIST=1, measured slower): grid = CUs x resident blocks; each block walks
+//     tiles lin, lin + G, ... with the NEXT tile's 16-byte loads in flight in registers during compute.
 #include "fmd_device.h"
 #include "fmd_kernels.h"
 
