@@ -134,6 +134,17 @@ __device__ __forceinline__ int disc_nosel(uint32_t a, uint32_t b)
     return (int)(res & (uint32_t)((int)(0u - den) >> 31));               // x == 0 && y == 0 -> 0 (:388)
 }
 
+// Sum of one audio group: FA samples plus one optional (low_pass_real, :411-415).
+template <int FA>
+__device__ __forceinline__ int group_sum(const int16_t* __restrict__ dp, bool extra)
+{
+    int sum = 0;
+#pragma unroll
+    for (int i = 0; i < FA; ++i) sum += dp[i];
+    const int v = dp[FA];
+    return sum + (extra ? v : 0);
+}
+
 // (re, im) -> re | im << 16 in one v_perm_b32.
 __device__ __forceinline__ uint32_t pack_lp_perm(int re, int im)
 {
@@ -337,26 +348,46 @@ __device__ __forceinline__ void tile_body(const FmdLaunch& L, const TileCtx& X, 
     __syncthreads();
 
     // ---- low_pass_real: one audio sample per lane -------------------------------------------------
+    // Audio sample k0 + q ends at decimated sample e = eq + q*fa + (er + q*fb) / sr; it sums fa samples, or
+    // fa + 1 when the remainder of that one division is below fb (then the previous group ended one sample
+    // earlier) -- so one small division gives both ends.  Only the first group of a call can be shorter
+    // (it continues the previous call's partial sum, :410-417): one lane redoes it below.
     const uint32_t nk = FMD_ABLATE(7) ? 0u : T.k1 - T.k0;
     int16_t* const outc = L.out + (uint64_t)c * L.out_stride;
     for (uint32_t q = tid; q < nk; q += NT) {
         if (FMD_ABLATE(2)) { outc[T.k0 + q] = d16[q + 1]; continue; }           // ablation: no resampler
-        const int e = (int)(T.eq + q * L.fa + fmd_udiv_small(T.er + q * L.fb, r.sr, L.inv_sr));
-        const int s = q == 0 ? T.jA
-                             : (int)(T.eq + (q - 1) * L.fa + fmd_udiv_small(T.er + (q - 1) * L.fb, r.sr, L.inv_sr)) + 1;
-        int sum = (T.k0 + q == 0) ? st.now_lpr : 0;
+        const uint32_t x = T.er + q * L.fb;
+        const uint32_t u = fmd_udiv_small(x, r.sr, L.inv_sr);
+        const bool extra = x - u * r.sr < L.fb;
+        const int e = (int)(T.eq + q * L.fa + u);
+        int s = e - (int)L.fa + (extra ? 0 : 1);
+        s = s > 0 ? s : 0;                                   // the call's first group starts at 0
         const int16_t* dp = d16 + (s - jfirst);
-        const int n = e - s + 1;                             // fa or fa + 1; only the call's first group can be shorter
-        if (T.k0 == 0 && n < (int)L.fa) {
+        int sum;
+        switch (L.fa) {                                      // wave-uniform: fa unconditional terms + one optional
+            case 1: sum = group_sum<1>(dp, extra); break;
+            case 2: sum = group_sum<2>(dp, extra); break;
+            case 3: sum = group_sum<3>(dp, extra); break;
+            case 4: sum = group_sum<4>(dp, extra); break;
+            case 5: sum = group_sum<5>(dp, extra); break;
+            case 6: sum = group_sum<6>(dp, extra); break;
+            case 7: sum = group_sum<7>(dp, extra); break;
+            case 8: sum = group_sum<8>(dp, extra); break;
+            default: {
+                sum = 0;
 #pragma clang loop vectorize(disable)
-            for (int u = 0; u < n; ++u) sum += dp[u];
-        } else {                                             // fa unconditional terms + one optional
-#pragma clang loop vectorize(disable)
-            for (int u = 0; u < (int)L.fa; ++u) sum += dp[u];
-            const int v = dp[L.fa];
-            sum += n > (int)L.fa ? v : 0;
+                for (int i = 0; i < (int)L.fa; ++i) sum += dp[i];
+                const int v = dp[L.fa];
+                sum += extra ? v : 0;
+            }
         }
         outc[T.k0 + q] = (int16_t)fmd_sdiv_small(sum, r.R, L.inv_R);
+    }
+    if (T.k0 == 0 && tid == 0 && nk > 0) {                   // same lane as the loop's store to outc[0]: this one wins
+        const int e = (int)(T.eq + fmd_udiv_small(T.er, r.sr, L.inv_sr));
+        int sum = st.now_lpr;
+        for (int jj = 0; jj <= e; ++jj) sum += d16[jj - jfirst];
+        outc[0] = (int16_t)fmd_sdiv_small(sum, r.R, L.inv_R);
     }
 
     // ---- Demod state after the call (last tile only; :232-239) -------------------------------------
