@@ -286,7 +286,7 @@ FMD_HD int32_t fmd_fast_atan2(int32_t y, int32_t x)
     return y < 0 ? (int32_t)(0u - (uint32_t)angle) : angle;
 }
 
-// The same function with the cheap exact division; valid while x + |y| < 2^30 (downsample <= 64).
+// The same function with the cheap exact division; valid while |x| + |y| < 2^30 (any downsample <= 128).
 FMD_HD int32_t fmd_fast_atan2_q(int32_t y, int32_t x)
 {
     const uint32_t ux = (uint32_t)x;

@@ -81,7 +81,8 @@ __device__ __forceinline__ int sdot2(uint32_t a, uint32_t b)
 // Demod::polar_discriminant_fast (:377-380) + fast_atan2 (:383-405), branch-free, for packed operands
 // (re | im << 16, components fit i16).  c = a * conj(b) is returned for the f64 sample.
 // Division: |quotient| <= 4097, so an f32 estimate is within 1 and one exact (wrapping) remainder fixes
-// it; valid while x + |y| < 2^30, i.e. downsample <= 64.  Same results as fmd_fast_atan2 (tested).
+// it; valid while |x| + |y| < 2^30, which holds for every downsample <= 128 (|lp| <= 128 * D).  Same results
+// as fmd_fast_atan2 (tested).
 __device__ __forceinline__ int disc_fast(uint32_t a, uint32_t b)
 {
     const uint32_t a_sw = __builtin_amdgcn_alignbit(a, a, 16);          // (im, re)
@@ -568,7 +569,8 @@ size_t fmd_tile_lds_bytes(const FmdLaunch& L)
 
 bool fmd_tile_kernel_supports(const FmdRates& r, uint32_t raw_cap)
 {
-    if (r.D > 64) return false;                                           // disc_fast: x + |y| < 2^30
+    // disc_fast / disc_nosel need |x| + |y| < 2^30: |lp| <= 128*D, so |x| + |y| < 4 * (128*D)^2 <= 2^30 up to D = 128
+    if (r.D > FMD_MAX_DOWNSAMPLE) return false;
     if ((uint64_t)r.sr * (r.kt + 2) >= (1u << 24)) return false;          // fmd_udiv_small operands
     if ((uint64_t)((r.fr + r.sr - 1) / r.sr + 2) * 32768ull >= (1u << 24)) return false;   // |group sum| < 2^24
     if ((uint32_t)r.R >= (1u << 24)) return false;

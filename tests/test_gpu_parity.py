@@ -382,3 +382,28 @@ def test_pinned_host_buffers(fmd, oracle):
     pin_in.close(); pin_out.close()
     p = C.c_void_p()
     assert fmd.lib().fmd_host_alloc(0, C.byref(p)) == -1 and fmd.lib().fmd_host_free(None) == 0
+
+
+@pytest.mark.parametrize("D,fast,slow", [(64, 15000, 8000), (81, 12500, 8000), (127, 8000, 8000), (128, 8000, 4000)])
+def test_large_downsample_full_scale(fmd, oracle, D, fast, slow):
+    """Narrow-band settings (optimal_settings(f, 12500) gives downsample 81): boxcar sums reach +-128*D and the
+    discriminator's |x| + |y| approaches 2^30; rotated full-scale DC of either sign, abrupt sign flips (largest
+    products of consecutive decimated samples) and random data, over ragged calls."""
+    rng = np.random.default_rng(D)
+    pos = np.array([255, 255, 0, 255, 0, 0, 255, 0], np.uint8)        # rotate_90 + centre -> (+128, +128) every sample
+    neg = 255 - pos                                                   # -> (-127, -127)
+    nch = 3
+    blocks = []
+    for i in range(4):
+        n = 8 * int(rng.integers(6 * D, 14 * D))
+        blk = np.empty((nch, n), np.uint8)
+        for c in range(nch):
+            segs, left = [], n
+            while left > 0:
+                m = min(left, 8 * int(rng.integers(1, 3 * D)))
+                kind = int(rng.integers(0, 3))
+                segs.append(np.tile(pos if kind == 0 else neg, m // 8) if kind < 2 else rng.integers(0, 256, m, dtype=np.uint8))
+                left -= m
+            blk[c] = np.concatenate(segs)
+        blocks.append(blk)
+    check_stream(fmd, oracle, D, fast, slow, blocks, n_channels=nch)
