@@ -119,3 +119,29 @@ def test_gpu_fir_errors(fmd):
     with pytest.raises(fmd.FmdError) as ei:
         b.filter_batch(np.zeros((1, 12), np.uint8))
     assert ei.value.status == -2
+
+
+@pytest.mark.gpu
+def test_gpu_fir_fuzz(fmd, oracle):
+    """Random taps / decimation / call sizes, streaming, both kernel forms chosen by the library's own rule
+    (matrix-core form for decim <= 64, VALU form beyond).  FMD_FUZZ_CASES scales the number of cases."""
+    import os
+    n_cases = int(os.environ.get("FMD_FUZZ_CASES", "40"))
+    rng = np.random.default_rng(int(os.environ.get("FMD_FUZZ_SEED", "4242")))
+    for _ in range(n_cases):
+        M = 2 * int(rng.choice([1, 2, 3, 4, 5, 8, 16, 25, 32, 33, 40]))
+        T = int(rng.choice([1, 2, 3, 7, 16, 31, 64, 127, 128, 200, 513, 1024]))
+        taps = rng.integers(-2047, 2048, T).astype(np.int16)
+        nch = int(rng.integers(1, 5))
+        bank = fmd.FirBank(taps, M, nch)
+        hs = [oracle.fir_new(taps, M) for _ in range(nch)]
+        for _ in range(int(rng.integers(1, 5))):
+            n = 8 * int(rng.integers(1, 3000))
+            iq = rng.integers(0, 256, (nch, n), dtype=np.uint8)
+            got = bank.filter_batch(iq)
+            for c in range(nch):
+                exp = oracle.fir_filter(hs[c], iq[c])
+                assert got[c].shape == exp.shape and np.array_equal(got[c], exp), (T, M, n, c)
+        for h in hs:
+            oracle.lib.fmo_fir_free(h)
+        bank.close() if hasattr(bank, "close") else None
