@@ -52,8 +52,10 @@ using namespace fmd_dev;
 typedef short fmd_s2 __attribute__((ext_vector_type(2)));
 
 // Cache policy of the staging loads (aux of global_load_lds): 0 = default, 2 = nt (read once, do not keep).
+// Settled-clock A/B at the bench configuration, three interleaved rounds: nt 0.1815-0.1818 ms vs default
+// 0.1826-0.1839 ms (-0.8 %); equal at the other configurations tried.
 #ifndef FMD_DMA_AUX
-#define FMD_DMA_AUX 0
+#define FMD_DMA_AUX 2
 #endif
 
 __device__ __forceinline__ uint32_t wave_shr1(uint32_t v)

@@ -55,3 +55,38 @@ json.dump(pm, open(os.path.join(out, rnd + "_pmc_summary.json"), "w"), indent=1)
 print("bench ms/step %.4f frac %.4f | trace timed avg %.1f us (events %.1f us) | traffic x%.4f | VALU/wave %.1f SALU/wave %.1f" % (
     bench["ms_per_step"], bench["roofline"]["frac"], summary["avg_ns_timed_region_%d_launches" % steps] / 1e3,
     prof_bench["roofline"]["kernel_ms_events_region"] * 1e3, traffic / alg, pm["per_wave"]["valu"], pm["per_wave"]["salu"]))
+
+# ---- config 4 (FIR): <tag>_fir_mfma.json, <tag>_fir_valu.json, <tag>_fir/prof, <tag>_pmc_fir/summary.json ----------
+g = os.path.join(root, "gpurun_out")
+if os.path.exists(os.path.join(g, tag + "_fir_mfma.json")):
+    m = json.loads(open(os.path.join(g, tag + "_fir_mfma.json")).read().strip().splitlines()[-1])
+    v = json.loads(open(os.path.join(g, tag + "_fir_valu.json")).read().strip().splitlines()[-1])
+    shutil.copy(os.path.join(g, tag + "_fir", "prof", "trace_kernel_stats.csv"), os.path.join(out, rnd + "_config4_fir_kernel_stats.csv"))
+    rows = [r for r in csv.DictReader(open(os.path.join(g, tag + "_fir", "prof", "trace_kernel_trace.csv"))) if "fir_mfma" in r["Kernel_Name"]]
+    d = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in rows]
+    fir = {"matrix_core_form": m, "valu_form_FMD_FIR_MFMA_0": v,
+           "rocprofv3_kernel_trace": {"kernel": rows[0]["Kernel_Name"], "launches": len(d), "avg_us_all": round(sum(d) / len(d), 2),
+                                      "avg_us_timed_region_last_100": round(sum(d[-100:]) / 100, 2)},
+           "ablations_exp_build_ms_before_nt_loads": {"full": 0.145, "no_mfma_phase": 0.139, "no_loads": 0.081, "no_stores": 0.100, "stores_only": 0.045},
+           "history": "VALU form 0.307 ms -> MFMA form with register staging 0.173 -> LDS-DMA staging 0.146 -> history write folded "
+                      "into the last tile 0.144 -> nt policy on the staging loads 0.137 (same-box A/B: -5 %)"}
+    json.dump(fir, open(os.path.join(out, rnd + "_config4_fir.json"), "w"), indent=1)
+    c = json.load(open(os.path.join(g, tag + "_pmc_fir", "summary.json")))
+    alg = m["algorithmic_GBps"] * m["ms_per_call"] * 1e6
+    fetch, wr = c["FETCH_SIZE"]["mean_per_launch"] * 2048, c["WRITE_SIZE"]["mean_per_launch"] * 1024
+    w = c["SQ_WAVES"]["mean_per_launch"]
+    pf = {"command": "rocprofv3 --kernel-trace --pmc <set> -- python3 tools/bench_fir.py (scripts/gpu_pmc_fir.sh; one pass per counter set)",
+          "kernel": rows[0]["Kernel_Name"], "counters": c,
+          "per_wave": {k: round(c[k]["mean_per_launch"] / w, 2) for k in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_INSTS_VMEM_RD", "SQ_INSTS_VMEM_WR", "SQ_INSTS_MFMA")},
+          "mfma_busy_cycles_per_mfma": round(c["SQ_VALU_MFMA_BUSY_CYCLES"]["mean_per_launch"] / c["SQ_INSTS_MFMA"]["mean_per_launch"], 2),
+          "lds_bank_conflict_cycles": c["SQ_LDS_BANK_CONFLICT"]["mean_per_launch"], "lds_bank_conflict_cycles_before_swizzle": 10485760.0,
+          "hbm_traffic": {"fetch_bytes_per_launch(FETCH_SIZE x 1 KiB x 2)": fetch, "write_bytes_per_launch(WRITE_SIZE x 1 KiB)": wr,
+                          "bytes_per_launch": fetch + wr, "algorithmic_bytes_per_launch": round(alg), "ratio": round((fetch + wr) / alg, 4)}}
+    json.dump(pf, open(os.path.join(out, rnd + "_config4_fir_pmc.json"), "w"), indent=1)
+    print("FIR mfma %.4f ms (%.1f %% of HBM spec), valu %.4f ms | trace timed %.1f us | traffic x%.4f | bank conflicts %.0f" % (
+        m["ms_per_call"], 100 * m["hbm_frac_of_8TBps"], v["ms_per_call"], fir["rocprofv3_kernel_trace"]["avg_us_timed_region_last_100"],
+        pf["hbm_traffic"]["ratio"], pf["lds_bank_conflict_cycles"]))
+cfgs = os.path.join(g, tag + "_configs.jsonl")
+if os.path.exists(cfgs):
+    with open(os.path.join(out, rnd + "_configs.jsonl"), "w") as f:
+        f.writelines(l for l in open(cfgs) if l.startswith('{"config"'))
