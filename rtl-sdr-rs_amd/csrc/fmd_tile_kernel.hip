@@ -298,10 +298,42 @@ __device__ __forceinline__ void tile_body(const FmdLaunch& L, const TileCtx& X, 
         const uint32_t wreL = (lastB ? wreB : wreA) & ml, wimL = (lastB ? wimB : wimA) & ml;
         const int cre = fmd_const_re((int)sm + D) - fmd_const_re((int)sm);
         const int cim = fmd_const_im((int)sm + D) - fmd_const_im((int)sm);
+        // Whole-dword windows an even number of dwords long (downsample 12, 16, ... with an even phase): lanes
+        // are ndw dwords apart, so up to 32 of them would hit one LDS bank (PMC at downsample 64: 94 % of the LDS
+        // cycles were bank conflicts).  Each lane therefore walks its window from a different even offset and
+        // wraps; an even rotation keeps the A, B weight order.
+        const bool rotate = (D & 1) == 0 && (p0 & 1u) == 0u && (ndw & 1) == 0 && ndw >= 4;
+        uint32_t rot0 = 0;
+        if (rotate) {
+            const uint32_t low = (uint32_t)ndw & (0u - (uint32_t)ndw);                   // lanes 32 / g apart share a bank,
+            const uint32_t g = low < 32u ? low : 32u;                                    // g = gcd(ndw, 32)
+            rot0 = 2u * ((((lane & 31u) * g) >> 5) % ((uint32_t)ndw >> 1));
+        }
         for (int base = (int)wave * RS; base < last; base += NW * RS) {
             const int i1 = base + (int)lane, i2 = i1 + 64;
             const uint32_t* __restrict__ pa = raw_w + (uint32_t)(wofs + ((s00 + D * i1) >> 1));
             const uint32_t* __restrict__ pb = raw_w + (uint32_t)(wofs + ((s00 + D * i2) >> 1));
+            if (rotate) {
+                int re1 = cre, im1 = cim, re2 = cre, im2 = cim;
+                uint32_t o = rot0;
+                for (int v = 0; v < ndw; v += 2) {
+                    uint32_t wa = pa[o] ^ 0x80808080u, wb = pb[o] ^ 0x80808080u;         // u8 -> s8 (b - 128)
+                    re1 = sdot4(wa, wreA, re1); im1 = sdot4(wa, wimA, im1);
+                    re2 = sdot4(wb, wreA, re2); im2 = sdot4(wb, wimA, im2);
+                    wa = pa[o + 1] ^ 0x80808080u; wb = pb[o + 1] ^ 0x80808080u;
+                    re1 = sdot4(wa, wreB, re1); im1 = sdot4(wa, wimB, im1);
+                    re2 = sdot4(wb, wreB, re2); im2 = sdot4(wb, wimB, im2);
+                    o += 2u;
+                    o = o == (uint32_t)ndw ? 0u : o;
+                }
+                const uint32_t pk1 = pack_lp_perm(re1, im1), pk2 = pack_lp_perm(re2, im2);
+                const uint32_t prev1 = wave_shr1(pk1);
+                const uint32_t prev2 = wave_shr1_old(wave_ror1(pk1), pk2);
+                const int d1 = disc_nosel(pk1, prev1), d2 = disc_nosel(pk2, prev2);
+                if (lane > 0 && i1 < cnt) d16[i1] = (int16_t)d1;
+                if (i2 < cnt) d16[i2] = (int16_t)d2;
+                continue;
+            }
             uint32_t wa = pa[0] ^ 0x80808080u, wb = pb[0] ^ 0x80808080u;                 // u8 -> s8 (b - 128)
             int re1 = sdot4(wa, wreF, cre), im1 = sdot4(wa, wimF, cim);
             int re2 = sdot4(wb, wreF, cre), im2 = sdot4(wb, wimF, cim);
