@@ -148,3 +148,84 @@ impl Drop for Demod {
         unsafe { fmd_demod_free(self.handle) }
     }
 }
+
+/// Many independent streams on one GPU: `n_channels` reference `Demod`s behind one handle (the case the GPU is
+/// for).  `iq` is channel-major `[n_channels][nbytes]`, exactly `n_channels` `read_sync` buffers back to back.
+pub struct DemodBank {
+    handle: *mut fmd_demod,
+    pub config: DemodConfig,
+    pub n_channels: usize,
+}
+
+unsafe impl Send for DemodBank {}
+
+impl DemodBank {
+    pub fn new(config: DemodConfig, n_channels: usize, device_id: i32) -> Result<Self> {
+        let dev = DeviceConfig { n_channels: n_channels as u32, device_id, flags: 0 };
+        let mut handle: *mut fmd_demod = std::ptr::null_mut();
+        check(unsafe { fmd_demod_new(&config, &dev, &mut handle) })?;
+        Ok(DemodBank { handle, config, n_channels })
+    }
+
+    /// One `Demod::demodulate` per channel; returns one `Vec<i16>` per channel.
+    pub fn demodulate(&mut self, iq: &[u8]) -> Result<Vec<Vec<i16>>> {
+        assert!(iq.len() % self.n_channels == 0, "iq must hold n_channels equal-sized buffers");
+        let nbytes = iq.len() / self.n_channels;
+        let cap = unsafe { fmd_out_cap(&self.config, nbytes) } + 1;
+        let mut out = vec![0i16; cap * self.n_channels];
+        let mut lens = vec![0usize; self.n_channels];
+        check(unsafe { fmd_demod_demodulate_batch(self.handle, iq.as_ptr(), nbytes, out.as_mut_ptr(), cap, lens.as_mut_ptr()) })?;
+        Ok((0..self.n_channels).map(|c| out[c * cap..c * cap + lens[c]].to_vec()).collect())
+    }
+}
+
+impl Drop for DemodBank {
+    fn drop(&mut self) {
+        unsafe { fmd_demod_free(self.handle) }
+    }
+}
+
+/// The producer side of the boundary as a trait: `RtlSdr::read_sync(&self, buf: &mut [u8]) -> Result<usize>`
+/// (src/lib.rs:153).  The reference has no `read_async`; this does not add one.
+pub trait IqSource {
+    /// Fill `buf` with interleaved u8 I/Q; the number of bytes written, `< buf.len()` meaning samples were lost
+    /// or the source ended (callers of the reference treat that as fatal, examples/simple_fm.rs:122).
+    fn read_sync(&mut self, buf: &mut [u8]) -> std::result::Result<usize, Box<dyn std::error::Error>>;
+}
+
+/// File / stdin mode of the example (examples/simple_fm.rs:65-84): any `Read` is a source.
+impl<R: std::io::Read> IqSource for R {
+    fn read_sync(&mut self, buf: &mut [u8]) -> std::result::Result<usize, Box<dyn std::error::Error>> {
+        let mut got = 0;
+        while got < buf.len() {
+            let n = self.read(&mut buf[got..])?;
+            if n == 0 {
+                break;
+            }
+            got += n;
+        }
+        Ok(got)
+    }
+}
+
+/// `receive()` + `process()` of the example (examples/simple_fm.rs:100-170) in one loop: blocks of
+/// `block_len` bytes (the reference uses DEFAULT_BUF_LENGTH = 262144, src/lib.rs:25) from `source` through the GPU
+/// `Demod` into `sink` as raw native-endian s16 (`output()`, examples/simple_fm.rs:430-438).  A short final block
+/// ends the stream as in the reference (:122-125).
+pub fn run<S: IqSource, W: std::io::Write>(source: &mut S, demod: &mut Demod, sink: &mut W, block_len: usize)
+    -> std::result::Result<u64, Box<dyn std::error::Error>> {
+    let mut total = 0u64;
+    let mut buf = vec![0u8; block_len];
+    loop {
+        let n = source.read_sync(&mut buf)?;
+        if n < block_len {
+            break;
+        }
+        let audio = demod.demodulate(buf.clone())?;
+        let bytes = unsafe { std::slice::from_raw_parts(audio.as_ptr() as *const u8, audio.len() * 2) };
+        sink.write_all(bytes)?;
+        sink.flush()?;
+        total += audio.len() as u64;
+    }
+    Ok(total)
+}
