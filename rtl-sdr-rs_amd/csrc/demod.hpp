@@ -81,6 +81,39 @@ private:
     fmd_demod* h_ = nullptr;
 };
 
+// n independent Demods on one GPU behind one handle (one `Demod` per stream, simple_fm.rs:137): `iq` holds
+// n_channels equal-sized read_sync buffers back to back.
+class DemodBank {
+public:
+    DemodBank(const DemodConfig& config, uint32_t n_channels, int device_id = -1) : config_(config), n_(n_channels)
+    {
+        fmd_device_config dev{n_channels, device_id, 0u};
+        check(fmd_demod_new(&config_, &dev, &h_));
+    }
+    ~DemodBank() { fmd_demod_free(h_); }
+    DemodBank(const DemodBank&) = delete;
+    DemodBank& operator=(const DemodBank&) = delete;
+
+    // out[c] = Demod::demodulate(channel c's buffer); `len` bytes per channel
+    std::vector<std::vector<int16_t>> demodulate(const uint8_t* iq, size_t len)
+    {
+        const size_t cap = fmd_out_cap(&config_, len) + 1;
+        std::vector<int16_t> flat(cap * n_);
+        std::vector<size_t> lens(n_);
+        check(fmd_demod_demodulate_batch(h_, iq, len, flat.data(), cap, lens.data()));
+        std::vector<std::vector<int16_t>> out(n_);
+        for (uint32_t c = 0; c < n_; ++c) out[c].assign(flat.begin() + c * cap, flat.begin() + c * cap + lens[c]);
+        return out;
+    }
+    uint32_t channels() const { return n_; }
+    const DemodConfig& config() const { return config_; }
+
+private:
+    DemodConfig config_;
+    uint32_t n_;
+    fmd_demod* h_ = nullptr;
+};
+
 // output(buf: Vec<i16>), simple_fm.rs:430-438: raw native-endian s16 to stdout, flushed.
 inline void output(const std::vector<int16_t>& buf, FILE* f = stdout)
 {

@@ -7,6 +7,9 @@
 // Defaults are the example's constants: FREQUENCY 94.9 MHz (unused here), SAMPLE_RATE 170 kHz, RATE_RESAMPLE 32 kHz
 // (:25-27) through optimal_settings (:48,189-214).
 //
+// Several input files: one channel per file in ONE bank (one Demod per stream, :137), block-synchronous; audio of
+// file k goes to <prefix>.<k>.s16 (-o prefix, default "audio") and the run ends with the shortest file.
+//
 // EOF policy (the reference ignores the read count and never terminates at EOF): only COMPLETE
 // blocks are demodulated; a trailing partial block is dropped with a note on stderr.  Logging goes to stderr
 // because stdout carries audio (:37-38).
@@ -18,20 +21,61 @@
 
 #include "demod.hpp"
 
+// one channel per file, all channels in one bank
+static int run_bank(const std::vector<const char*>& paths, const char* prefix, uint32_t freq, uint32_t rate, uint32_t resample)
+{
+    const size_t C = paths.size(), N = fm::DEFAULT_BUF_LENGTH;
+    std::vector<FILE*> in(C, nullptr), out(C, nullptr);
+    int rc = 0;
+    try {
+        for (size_t c = 0; c < C; ++c) {
+            if (!(in[c] = fopen(paths[c], "rb"))) { perror(paths[c]); throw 2; }
+            char name[4096];
+            snprintf(name, sizeof name, "%s.%zu.s16", prefix, c);
+            if (!(out[c] = fopen(name, "wb"))) { perror(name); throw 2; }
+        }
+        const auto settings = fm::optimal_settings(freq, rate, resample);
+        fm::DemodBank bank(settings.second, (uint32_t)C);
+        std::vector<uint8_t> buf(C * N);
+        size_t loops = 0;
+        for (;; ++loops) {
+            bool full = true;
+            for (size_t c = 0; c < C && full; ++c) full = fread(buf.data() + c * N, 1, N, in[c]) == N;
+            if (!full) break;                                   // the shortest file ends the run; partial blocks dropped
+            const auto audio = bank.demodulate(buf.data(), N);
+            for (size_t c = 0; c < C; ++c) fm::output(audio[c], out[c]);
+        }
+        fprintf(stderr, "%zu channels x %zu blocks\n", C, loops);
+    } catch (const fm::Error& e) {
+        fprintf(stderr, "error: %s\n", e.what());
+        rc = 1;
+    } catch (int code) {
+        rc = code;
+    }
+    for (size_t c = 0; c < C; ++c) { if (in[c]) fclose(in[c]); if (out[c]) fclose(out[c]); }
+    return rc;
+}
+
 int main(int argc, char** argv)
 {
     uint32_t rate = 170000, resample = 32000, freq = 94900000;
     const char* path = nullptr;
+    const char* prefix = "audio";
+    std::vector<const char*> paths;
     for (int i = 1; i < argc; ++i) {
         if (!strcmp(argv[i], "-s") && i + 1 < argc) rate = (uint32_t)strtoul(argv[++i], nullptr, 10);
         else if (!strcmp(argv[i], "-r") && i + 1 < argc) resample = (uint32_t)strtoul(argv[++i], nullptr, 10);
         else if (!strcmp(argv[i], "-f") && i + 1 < argc) freq = (uint32_t)strtoul(argv[++i], nullptr, 10);
+        else if (!strcmp(argv[i], "-o") && i + 1 < argc) prefix = argv[++i];
         else if (!strcmp(argv[i], "-h") || !strcmp(argv[i], "--help")) {
-            fprintf(stderr, "usage: %s [-f freq_hz] [-s sample_rate_hz] [-r resample_hz] <capture.bin | ->\n", argv[0]);
+            fprintf(stderr, "usage: %s [-f freq_hz] [-s sample_rate_hz] [-r resample_hz] <capture.bin | ->\n"
+                            "       %s [-s ...] [-r ...] [-o prefix] <a.bin> <b.bin> ...   (one channel per file)\n", argv[0], argv[0]);
             return 0;
-        } else path = argv[i];
+        } else paths.push_back(argv[i]);
     }
-    if (!path) { fprintf(stderr, "missing input file (use - for stdin)\n"); return 2; }
+    if (paths.empty()) { fprintf(stderr, "missing input file (use - for stdin)\n"); return 2; }
+    if (paths.size() > 1) return run_bank(paths, prefix, freq, rate, resample);
+    path = paths[0];
     FILE* in = strcmp(path, "-") ? fopen(path, "rb") : stdin;
     if (!in) { perror(path); return 2; }
     try {

@@ -42,3 +42,26 @@ def test_cli_file_mode_matches_oracle(fmd, oracle, tmp_path):
     assert p2.returncode == 0, p2.stderr.decode()
     _, cfg2 = oracle.optimal_settings(94_900_000, 240_000, 48_000)
     assert np.array_equal(np.frombuffer(p2.stdout, dtype=np.int16), oracle_file_mode(oracle, cfg2, data, N))
+
+
+def test_cli_bank_mode_one_channel_per_file(fmd, oracle, tmp_path):
+    """Several input files = one channel per file in one bank; every output file equals the oracle's file mode of
+    its input over the blocks the shortest file allows."""
+    N = fmd.DEFAULT_BUF_LENGTH
+    blocks = [3, 2, 3]
+    paths = []
+    datas = []
+    for k, nb in enumerate(blocks):
+        d = fmd.synth.synth_iq(1, nb * N + 1000 * k, seed=100 + k, amplitude=40 + 30 * k)[0]
+        p = tmp_path / ("cap%d.bin" % k)
+        d.tofile(p)
+        paths.append(str(p)); datas.append(d)
+    prefix = str(tmp_path / "out")
+    r = subprocess.run([CLI, "-o", prefix] + paths, capture_output=True, timeout=120)
+    assert r.returncode == 0, r.stderr.decode()
+    assert b"3 channels x 2 blocks" in r.stderr
+    _, cfg = oracle.optimal_settings(94_900_000, 170_000)
+    for k in range(3):
+        got = np.fromfile("%s.%d.s16" % (prefix, k), dtype=np.int16)
+        exp = oracle_file_mode(oracle, cfg, datas[k][:2 * N], N)
+        assert got.size == exp.size and np.array_equal(got, exp), k
