@@ -121,6 +121,17 @@ int fmd_demod_demodulate_batch(fmd_demod *d, const uint8_t *iq, size_t nbytes,
 int fmd_demod_demodulate_device(fmd_demod *d, const void *d_iq, size_t nbytes,
                                 void *d_out, size_t out_cap, void *d_out_len, void *stream);
 
+/* Several reference calls per launch.  Demod::demodulate takes the f64 atan2 path for the first
+ * decimated sample of EVERY call (simple_fm.rs:359), so the audio of a stream depends on where
+ * the caller cut it into buffers.  After fmd_demod_set_block_len(d, block_bytes) every
+ * demodulate_* call is treated as the concatenation of nbytes / block_bytes consecutive
+ * reference calls of block_bytes each (nbytes must be a multiple): one launch then returns
+ * exactly the concatenated audio -- and leaves exactly the state -- of feeding the reference
+ * those blocks one by one, e.g. 256 x DEFAULT_BUF_LENGTH in one 64 MiB launch.  block_bytes
+ * % 8 == 0 and >= 4 * downsample bytes (every block yields >= 2 decimated samples, :356);
+ * 0 (the default) switches it off: one call = one reference call. */
+int fmd_demod_set_block_len(fmd_demod *d, size_t block_bytes);
+
 /* Per-channel sample counts of the most recent demodulate_* call (host bookkeeping). */
 int fmd_demod_last_out_len(const fmd_demod *d, size_t *out_len /* [n_channels] */);
 

@@ -74,6 +74,8 @@ public:
         return s;
     }
     void set_state(const fmd_demod_state& s) { check(fmd_demod_set_state(h_, 0, &s)); }
+    // treat every buffer as consecutive reference calls of block_bytes each (0 = off); see fmd_demod_set_block_len
+    void set_block_len(size_t block_bytes) { check(fmd_demod_set_block_len(h_, block_bytes)); }
     const DemodConfig& config() const { return config_; }
 
 private:

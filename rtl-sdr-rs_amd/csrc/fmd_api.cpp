@@ -64,6 +64,7 @@ struct fmd_demod {
     uint32_t C = 0;
     int device = 0;
     uint32_t lp_cap = 0, raw_cap = 0;
+    uint32_t block_ns = 0;                // fmd_demod_set_block_len: samples per reference call inside one launch
     bool force_generic = false;
     bool stream_mode = false;             // register-streaming kernel: tiling = its round size
     uint32_t rounds_per_wave = 7;         // FMD_RPW
@@ -174,6 +175,16 @@ int plan_call(const fmd_demod* d, size_t nbytes, size_t out_cap, std::vector<Fmd
 {
     if (nbytes % 8 != 0) { set_err("nbytes %% 8 != 0 (simple_fm.rs:286 would panic)"); return FMD_ERR_BAD_LENGTH; }
     const uint64_t ns = nbytes / 2;
+    if (d->block_ns) {
+        if (ns % d->block_ns != 0) {
+            set_err("nbytes %zu is not a multiple of the block length %u set by fmd_demod_set_block_len", nbytes, 2u * d->block_ns);
+            return FMD_ERR_BAD_LENGTH;
+        }
+        if (!tile_kernel_ok(d)) {
+            set_err("several reference calls per launch need the tile kernel (<= %d phase classes)", FMD_MAX_CLASSES);
+            return FMD_ERR_UNSUPPORTED;
+        }
+    }
     if (!fmd_ranges_fit32(d->r, ns)) {
         set_err("call of %zu bytes exceeds the 32-bit index range for these rates", nbytes);
         return FMD_ERR_UNSUPPORTED;
@@ -219,6 +230,7 @@ int enqueue(fmd_demod* d, const void* d_iq, size_t nbytes, void* d_out, size_t o
     L.total_bytes = (uint64_t)nbytes * d->C;
     L.r = d->r;
     L.ns = (uint32_t)(nbytes / 2);
+    L.block_ns = d->block_ns;
     L.n_channels = d->C;
     L.tiles = tiles;
     L.lp_cap = d->lp_cap;
@@ -254,7 +266,7 @@ int enqueue(fmd_demod* d, const void* d_iq, size_t nbytes, void* d_out, size_t o
         L.block_threads = d->block_threads;
         bool even_phases = true;                              // whole-dword windows in every class
         for (const PhaseClass& pc : d->classes) even_phases &= (pc.p0 % 2 == 0);
-        if (d->stream_mode && even_phases && fmd_stream_kernel_supports(r)) {
+        if (d->stream_mode && even_phases && !d->block_ns && fmd_stream_kernel_supports(r)) {
             L.rounds_per_wave = d->rounds_per_wave;
             L.group_rounds = fmd_stream_group_rounds(r);
             HIP_TRY(fmd_launch_stream(L, stream));
@@ -538,6 +550,20 @@ int fmd_host_free(void* ptr)
 {
     if (!ptr) return FMD_OK;
     HIP_TRY(hipHostFree(ptr));
+    return FMD_OK;
+}
+
+int fmd_demod_set_block_len(fmd_demod* d, size_t block_bytes)
+{
+    if (!d) { set_err("null argument"); return FMD_ERR_INVALID_ARG; }
+    if (block_bytes == 0) { d->block_ns = 0; return FMD_OK; }
+    if (block_bytes % 8 != 0) { set_err("block_bytes %% 8 != 0 (simple_fm.rs:286 would panic on every block)"); return FMD_ERR_BAD_LENGTH; }
+    if (block_bytes / 2 < 2ull * d->r.D) {
+        set_err("a block of %zu bytes yields fewer than 2 decimated samples at downsample %u (simple_fm.rs:356)", block_bytes, d->r.D);
+        return FMD_ERR_TOO_SHORT;
+    }
+    if (block_bytes / 2 > (1ull << 30)) { set_err("block_bytes out of range"); return FMD_ERR_UNSUPPORTED; }
+    d->block_ns = (uint32_t)(block_bytes / 2);
     return FMD_OK;
 }
 

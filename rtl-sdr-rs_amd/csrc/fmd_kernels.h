@@ -21,6 +21,7 @@ struct FmdLaunch {
     uint64_t total_bytes;     // n_channels * chan_stride
     FmdRates r;
     uint32_t ns;              // complex samples per channel this call
+    uint32_t block_ns;        // > 0: the call is ns / block_ns consecutive reference calls of block_ns samples each
     uint32_t n_channels;
     uint32_t tiles;           // grid tiles per channel (>= every channel's own tile count)
     uint32_t lp_cap;          // LDS sizing: decimated samples per tile

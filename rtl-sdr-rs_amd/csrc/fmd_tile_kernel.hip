@@ -410,6 +410,29 @@ __device__ __forceinline__ void tile_body(const FmdLaunch& L, const TileCtx& X, 
         d16[1 - jfirst] = (int16_t)fmd_fast_atan2(ci, cr);
     }
     __syncthreads();
+    // Several reference calls in one launch (fmd_demod_set_block_len): reference call b >= 1 starts at sample
+    // b * block_ns, and its first decimated sample -- index (p0 + b * block_ns) / D of this launch -- takes the
+    // f64 path against its predecessor (:359).  A tile owns discriminator samples jA .. jB; at most a few
+    // boundaries fall into one, and one lane redoes them -- after the barrier (another wave's loop wrote the entry)
+    // and with a second one before the resampler reads it.
+    if (L.block_ns && tid == 0) {
+        const uint32_t D = r.D, nb = L.block_ns;
+        const uint32_t lo = (uint32_t)(T.jA > 1 ? T.jA : 1) * D;             // first sample count that can complete sample jA
+        uint32_t b = lo > p0 ? (lo - p0 + nb - 1u) / nb : 1u;                 // smallest b with (p0 + b*nb) / D >= max(jA, 1)
+        if (b == 0u) b = 1u;
+        for (; (uint64_t)b * nb < L.ns; ++b) {
+            const int j = (int)((p0 + b * nb) / D);
+            if (j > T.jB) break;
+            if (j < T.jA) continue;
+            int ar, ai, br, bi, cr, ci;
+            lds_window_sum(raw_w, wofs, fmd_win_begin(D, p0, j), fmd_win_end(D, p0, j), ar, ai);
+            lds_window_sum(raw_w, wofs, fmd_win_begin(D, p0, j - 1), fmd_win_end(D, p0, j - 1), br, bi);
+            if (j - 1 == 0) { br += st.lp_now_re; bi += st.lp_now_im; }
+            fmd_mul_conj(ar, ai, br, bi, cr, ci);
+            d16[j - jfirst] = (int16_t)polar_f64(cr, ci);
+        }
+    }
+    if (L.block_ns) __syncthreads();
 
     // ---- low_pass_real: one audio sample per lane -------------------------------------------------
     // Audio sample k0 + q ends at decimated sample e = eq + q*fa + (er + q*fb) / sr; it sums fa samples, or

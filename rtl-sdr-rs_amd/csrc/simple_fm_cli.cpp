@@ -59,6 +59,7 @@ static int run_bank(const std::vector<const char*>& paths, const char* prefix, u
 int main(int argc, char** argv)
 {
     uint32_t rate = 170000, resample = 32000, freq = 94900000;
+    size_t per_launch = 1;                                   // -b: reference blocks handed to the GPU per launch
     const char* path = nullptr;
     const char* prefix = "audio";
     std::vector<const char*> paths;
@@ -67,8 +68,9 @@ int main(int argc, char** argv)
         else if (!strcmp(argv[i], "-r") && i + 1 < argc) resample = (uint32_t)strtoul(argv[++i], nullptr, 10);
         else if (!strcmp(argv[i], "-f") && i + 1 < argc) freq = (uint32_t)strtoul(argv[++i], nullptr, 10);
         else if (!strcmp(argv[i], "-o") && i + 1 < argc) prefix = argv[++i];
+        else if (!strcmp(argv[i], "-b") && i + 1 < argc) { per_launch = strtoul(argv[++i], nullptr, 10); if (!per_launch) per_launch = 1; }
         else if (!strcmp(argv[i], "-h") || !strcmp(argv[i], "--help")) {
-            fprintf(stderr, "usage: %s [-f freq_hz] [-s sample_rate_hz] [-r resample_hz] <capture.bin | ->\n"
+            fprintf(stderr, "usage: %s [-f freq_hz] [-s sample_rate_hz] [-r resample_hz] [-b blocks_per_launch] <capture.bin | ->\n"
                             "       %s [-s ...] [-r ...] [-o prefix] <a.bin> <b.bin> ...   (one channel per file)\n", argv[0], argv[0]);
             return 0;
         } else paths.push_back(argv[i]);
@@ -86,7 +88,9 @@ int main(int argc, char** argv)
         fprintf(stderr, "Output scale: %u\n", dc.output_scale);                     // :140
         fprintf(stderr, "capture_rate: %u capture_freq: %u\n", settings.first.capture_rate, settings.first.capture_freq);
         fm::Demod demod(dc);
-        std::vector<uint8_t> buf(fm::DEFAULT_BUF_LENGTH);
+        // -b N: N blocks per launch with the result of N single calls (the f64 sample at every block start, :359)
+        if (per_launch > 1) demod.set_block_len(fm::DEFAULT_BUF_LENGTH);
+        std::vector<uint8_t> buf(fm::DEFAULT_BUF_LENGTH * per_launch);
         size_t fill = 0, loops = 0;
         std::chrono::duration<double> total(0);
         for (;;) {
@@ -100,10 +104,16 @@ int main(int argc, char** argv)
             const std::vector<int16_t> audio = demod.demodulate(buf);              // :80
             total += std::chrono::steady_clock::now() - t0;
             fm::output(audio);                                                      // :82
-            ++loops;
+            loops += per_launch;
             fill = 0;
         }
-        if (fill) fprintf(stderr, "dropped %zu trailing bytes (not a complete %zu-byte block)\n", fill, buf.size());
+        if (per_launch > 1 && fill >= fm::DEFAULT_BUF_LENGTH) {                     // complete blocks of a partly filled launch
+            const size_t whole = fill / fm::DEFAULT_BUF_LENGTH * fm::DEFAULT_BUF_LENGTH;
+            fm::output(demod.demodulate(buf.data(), whole));
+            loops += whole / fm::DEFAULT_BUF_LENGTH;
+            fill -= whole;
+        }
+        if (fill) fprintf(stderr, "dropped %zu trailing bytes (not a complete %zu-byte block)\n", fill, (size_t)fm::DEFAULT_BUF_LENGTH);
         if (loops)                                                                  // :162-168
             fprintf(stderr, "Average processing time: %.2fms (%zu loops)\n", 1e3 * total.count() / (double)loops, loops);
     } catch (const fm::Error& e) {

@@ -114,6 +114,10 @@ class DemodBank:
         check(lib().fmd_demod_tiling(self._h, C.byref(a), C.byref(b), C.byref(c)))
         return {"audio_per_tile": a.value, "lds_bytes": b.value, "block_threads": c.value}
 
+    def set_block_len(self, block_bytes):
+        """Treat every call as nbytes / block_bytes consecutive reference calls (0 = off): fmd_demod_set_block_len."""
+        check(lib().fmd_demod_set_block_len(self._h, block_bytes))
+
     def set_tiling(self, audio_per_tile):
         check(lib().fmd_demod_set_tiling(self._h, audio_per_tile))
 

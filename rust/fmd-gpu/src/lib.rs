@@ -62,6 +62,7 @@ extern "C" {
     pub fn fmd_demod_demodulate(d: *mut fmd_demod, iq: *const u8, nbytes: usize, out: *mut i16, out_cap: usize, out_len: *mut usize) -> c_int;
     pub fn fmd_demod_demodulate_batch(d: *mut fmd_demod, iq: *const u8, nbytes: usize, out: *mut i16, out_cap: usize, out_len: *mut usize) -> c_int;
     pub fn fmd_demod_demodulate_device(d: *mut fmd_demod, d_iq: *const c_void, nbytes: usize, d_out: *mut c_void, out_cap: usize, d_out_len: *mut c_void, stream: *mut c_void) -> c_int;
+    pub fn fmd_demod_set_block_len(d: *mut fmd_demod, block_bytes: usize) -> c_int;
     pub fn fmd_demod_last_out_len(d: *const fmd_demod, out_len: *mut usize) -> c_int;
     pub fn fmd_host_alloc(nbytes: usize, ptr: *mut *mut c_void) -> c_int;
     pub fn fmd_host_free(ptr: *mut c_void) -> c_int;

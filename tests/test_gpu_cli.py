@@ -37,6 +37,11 @@ def test_cli_file_mode_matches_oracle(fmd, oracle, tmp_path):
     exp = oracle_file_mode(oracle, cfg, data, N)
     assert got.size == exp.size and np.array_equal(got, exp)
     assert b"dropped 4096 trailing bytes" in p.stderr           # EOF policy: complete blocks only
+    # several blocks per launch (-b): byte-identical stdout, incl. a launch that is only partly filled
+    for b in ("2", "4", "64"):
+        pb = subprocess.run([CLI, "-b", b, str(path)], capture_output=True, timeout=120)
+        assert pb.returncode == 0 and pb.stdout == p.stdout, b
+        assert b"dropped 4096 trailing bytes" in pb.stderr
     # and through stdin with other rates
     p2 = subprocess.run([CLI, "-s", "240000", "-r", "48000", "-"], input=data.tobytes(), capture_output=True, timeout=120)
     assert p2.returncode == 0, p2.stderr.decode()

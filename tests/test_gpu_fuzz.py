@@ -90,3 +90,44 @@ def test_fuzz_desynchronised_phases(fmd, oracle):
         for c in range(nch):
             assert gpu_state(bank, c) == oracle.state_of(obank[c]), (D, fast, slow, ncls, c)
         bank.close()
+
+
+def test_fuzz_several_reference_calls_per_launch(fmd, oracle):
+    """Random rates / block lengths / block counts with fmd_demod_set_block_len: one launch == the oracle fed block
+    by block."""
+    n_cases = max(8, int(os.environ.get("FMD_FUZZ_CASES", "40")) // 2)
+    rng = np.random.default_rng(int(os.environ.get("FMD_FUZZ_SEED", "20260101")) + 5)
+    done = 0
+    while done < n_cases:
+        D, fast, slow = random_case(rng)
+        nch = int(rng.integers(1, 4))
+        block = 8 * int(rng.integers(max(1, (4 * D + 7) // 8), 12 * D + 300))
+        try:
+            bank = fmd.DemodBank(mkcfg(fmd, D, fast, slow), nch)
+            bank.set_block_len(block)
+        except fmd.FmdError as e:
+            assert e.status in (-3, -6), (D, fast, slow, block, e)
+            continue
+        if rng.random() < 0.5:
+            try:
+                bank.set_tiling(int(rng.integers(1, 300)))
+            except fmd.FmdError as e:                    # tile would not fit LDS: the previous tiling stays
+                assert e.status == -6
+        obank = oracle.new_bank(oracle.config(D, fast, slow), nch)
+        ok = True
+        for _ in range(int(rng.integers(1, 4))):
+            B = int(rng.integers(1, 9))
+            iq = rng.integers(0, 256, (nch, B * block), dtype=np.uint8)
+            try:
+                got = bank.demodulate_batch(iq)
+            except fmd.FmdError as e:
+                assert e.status in (-5, -6), (D, fast, slow, block, B, e)
+                ok = False
+                break
+            for c in range(nch):
+                exp = np.concatenate([oracle.demodulate(obank[c], iq[c, b * block:(b + 1) * block]) for b in range(B)])
+                assert got[c].size == exp.size and np.array_equal(got[c], exp), (D, fast, slow, block, B, c)
+            for c in range(nch):
+                assert gpu_state(bank, c) == oracle.state_of(obank[c]), (D, fast, slow, block, B, c)
+        bank.close()
+        done += ok

@@ -407,3 +407,42 @@ def test_large_downsample_full_scale(fmd, oracle, D, fast, slow):
             blk[c] = np.concatenate(segs)
         blocks.append(blk)
     check_stream(fmd, oracle, D, fast, slow, blocks, n_channels=nch)
+
+
+@pytest.mark.parametrize("D,fast,slow,block", [(6, 170000, 32000, 262144), (10, 240000, 32000, 262144), (10, 240000, 32000, 4096),
+                                               (7, 166666, 32000, 30008), (5, 250000, 44100, 1000), (16, 150000, 32000, 8192),
+                                               (2, 500000, 32000, 64)])
+def test_several_reference_calls_per_launch(fmd, oracle, D, fast, slow, block):
+    """fmd_demod_set_block_len: one launch over B blocks == the oracle (the reference) fed those B blocks one by
+    one -- same audio (incl. the f64 sample at every block start, simple_fm.rs:359) and same state; then a second
+    launch continues the stream, and switching the mode off again gives single-call semantics back."""
+    rng = np.random.default_rng(D + block)
+    nch = 3
+    bank = fmd.DemodBank(mkcfg(fmd, D, fast, slow), nch)
+    bank.set_block_len(block)
+    obank = oracle.new_bank(oracle.config(D, fast, slow), nch)
+    for B in (5, 3):
+        iq = rng.integers(0, 256, (nch, B * block), dtype=np.uint8)
+        if B == 3:
+            iq[:, :block] = np.where(rng.integers(0, 2, (nch, block)) > 0, 255, 0)       # a full-scale block
+        got = bank.demodulate_batch(iq)
+        for c in range(nch):
+            parts = [oracle.demodulate(obank[c], iq[c, b * block:(b + 1) * block]) for b in range(B)]
+            exp = np.concatenate(parts)
+            assert got[c].size == exp.size and np.array_equal(got[c], exp), (B, c)
+        for c in range(nch):
+            assert gpu_state(bank, c) == oracle.state_of(obank[c])
+    with pytest.raises(fmd.FmdError) as ei:
+        bank.demodulate_batch(np.zeros((nch, block + 8), np.uint8))                     # not a multiple of the block
+    assert ei.value.status == -2
+    bank.set_block_len(0)
+    iq = rng.integers(0, 256, (nch, 2 * block + 8 * D * 4), dtype=np.uint8)
+    got = bank.demodulate_batch(iq)
+    for c in range(nch):
+        assert np.array_equal(got[c], oracle.demodulate(obank[c], iq[c]))
+    with pytest.raises(fmd.FmdError):
+        bank.set_block_len(12)
+    if D >= 4:
+        with pytest.raises(fmd.FmdError) as ei:
+            bank.set_block_len(8 * (D // 4))                                            # < 2 decimated samples per block
+        assert ei.value.status == -3

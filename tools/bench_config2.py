@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """BASELINE configs[1]: ONE synthetic FM channel at 2.4 Msps on one MI355X (device-resident input).
 (a) DEFAULT_BUF_LENGTH per call -- launch-latency bound; (b) 64 MiB per call -- time-tiled
-inside the channel.  Prints one JSON line; reported in DESIGN.md, not by bench.py."""
+inside the channel; (c) the same 64 MiB handed over as 256 reference calls in one launch (fmd_demod_set_block_len).  Prints one JSON line; reported in DESIGN.md, not by bench.py."""
 import json, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -9,8 +9,10 @@ import rtl_sdr_rs_amd as fmd
 
 cfg = fmd.DemodConfig(240000, 240000, 32000, 10, 25)
 res = {}
-for name, n, steps in [("262144_B_per_call", fmd.DEFAULT_BUF_LENGTH, 2000), ("64_MiB_per_call", 64 << 20, 100)]:
+for name, n, steps, blk in [("262144_B_per_call", fmd.DEFAULT_BUF_LENGTH, 2000, 0), ("64_MiB_per_call", 64 << 20, 100, 0),
+                            ("64_MiB_per_launch_as_256_reference_calls_of_262144_B", 64 << 20, 100, fmd.DEFAULT_BUF_LENGTH)]:
     bank = fmd.DemodBank(cfg, 1)
+    bank.set_block_len(blk)
     iq = torch.empty((1, n), dtype=torch.uint8, device="cuda")
     stream = torch.cuda.current_stream().cuda_stream
     fmd.synth.fill_device(iq.data_ptr(), 1, n, stream=stream)
