@@ -61,10 +61,14 @@ extern "C" {
 
 // Returns number of s16 written, or -1 bad length, -2 fewer than two decimated samples,
 // -3 capacity, -4 bad rates.  `st` is updated like Demod's fields.
-long fmcf_demodulate(uint32_t D, uint32_t fast, uint32_t slow, uint32_t kt, FmdChanState* st,
-                     const uint8_t* buf, size_t nbytes, int16_t* out, size_t out_cap)
+// block_ns > 0: the buffer is nbytes / (2 * block_ns) consecutive reference calls (fmd_demod_set_block_len): the
+// first decimated sample of every block takes the f64 path, index (p0 + b * block_ns) / D -- the same expression
+// the kernel uses.
+long fmcf_demodulate_blocks(uint32_t D, uint32_t fast, uint32_t slow, uint32_t kt, uint32_t block_ns, FmdChanState* st,
+                            const uint8_t* buf, size_t nbytes, int16_t* out, size_t out_cap)
 {
     if (nbytes % 8) return -1;
+    if (block_ns && ((nbytes / 2) % block_ns != 0 || block_ns < 2 * D)) return -1;
     if (D == 0 || slow == 0 || fast < slow || kt == 0) return -4;
     FmdRates r;
     r.D = D; r.fast = fast; r.slow = slow;
@@ -100,7 +104,14 @@ long fmcf_demodulate(uint32_t D, uint32_t fast, uint32_t slow, uint32_t kt, FmdC
         for (int32_t i = 1; i < cnt; i++) {
             int32_t cr, ci;
             fmd_mul_conj(lre[i], lim[i], lre[i - 1], lim[i - 1], cr, ci);
-            const int32_t pcm = (jfirst + i == 0) ? polar_f64(cr, ci) : fmd_fast_atan2(ci, cr);
+            const uint32_t j = (uint32_t)(jfirst + i);
+            bool first_of_a_call = j == 0;
+            if (block_ns && j > 0) {                                              // j == (p0 + b*block_ns) / D for some b >= 1 ?
+                const uint64_t lo = (uint64_t)j * D, hi = lo + D;                 // p0 + b*block_ns in [lo, hi)
+                const uint64_t b = lo > p0 ? (lo - p0 + block_ns - 1) / block_ns : 1;
+                first_of_a_call = b >= 1 && p0 + b * block_ns < hi && p0 + b * block_ns >= lo && b * (uint64_t)block_ns < ns;
+            }
+            const int32_t pcm = first_of_a_call ? polar_f64(cr, ci) : fmd_fast_atan2(ci, cr);
             d[i] = (int16_t)(uint16_t)(uint32_t)pcm;
         }
         for (uint32_t k = T.k0; k < T.k1; k++) {
@@ -127,6 +138,12 @@ long fmcf_demodulate(uint32_t D, uint32_t fast, uint32_t slow, uint32_t kt, FmdC
     }
     *st = nst;
     return (long)K;
+}
+
+long fmcf_demodulate(uint32_t D, uint32_t fast, uint32_t slow, uint32_t kt, FmdChanState* st,
+                     const uint8_t* buf, size_t nbytes, int16_t* out, size_t out_cap)
+{
+    return fmcf_demodulate_blocks(D, fast, slow, kt, 0, st, buf, nbytes, out, out_cap);
 }
 
 // The planned tile form used by the production kernel (phase-class plans + tiling constants; one small

@@ -77,3 +77,28 @@ def test_f64_sample_positions(oracle):
         p0 = (p0 + N // 2) % D
         mb += M
     assert pos == [0, 21845, 43690, 65536, 87381]
+
+
+@pytest.mark.parametrize("D,fast,slow", CONFIGS)
+def test_closed_form_several_reference_calls_per_buffer(oracle, D, fast, slow):
+    """fmd_demod_set_block_len semantics in the closed-form model: one buffer of B blocks with the block-start
+    sample index (p0 + b * block_ns) / D taking the f64 path == the oracle fed block by block (audio and state)."""
+    lib = oracle.lib
+    lib.fmcf_demodulate_blocks.argtypes = [C.c_uint32] * 5 + [C.POINTER(oracle_lib.ChanState), C.POINTER(C.c_uint8), C.c_size_t,
+                                                              C.POINTER(C.c_int16), C.c_size_t]
+    lib.fmcf_demodulate_blocks.restype = C.c_long
+    rng = np.random.default_rng(D + 99)
+    d = oracle.new(oracle.config(D, fast, slow))
+    st = oracle_lib.ChanState()
+    for _ in range(4):
+        block = 8 * int(rng.integers((4 * D + 7) // 8 + 1, 6 * D + 120))
+        B = int(rng.integers(1, 7))
+        kt = int(rng.choice([1, 5, 64, 200]))
+        buf = rng.integers(0, 256, B * block, dtype=np.uint8)
+        exp = np.concatenate([oracle.demodulate(d, buf[b * block:(b + 1) * block]) for b in range(B)])
+        out = np.empty(buf.size // 2 + 16, dtype=np.int16)
+        n = lib.fmcf_demodulate_blocks(D, fast, slow, kt, block // 2, C.byref(st), buf.ctypes.data_as(C.POINTER(C.c_uint8)),
+                                       buf.size, out.ctypes.data_as(C.POINTER(C.c_int16)), out.size)
+        assert n == exp.size and np.array_equal(out[:n], exp), (D, block, B, kt)
+        s = oracle.state_of(d)
+        assert (st.prev_index, st.now_lpr, [st.demod_pre_re, st.demod_pre_im]) == (s["prev_index"], s["now_lpr"], s["demod_pre"])
