@@ -151,7 +151,7 @@ struct FmdClassPlan {
     uint32_t p0, i0r;   // call-start phases of the class
     uint32_t M, K, nt;  // decimated / audio samples and tiles of this call
     uint32_t eq0, er0;  // fr - i0r - 1 = eq0*sr + er0
-    uint32_t pad[5];
+    uint32_t pad;       // 32 bytes: FMD_MAX_CLASSES of them travel in the kernel arguments
 };
 
 struct FmdTiling {

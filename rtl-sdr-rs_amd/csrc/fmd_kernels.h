@@ -8,7 +8,9 @@
 #include "fmd_index.h"
 
 #define FMD_BLOCK_THREADS 256
-#define FMD_MAX_CLASSES 4
+#ifndef FMD_MAX_CLASSES
+#define FMD_MAX_CLASSES 16       /* phase classes one launch can carry (32-byte plans in the kernel arguments) */
+#endif
 #define FMD_TILE_MAX_LOADS 8      /* 16-byte chunks per thread the tile kernel can stage */
 
 // Device-side error bits (FmdLaunch::err), all "cannot happen" conditions.

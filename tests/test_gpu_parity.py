@@ -296,13 +296,13 @@ def test_generic_kernel_forced(fmd, oracle, monkeypatch):
     check_stream(fmd, oracle, *CFG_REF, blocks, n_channels=6)
 
 
-@pytest.mark.parametrize("nclasses", [2, 4, 7])
+@pytest.mark.parametrize("nclasses", [2, 4, 7, 16, 23])
 def test_phase_classes(fmd, oracle, nclasses):
-    """Channels with different call-start phases in one bank: <= 4 classes run the tile kernel with a
+    """Channels with different call-start phases in one bank: <= 16 classes run the tile kernel with a
     per-channel class table, more fall back to the generic kernel.  Phases are desynchronised the way a
     caller could: by checkpointing a Demod that has consumed a different amount of input."""
     D, fast, slow = CFG_REF
-    nch = 12
+    nch = 48
     rng = np.random.default_rng(nclasses)
     cfg = mkcfg(fmd, D, fast, slow)
     bank = fmd.DemodBank(cfg, nch)
