@@ -75,32 +75,16 @@ __device__ __forceinline__ uint32_t wave_ror1(uint32_t v)
     return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x13C /* wave_ror:1 */, 0xf, 0xf, false);
 }
 
-// hipcc selects the VOP2 accumulate-in-place forms (v_dot2c / v_dot4c) for the dot builtins and then has to
-// v_mov the addend into the destination first; the VOP3P forms take the addend as a third source.
-#ifndef FMD_VOP3_DOT
-#define FMD_VOP3_DOT 1
-#endif
-
+// Two things tried around these helpers and withdrawn (both caught by tests/test_gpu_fuzz.py, downsample 2):
+//  * the dot products as inline-asm VOP3P forms (no v_mov of the addend into a v_dot*c destination, -0.5..1.2 %):
+//    on gfx950 a non-dot VALU instruction must not read a dot result for 3 wait states; hipcc inserts the
+//    s_nops for its own builtins but cannot see through inline asm, so correctness hung on instruction order;
+//  * bound_ctrl on the DPP moves (saves the v_mov 0 of `old`): the DPP-combine pass may then fold the move
+//    into a consumer that runs under the narrower EXEC mask of the predicated stores, where a masked-off
+//    neighbour lane reads as 0.
 __device__ __forceinline__ int sdot2(uint32_t a, uint32_t b)
 {
-#if FMD_VOP3_DOT && defined(__HIP_DEVICE_COMPILE__)
-    int d;
-    asm("v_dot2_i32_i16 %0, %1, %2, 0" : "=v"(d) : "v"(a), "v"(b));
-    return d;
-#else
     return __builtin_amdgcn_sdot2(__builtin_bit_cast(fmd_s2, a), __builtin_bit_cast(fmd_s2, b), 0, false);
-#endif
-}
-
-__device__ __forceinline__ int sdot4_vop3(uint32_t a, uint32_t b, int c)
-{
-#if defined(__HIP_DEVICE_COMPILE__)
-    int d;
-    asm("v_dot4_i32_i8 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
-    return d;
-#else
-    return (int)(a + b) + c;                                  // host pass only parses this body
-#endif
 }
 
 // Demod::polar_discriminant_fast (:377-380) + fast_atan2 (:383-405), branch-free, for packed operands
@@ -266,7 +250,6 @@ __device__ __forceinline__ void tile_body(const FmdLaunch& L, const TileCtx& X, 
     const uint32_t wimA = odd ? FMD_W_IM_ODD : FMD_W_IM_EVEN, wimB = odd ? FMD_W_IM_EVEN : FMD_W_IM_ODD;
     const int im0 = 2 * (odd ? DH / 2 : (DH + 1) / 2);       // +2 per call-even dword; re gets +1 per dword
     const int last = cnt - 1;
-    const int cDH = DH;
 
     // ---- boxcar + discriminator ------------------------------------------------------------------
     // A wave-round is 128 windows, two per lane (i and i + 64: two independent dependency chains the
@@ -287,11 +270,6 @@ __device__ __forceinline__ void tile_body(const FmdLaunch& L, const TileCtx& X, 
 #pragma unroll
                 for (int u = 0; u < (DH > 0 ? DH : 1); ++u) {
                     const uint32_t wa = pa[u] ^ 0x80808080u, wb = pb[u] ^ 0x80808080u;   // u8 -> s8 (b - 128)
-                    if (FMD_VOP3_DOT && u == 0) {            // first link of each chain: d = dot + c, no v_mov of c
-                        re1 = sdot4_vop3(wa, wreA, cDH); im1 = sdot4_vop3(wa, wimA, im0);
-                        re2 = sdot4_vop3(wb, wreA, cDH); im2 = sdot4_vop3(wb, wimA, im0);
-                        continue;
-                    }
                     re1 = sdot4(wa, (u & 1) ? wreB : wreA, re1);
                     im1 = sdot4(wa, (u & 1) ? wimB : wimA, im1);
                     re2 = sdot4(wb, (u & 1) ? wreB : wreA, re2);
