@@ -234,6 +234,7 @@ __global__ void __launch_bounds__(kFirThreads) fmd_fir_mfma_kernel(const FirLaun
         }
     }
     __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_s_waitcnt(0x0F70);                             // vmcnt(0): the LDS-DMAs (and the A fragments) have landed
     __syncthreads();
 
     const uint8_t* lb = reinterpret_cast<const uint8_t*>(lds);

@@ -515,6 +515,9 @@ __global__ void __launch_bounds__(NT) fmd_demod_tile_kernel(const FmdLaunch L)
         if (tid == 0) L.out[(uint64_t)c * L.out_stride + X.T.k0] = (int16_t)reinterpret_cast<uint32_t*>(smem)[blockIdx.x & 63u];
         return;
     }
+    // The LDS-DMAs count on vmcnt.  hipcc already waits for them at the barrier (it knows the builtin writes LDS);
+    // the explicit s_waitcnt vmcnt(0) states the requirement instead of relying on that.
+    __builtin_amdgcn_s_waitcnt(0x0F70);
     __syncthreads();
     // (Measured and rejected: touching the lines of a tile 512..3584 dispatch slots ahead to pre-warm
     //  L2 / Infinity Cache made the launch 4..40 % SLOWER -- the stream is bandwidth-, not latency-bound.)
