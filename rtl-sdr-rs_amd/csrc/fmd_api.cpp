@@ -37,7 +37,7 @@ void set_err(const char* fmt, ...)
         hipError_t e_ = (expr);                                                              \
         if (e_ != hipSuccess) {                                                              \
             set_err("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
-            return FMD_ERR_HIP;                                                              \
+            return e_ == hipErrorOutOfMemory ? FMD_ERR_NOMEM : FMD_ERR_HIP;                  \
         }                                                                                    \
     } while (0)
 
@@ -422,7 +422,7 @@ int fmd_demod_new(const fmd_demod_config* config, const fmd_device_config* dev, 
     auto fail = [&](hipError_t e, const char* what) {
         set_err("%s: %s", what, hipGetErrorString(e));
         fmd_demod_free(d);
-        return FMD_ERR_HIP;
+        return e == hipErrorOutOfMemory ? FMD_ERR_NOMEM : FMD_ERR_HIP;
     };
     hipError_t e;
     if ((e = hipSetDevice(device)) != hipSuccess) return fail(e, "hipSetDevice");
