@@ -231,6 +231,7 @@ int enqueue(fmd_demod* d, const void* d_iq, size_t nbytes, void* d_out, size_t o
     L.r = d->r;
     L.ns = (uint32_t)(nbytes / 2);
     L.block_ns = d->block_ns;
+    L.xcd_swizzle = env_u32("FMD_XCD", 2);        // 2 (default): contiguous eighth of the channels per XCD; 0: plain
     L.n_channels = d->C;
     L.tiles = tiles;
     L.lp_cap = d->lp_cap;

@@ -74,6 +74,7 @@ struct FirLaunch {
     uint32_t col_bytes;        // 8 * decim: byte distance between consecutive columns
     int32_t mre[2], mim[2];    // additive constants (s8 domain) by window parity
     uint32_t dbg;              // ablation bits, honoured by -DFMD_EXPERIMENT builds only
+    uint32_t xcd_swizzle;      // 0 plain, 1 / 2: XCD-aware block -> (channel, tile) mapping
 };
 
 #ifdef FMD_EXPERIMENT
@@ -187,9 +188,16 @@ __global__ void __launch_bounds__(kFirThreads) fmd_fir_mfma_kernel(const FirLaun
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     const uint32_t tid = threadIdx.x;
     __builtin_amdgcn_s_setprio(3);                                  // get the loads out first (see fmd_tile_kernel.hip)
-    const uint32_t c = blockIdx.y + 65535u * blockIdx.z;
+    uint32_t c = blockIdx.y + 65535u * blockIdx.z, tix = blockIdx.x;
+    // XCD-aware block -> (channel, tile) mapping as in fmd_tile_kernel.hip: XCD k works through its own contiguous
+    // eighth of the channels tile after tile (about -1 % per call here).
+    if (L.xcd_swizzle && c < (L.n_channels & ~7u)) {
+        const uint32_t lin = blockIdx.x + gridDim.x * c, xcd = lin & 7u, idx = lin >> 3, q = idx / gridDim.x;
+        c = L.xcd_swizzle == 1u ? q * 8u + xcd : xcd * (L.n_channels >> 3) + q;
+        tix = idx - q * gridDim.x;
+    }
     if (c >= L.n_channels) return;
-    const uint32_t o0 = blockIdx.x * L.out_tile;
+    const uint32_t o0 = tix * L.out_tile;
     if (o0 >= L.n_out) return;
     const uint32_t no = L.n_out - o0 < L.out_tile ? L.n_out - o0 : L.out_tile;
     const uint32_t w0 = L.wd_first + o0 * L.half_M;                 // first virtual dword of the tile
@@ -262,7 +270,7 @@ __global__ void __launch_bounds__(kFirThreads) fmd_fir_mfma_kernel(const FirLaun
         }
     }
     // the channel's last tile also writes the next call's history (saves the separate launch)
-    if (blockIdx.x == gridDim.x - 1u && !FIR_ABLATE(3)) {
+    if (tix == gridDim.x - 1u && !FIR_ABLATE(3)) {
         typedef const FMD_AS_GLOBAL uint32_t* gw;
         for (uint32_t k = tid; k < L.Hw; k += kFirThreads) {
             const uint64_t w = L.stride_w + k;                      // virtual dword (history ++ call), < Hw + stride_w
@@ -379,6 +387,7 @@ int fir_enqueue(fmd_fir* f, const void* d_iq, size_t nbytes, void* d_out, size_t
     { const char* e = getenv("FMD_DBG"); L.dbg = e ? (uint32_t)atoi(e) : 0u; }
 #endif
     if (n_out && f->n_pass) {
+        { const char* ex = getenv("FMD_XCD"); L.xcd_swizzle = ex ? (uint32_t)atoi(ex) : 2u; }      // 0 = plain mapping (tuning)
         L.amat = f->d_amat; L.n_pass = f->n_pass; L.nku = f->nku; L.groups = f->groups; L.col_bytes = 8u * f->M;
         L.mre[0] = f->mre[0]; L.mre[1] = f->mre[1]; L.mim[0] = f->mim[0]; L.mim[1] = f->mim[1];
         L.out_tile = 64u * f->groups;

@@ -23,6 +23,7 @@ struct FmdLaunch {
     uint64_t total_bytes;     // n_channels * chan_stride
     FmdRates r;
     uint32_t ns;              // complex samples per channel this call
+    uint32_t xcd_swizzle;     // tile kernel: 0 plain, 1 / 2 XCD-aware block -> (channel, tile) mapping (FMD_XCD, default 2)
     uint32_t block_ns;        // > 0: the call is ns / block_ns consecutive reference calls of block_ns samples each
     uint32_t n_channels;
     uint32_t tiles;           // grid tiles per channel (>= every channel's own tile count)

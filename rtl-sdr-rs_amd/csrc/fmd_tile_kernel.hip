@@ -494,9 +494,19 @@ __global__ void __launch_bounds__(NT) fmd_demod_tile_kernel(const FmdLaunch L)
     // A freshly dispatched block's only job is to get its loads out: let it win issue arbitration against the
     // computing waves of the other resident blocks until the DMAs are queued (measured -1.8 % launch time).
     __builtin_amdgcn_s_setprio(3);
-    const uint32_t c = blockIdx.z * 65535u + blockIdx.y;
+    uint32_t c = blockIdx.z * 65535u + blockIdx.y, tix = blockIdx.x;
+    // XCD-aware block -> (channel, tile) mapping.  Workgroups go to the 8 XCDs (each with its own L2) round-robin
+    // in dispatch order, so with the plain mapping the 15 tiles of one channel's 256 KiB are spread over all XCDs.
+    // Here XCD k works through its own contiguous eighth of the channels, tile after tile: neighbouring tiles
+    // share their halo in one L2 and every XCD streams one contiguous region.  A/B on four boxes: 0 ... -3 %
+    // per call, never slower.  Channels beyond the last multiple of 8 keep the plain mapping.
+    if (L.xcd_swizzle && c < (L.n_channels & ~7u)) {
+        const uint32_t lin = blockIdx.x + L.tiles * c, xcd = lin & 7u, idx = lin >> 3, q = idx / L.tiles;
+        c = L.xcd_swizzle == 1u ? q * 8u + xcd : xcd * (L.n_channels >> 3) + q;
+        tix = idx - q * L.tiles;
+    }
     if (c >= L.n_channels) return;
-    const TileCtx X = tile_setup(L, c, blockIdx.x);
+    const TileCtx X = tile_setup(L, c, tix);
     if (!X.valid || !tile_fits(L, X, tid)) return;
     if (FMD_ABLATE(4)) {                                     // ablation: no loads at all (compute on LDS garbage)
     } else if (X.whole) {
