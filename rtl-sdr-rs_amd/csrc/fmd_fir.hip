@@ -191,7 +191,12 @@ __global__ void __launch_bounds__(kFirThreads) fmd_fir_mfma_kernel(const FirLaun
     uint32_t c = blockIdx.y + 65535u * blockIdx.z, tix = blockIdx.x;
     // XCD-aware block -> (channel, tile) mapping as in fmd_tile_kernel.hip: XCD k works through its own contiguous
     // eighth of the channels tile after tile (about -1 % per call here).
-    if (L.xcd_swizzle && c < (L.n_channels & ~7u)) {
+    uint32_t ntiles = gridDim.x;
+    if (L.xcd_swizzle == 3u) {                                      // grid (8, tiles, ceil(C / 8)): blockIdx.x is the XCD
+        c = blockIdx.x * gridDim.z + blockIdx.z;
+        tix = blockIdx.y;
+        ntiles = gridDim.y;
+    } else if (L.xcd_swizzle && c < (L.n_channels & ~7u)) {
         const uint32_t lin = blockIdx.x + gridDim.x * c, xcd = lin & 7u, idx = lin >> 3, q = idx / gridDim.x;
         c = L.xcd_swizzle == 1u ? q * 8u + xcd : xcd * (L.n_channels >> 3) + q;
         tix = idx - q * gridDim.x;
@@ -270,7 +275,7 @@ __global__ void __launch_bounds__(kFirThreads) fmd_fir_mfma_kernel(const FirLaun
         }
     }
     // the channel's last tile also writes the next call's history (saves the separate launch)
-    if (tix == gridDim.x - 1u && !FIR_ABLATE(3)) {
+    if (tix == ntiles - 1u && !FIR_ABLATE(3)) {
         typedef const FMD_AS_GLOBAL uint32_t* gw;
         for (uint32_t k = tid; k < L.Hw; k += kFirThreads) {
             const uint64_t w = L.stride_w + k;                      // virtual dword (history ++ call), < Hw + stride_w
@@ -396,7 +401,9 @@ int fir_enqueue(fmd_fir* f, const void* d_iq, size_t nbytes, void* d_out, size_t
         const size_t touched = (size_t)16 * f->groups * L.col_bytes + (size_t)64 * f->n_pass * f->nku;
         const size_t lds = staged > touched ? staged : touched;
         const uint32_t gy = f->C < 65535u ? f->C : 65535u, gz = (f->C + 65534u) / 65535u;
-        const dim3 g((uint32_t)((n_out + L.out_tile - 1) / L.out_tile), gy, gz);
+        dim3 g((uint32_t)((n_out + L.out_tile - 1) / L.out_tile), gy, gz);
+        const uint32_t per = (f->C + 7u) / 8u;                      // XCD-aware grid without index arithmetic
+        if (L.xcd_swizzle && f->C >= 8u && g.x <= 65535u && per <= 65535u) { g = dim3(8u, g.x, per); L.xcd_swizzle = 3u; }
         switch (f->nku) {
             case 1: launch_mfma<1>(L, g, lds, stream); break;
             case 2: launch_mfma<2>(L, g, lds, stream); break;

@@ -500,7 +500,10 @@ __global__ void __launch_bounds__(NT) fmd_demod_tile_kernel(const FmdLaunch L)
     // Here XCD k works through its own contiguous eighth of the channels, tile after tile: neighbouring tiles
     // share their halo in one L2 and every XCD streams one contiguous region.  A/B on four boxes: 0 ... -3 %
     // per call, never slower.  Channels beyond the last multiple of 8 keep the plain mapping.
-    if (L.xcd_swizzle && c < (L.n_channels & ~7u)) {
+    if (L.xcd_swizzle == 3u) {                               // grid (8, tiles, ceil(C / 8)): see fmd_launch_tile
+        c = blockIdx.x * gridDim.z + blockIdx.z;
+        tix = blockIdx.y;
+    } else if (L.xcd_swizzle && c < (L.n_channels & ~7u)) {
         const uint32_t lin = blockIdx.x + L.tiles * c, xcd = lin & 7u, idx = lin >> 3, q = idx / L.tiles;
         c = L.xcd_swizzle == 1u ? q * 8u + xcd : xcd * (L.n_channels >> 3) + q;
         tix = idx - q * L.tiles;
@@ -688,16 +691,24 @@ hipError_t fmd_launch_tile(const FmdLaunch& L, hipStream_t stream)
         }
         return hipGetLastError();
     }
-    const uint32_t gy = L.n_channels < 65535u ? L.n_channels : 65535u;
-    const uint32_t gz = (L.n_channels + 65534u) / 65535u;
-    const dim3 g(L.tiles, gy, gz);
+    uint32_t gy = L.n_channels < 65535u ? L.n_channels : 65535u;
+    uint32_t gz = (L.n_channels + 65534u) / 65535u;
+    dim3 g(L.tiles, gy, gz);
+    FmdLaunch K = L;
+    // XCD-aware mapping without index arithmetic: grid (8, tiles, ceil(C / 8)), x fastest in dispatch order, so
+    // blockIdx.x IS the XCD and channel = x * gridDim.z + z (blocks of channels >= C exit at once).
+    const uint32_t per = (L.n_channels + 7u) / 8u;
+    if (L.xcd_swizzle && L.n_channels >= 8u && L.tiles <= 65535u && per <= 65535u) {
+        g = dim3(8u, L.tiles, per);
+        K.xcd_swizzle = 3u;
+    }
     switch (dh) {
-        case 1: launch_one<1>(L, g, lds, stream); break;
-        case 2: launch_one<2>(L, g, lds, stream); break;
-        case 3: launch_one<3>(L, g, lds, stream); break;
-        case 4: launch_one<4>(L, g, lds, stream); break;
-        case 5: launch_one<5>(L, g, lds, stream); break;
-        default: launch_one<0>(L, g, lds, stream); break;
+        case 1: launch_one<1>(K, g, lds, stream); break;
+        case 2: launch_one<2>(K, g, lds, stream); break;
+        case 3: launch_one<3>(K, g, lds, stream); break;
+        case 4: launch_one<4>(K, g, lds, stream); break;
+        case 5: launch_one<5>(K, g, lds, stream); break;
+        default: launch_one<0>(K, g, lds, stream); break;
     }
     return hipGetLastError();
 }
