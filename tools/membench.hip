@@ -7,6 +7,9 @@
 #include <cstdlib>
 #include <vector>
 
+#ifndef NTAUX
+#define NTAUX 2      /* cache policy of the XCD-aware variant's loads: 2 = nt, as in the product */
+#endif
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1); } } while (0)
 
 // (a) grid-stride 16 B/lane register loads, xor-reduced so nothing is dead
@@ -48,6 +51,27 @@ __global__ void __launch_bounds__(256) k_tile_dma(const unsigned char* __restric
     for (int l = 0; l < LOADS; ++l)
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + 4096u * l),
                                          (__attribute__((address_space(3))) void*)(smem + 4096u * l + 1024u * wave), 16, 0, 0);
+    __syncthreads();
+    unsigned acc = 0;
+    const unsigned* w = reinterpret_cast<const unsigned*>(smem);
+#pragma unroll
+    for (int l = 0; l < LOADS * 4; ++l) acc ^= w[tid * 5 % (LOADS * 1024) + l * 256 % 7];
+    if (acc == 0x12345678u) sink[0] = acc;
+}
+
+// (c') the same with the XCD-aware block order of the product kernels: grid (8, tiles per eighth), blockIdx.x is the
+// XCD (workgroups go to XCDs round-robin in dispatch order) and XCD k streams its own contiguous eighth of the buffer
+template <int LOADS>
+__global__ void __launch_bounds__(256) k_tile_dma_xcd(const unsigned char* __restrict__ p, unsigned* sink)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const unsigned tid = threadIdx.x, wave = tid >> 6;
+    const size_t tile = (size_t)blockIdx.x * gridDim.y + blockIdx.y;
+    const unsigned char* src = p + tile * LOADS * 4096 + 16u * tid;
+#pragma unroll
+    for (int l = 0; l < LOADS; ++l)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + 4096u * l),
+                                         (__attribute__((address_space(3))) void*)(smem + 4096u * l + 1024u * wave), 16, 0, NTAUX);
     __syncthreads();
     unsigned acc = 0;
     const unsigned* w = reinterpret_cast<const unsigned*>(smem);
@@ -132,6 +156,7 @@ int main(int argc, char** argv)
     report("tile reg 5 x 16 B/lane (20 KiB tiles)", time_ms([&](int i) { hipLaunchKernelGGL(k_tile_reg<5>, dim3(bytes / 20480), dim3(256), 0, 0, (const uint4*)bufs[i % nbuf], sink); }, iters));
     report("tile reg 8 x 16 B/lane (32 KiB tiles)", time_ms([&](int i) { hipLaunchKernelGGL(k_tile_reg<8>, dim3(bytes / 32768), dim3(256), 0, 0, (const uint4*)bufs[i % nbuf], sink); }, iters));
     report("tile LDS-DMA 5 x 16 B/lane + barrier", time_ms([&](int i) { hipLaunchKernelGGL(k_tile_dma<5>, dim3(bytes / 20480), dim3(256), 20480, 0, bufs[i % nbuf], sink); }, iters));
+    report("tile LDS-DMA 5 x 16 B/lane + barrier, XCD-aware order, nt", time_ms([&](int i) { hipLaunchKernelGGL(k_tile_dma_xcd<5>, dim3(8, bytes / 20480 / 8), dim3(256), 20480, 0, bufs[i % nbuf], sink); }, iters));
     report("tile LDS-DMA 8 x 16 B/lane + barrier", time_ms([&](int i) { hipLaunchKernelGGL(k_tile_dma<8>, dim3(bytes / 32768), dim3(256), 32768, 0, bufs[i % nbuf], sink); }, iters));
     report("tile LDS-DMA 2 x 16 B/lane + barrier", time_ms([&](int i) { hipLaunchKernelGGL(k_tile_dma<2>, dim3(bytes / 8192), dim3(256), 8192, 0, bufs[i % nbuf], sink); }, iters));
     {
