@@ -302,7 +302,12 @@ __global__ void __launch_bounds__(kFirThreads) fmd_fir_mfma_kernel(const FirLaun
 template <int NKU>
 void launch_mfma(const FirLaunch& L, dim3 g, size_t lds, hipStream_t stream)
 {
-    if (L.col_bytes == 64u) hipLaunchKernelGGL((fmd_fir_mfma_kernel<NKU, true>), g, dim3(kFirThreads), lds, stream, L);
+    // The conflict-free LDS layout (SWZ) removes every bank conflict of the fragment reads (PMC: 10.5 M -> 0 cycles
+    // per launch) but the lane-permuted DMA that produces it costs more than the conflicts did: 0.1365 vs 0.1344 ms
+    // per config-4 call, loads alone 0.0996 vs 0.0973 ms.  Off unless FMD_FIR_SWZ=1.
+    const char* e = getenv("FMD_FIR_SWZ");
+    const bool swz = e && e[0] == '1';
+    if (L.col_bytes == 64u && swz) hipLaunchKernelGGL((fmd_fir_mfma_kernel<NKU, true>), g, dim3(kFirThreads), lds, stream, L);
     else hipLaunchKernelGGL((fmd_fir_mfma_kernel<NKU, false>), g, dim3(kFirThreads), lds, stream, L);
 }
 

@@ -62,7 +62,7 @@ def test_oracle_fir_equals_numpy_convolution(oracle, T, M):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("form", ["mfma", "valu"])
+@pytest.mark.parametrize("form", ["mfma", "mfma_swz", "valu"])
 @pytest.mark.parametrize("T,M", [(127, 8), (6, 6), (10, 10), (5, 2), (16, 16), (33, 4), (1, 2), (64, 6), (255, 32),
                                  (300, 8), (1024, 2), (129, 64), (77, 66), (31, 128)])
 def test_gpu_fir_matches_oracle(fmd, oracle, monkeypatch, form, T, M):
@@ -70,6 +70,8 @@ def test_gpu_fir_matches_oracle(fmd, oracle, monkeypatch, form, T, M):
     streaming over ragged calls; shapes cover one and several K passes, both window parities, decim > 64."""
     if form == "valu":
         monkeypatch.setenv("FMD_FIR_MFMA", "0")
+    if form == "mfma_swz":                                        # conflict-free LDS layout (decim 8 only; off by default)
+        monkeypatch.setenv("FMD_FIR_SWZ", "1")
     rng = np.random.default_rng(T * 7 + M)
     taps = np.ones(T, np.int16) if T == M else rng.integers(-2047, 2048, T).astype(np.int16)
     nch = 5
