@@ -387,7 +387,7 @@ int fmd_demod_new(const fmd_demod_config* config, const fmd_device_config* dev, 
     }
     d->force_generic = env_u32("FMD_FORCE_GENERIC", 0) != 0;
     d->block_threads = env_u32("FMD_NT", 256);
-    if (d->block_threads != 128 && d->block_threads != 512) d->block_threads = 256;
+    if (d->block_threads != 128 && d->block_threads != 64) d->block_threads = 256;
     // two waves per block step 2*127 windows per round: an odd downsample would flip a lane's rotation phase
     if (d->block_threads == 128 && (config->downsample & 1u)) d->block_threads = 256;
     // Default data movement: the LDS-tile kernel.  FMD_STREAM=1 selects the register-streaming kernel with the

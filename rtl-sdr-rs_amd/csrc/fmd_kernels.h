@@ -37,7 +37,7 @@ struct FmdLaunch {
     uint32_t* err;            // device error word
     uint32_t dbg;             // ablation bits, honoured only by -DFMD_EXPERIMENT builds (tuning; never shipped)
     uint32_t persist_blocks;  // > 0: persistent kernel with this many blocks; 0: one block per tile
-    uint32_t block_threads;   // one-block-per-tile kernel: 128, 256 (default) or 512 threads
+    uint32_t block_threads;   // one-block-per-tile kernel: 64, 128 or 256 (default) threads
     uint32_t rounds_per_wave; // streaming kernel: consecutive rounds (tiles of kt audio samples) one wave walks
     uint32_t group_rounds;    // streaming kernel: rounds whose audio samples are produced together (<= 64 / kt)
     // ---- tile kernel only (phase-class plans; see fmd_index.h) ----

@@ -242,7 +242,9 @@ __device__ __forceinline__ void tile_body(const FmdLaunch& L, const TileCtx& X, 
     // apart and a wave-round advances by an even number, so the parity of m0 -- hence the weights -- is
     // fixed per lane for the whole tile.
     constexpr int NW = NT / 64;
-    constexpr int RS = 127;                                  // new decimated samples per wave-round
+    // new decimated samples per wave-round: 128 windows minus the overlap.  A block's round stride NW * RS windows
+    // must keep a lane's rotation phase fixed (see above); one wave per block (NW == 1) therefore steps 124.
+    constexpr int RS = NW == 1 ? 124 : 127;
     const uint32_t hp = p0 >> 1;
     const int j0 = jfirst + (int)wave * RS + (int)lane;
     const bool odd = ((((DH & 1) ? ((uint32_t)j0 ^ hp) : hp)) & 1u) != 0u;
@@ -619,7 +621,7 @@ void launch_one(const FmdLaunch& L, dim3 g, size_t lds, hipStream_t stream)
 {
     switch (L.block_threads) {
         case 128: hipLaunchKernelGGL((fmd_demod_tile_kernel<DH, 128>), g, dim3(128), lds, stream, L); break;
-        case 512: hipLaunchKernelGGL((fmd_demod_tile_kernel<DH, 512>), g, dim3(512), lds, stream, L); break;
+        case 64: hipLaunchKernelGGL((fmd_demod_tile_kernel<DH, 64>), g, dim3(64), lds, stream, L); break;
         default:  hipLaunchKernelGGL((fmd_demod_tile_kernel<DH, 256>), g, dim3(256), lds, stream, L); break;
     }
 }

@@ -1,6 +1,6 @@
 """GPU parity of the non-default kernel variants (same results by construction, selected by environment at
 Demod creation): the register-streaming kernel (FMD_STREAM=1), the persistent tile kernel (FMD_PERSIST=1),
-128/512-thread tile blocks (FMD_NT)."""
+64/128-thread tile blocks (FMD_NT)."""
 import numpy as np
 import pytest
 
@@ -22,7 +22,7 @@ def blocks_for(fmd, nch, ncalls, seed, n=None):
 
 
 @pytest.mark.parametrize("env", [{"FMD_STREAM": "1"}, {"FMD_STREAM": "1", "FMD_RPW": "9"},
-                                 {"FMD_PERSIST": "1"}, {"FMD_NT": "128"}, {"FMD_NT": "512"}])
+                                 {"FMD_PERSIST": "1"}, {"FMD_NT": "128"}, {"FMD_NT": "64"}])
 @pytest.mark.parametrize("cfg", [CFG_24, CFG_REF, (4, 300000, 50000), (16, 62500, 31250)])
 def test_kernel_variants_bit_exact(fmd, oracle, monkeypatch, env, cfg):
     for k, v in env.items():
