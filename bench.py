@@ -196,6 +196,8 @@ def main():
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "kernel": KERNEL,
                          "algorithmic_bytes_per_launch": alg_bytes,
+                         # BASELINE's "% HBM-read roofline" (SURVEY 8d): 2 B per IQ sample only, writes not counted
+                         "hbm_read_frac": round(nch * BLOCK / (kern_ms_region * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                          "kernel_ms_events_region": round(kern_ms_region, 4),
                          "kernel_ms_events_per_launch_median": round(kern_ms_pair, 4)},
         }
