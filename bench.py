@@ -4,13 +4,25 @@
 One "step" = one call of fmd_demod_demodulate_device over one batch of synthetic IQ already
 resident in HBM: BASELINE.json configs[2], 4096 FM channels x 262144 B (DEFAULT_BUF_LENGTH,
 src/lib.rs:25) at the 2.4 Msps configuration (downsample 10, 240 kHz -> 32 kHz), per GPU.
-Channels are independent, so N GPUs = N x 4096 channels with no data-path collective (weak scaling).
-Prints ONE JSON line on rank 0.
+Channels are independent (one Demod per stream, examples/simple_fm.rs:137), so N GPUs = N x 4096
+channels with no data-path collective (weak scaling).  Prints ONE JSON line on rank 0.
+
+Launching:  `python bench.py --gpus N` starts N rank processes ITSELF (fresh children, created before this
+process touches the GPU; the parent only relays rank 0's line);  under `python -m torch.distributed.run
+--nproc-per-node N bench.py --gpus N` (RANK / WORLD_SIZE set) each process is one rank.  Both ways: one rank
+per GPU, RCCL ("nccl") only for the barrier / max-over-ranks timing.
+
+Timing: exactly K steps per timed region, each region bracketed by barrier + synchronize, MAX over ranks;
+the region is repeated until >= 50 ms have been timed and the MEDIAN region is reported (min / max beside it).
 """
 import argparse
 import ctypes as C
+import hashlib
 import json
+import math
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -22,6 +34,19 @@ BLOCK = 16 * 16384
 D, FAST, SLOW = 10, 240000, 32000
 HBM_PEAK_GBS = 8000.0            # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 KERNEL = "fmd_demod_tile_kernel<5, 256>"   # the dominant kernel of this workload (rocprofv3 --kernel-trace name)
+MIN_TIMED_S = 0.050              # repeat the K-step region until this much has been timed
+PMC_SUMMARY = os.path.join("profiles", "r02_pmc_summary.json")
+
+
+def kernel_source_hash():
+    """sha256 over the kernel sources: ties a committed PMC summary to the code it was measured on."""
+    h = hashlib.sha256()
+    csrc = os.path.join(ROOT, "rtl-sdr-rs_amd", "csrc")
+    for f in sorted(os.listdir(csrc)):
+        if f.endswith((".hip", ".h", ".cpp")):
+            h.update(f.encode())
+            h.update(open(os.path.join(csrc, f), "rb").read())
+    return h.hexdigest()[:16]
 
 
 def cpu_baseline(fmd, torch, cfg, iq_dev, target_s=12.0):
@@ -65,7 +90,83 @@ def cpu_baseline(fmd, torch, cfg, iq_dev, target_s=12.0):
     return {"value": round(samples / total / 1e6, 2), "unit": "Msamples/s", "cores": cores, "kind": "port",
             "single_thread_value": single,
             "sample": "%d passes x %d channels x %d calls x %d B of the same synthetic workload, %d threads, "
-                      "%.1f s of oracle time" % (passes, chans, calls, BLOCK, cores, total)}
+                      "%.1f s of oracle time (oracle/fm_oracle.c, gcc -O3 -fwrapv)" % (passes, chans, calls, BLOCK, cores, total)}
+
+
+def extra_config4(fmd, torch, dev, stream, fused):
+    """BASELINE configs[3] beside the headline (outside its timed region): 127-tap FIR, decimate 8, 256 channels x
+    2 MiB per call.  fused=False: the stand-alone operator fmd_fir_* (complex i32 out, 3 B per IQ sample);
+    fused=True: FIR -> discriminator -> resampler in one kernel (fmd_firdemod_*, s16 audio out)."""
+    import numpy as np
+    nch, n, T, M = 256, 2 << 20, 127, 8
+    rng = np.random.default_rng(1)
+    bufs = []
+    for b in range(3):
+        t = torch.empty((nch, n), dtype=torch.uint8, device=dev)
+        fmd.synth.fill_device(t.data_ptr(), nch, n, sample_offset=b * (n // 2), device_id=dev.index, stream=stream)
+        bufs.append(t)
+    if fused:
+        taps = rng.integers(-60, 61, T).astype(np.int16)          # |y| <= 128 * sum|h| must fit the packed i16 form
+        fast, slow = 2_500_000, 48_000                               # 20 Msps / 8 -> 2.5 Msps -> 48 kHz audio
+        bank = fmd.FirDemodBank(taps, M, fast, slow, nch, device_id=dev.index)
+        cap = bank.out_cap(n)
+        out = torch.zeros((nch, cap), dtype=torch.int16, device=dev)
+        call = lambda i: bank.demodulate_device(bufs[i % 3].data_ptr(), n, out.data_ptr(), cap, stream)
+        out_bytes = lambda k: 2 * k
+    else:
+        taps = rng.integers(-2047, 2048, T).astype(np.int16)
+        bank = fmd.FirBank(taps, M, nch, device_id=dev.index)
+        cap = bank.out_cap(n)
+        out = torch.zeros((nch, cap, 2), dtype=torch.int32, device=dev)
+        call = lambda i: bank.filter_device(bufs[i % 3].data_ptr(), n, out.data_ptr(), cap, stream)
+        out_bytes = lambda k: 8 * k
+    for i in range(150):                                              # untimed: clocks settle
+        call(i)
+    torch.cuda.synchronize()
+    regs = []
+    nout = 0
+    for r in range(5):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for i in range(100):
+            nout = call(i)
+        e1.record()
+        torch.cuda.synchronize()
+        regs.append(e0.elapsed_time(e1) / 100)
+    regs.sort()
+    ms = regs[len(regs) // 2]
+    alg = nch * n + nch * out_bytes(int(nout))
+    res = {"workload": "BASELINE configs[3]: %d-tap FIR, decimate %d, %d channels x %d B/call (20 Msps x 52.4 ms)%s"
+                       % (T, M, nch, n, ", fused with the discriminator and the %d -> %d Hz resampler" % (fast, slow) if fused else ""),
+           "kernel": "fmd_firdemod_kernel" if fused else "fmd_fir_mfma_kernel", "ms_per_call": round(ms, 4),
+           "ms_min_max": [round(regs[0], 4), round(regs[-1], 4)],
+           "iq_msamples_per_s": round(nch * (n // 2) / ms / 1e3, 1), "outputs_per_channel": int(nout),
+           "algorithmic_bytes_per_launch": alg, "GBps": round(alg / ms / 1e6, 1), "frac": round(alg / ms / 1e6 / HBM_PEAK_GBS, 4)}
+    del bank, out, bufs
+    return res
+
+
+def spawn_ranks(args):
+    """`python bench.py --gpus N` without a launcher: start N fresh rank processes (this process has not touched
+    the GPU and never will), relay rank 0's JSON line, fail if any rank fails."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE=str(args.gpus),
+               LOCAL_WORLD_SIZE=str(args.gpus), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, os.path.abspath(__file__)] + sys.argv[1:]
+    procs = []
+    for r in range(args.gpus):
+        e = dict(env, RANK=str(r), LOCAL_RANK=str(r))
+        procs.append(subprocess.Popen(cmd, env=e, stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out0, _ = procs[0].communicate()
+    rcs = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    sys.stdout.write(out0.decode())
+    sys.stdout.flush()
+    if any(rcs):
+        sys.stderr.write("bench.py: rank exit codes %r\n" % (rcs,))
+        return 1
+    return 0
 
 
 def main():
@@ -77,23 +178,37 @@ def main():
     ap.add_argument("--nbuf", type=int, default=3, help="distinct input batches rotated through (defeats the 256 MiB L3)")
     ap.add_argument("--kt", type=int, default=0, help="tiling override (audio samples per tile)")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-extra", action="store_true", help="skip the config-4 lines (extra.*)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
-                    help="torch.distributed backend for the barrier / max-over-ranks timing (nccl = RCCL)")
+                    help="torch.distributed backend for the barrier / max-over-ranks timing (nccl = RCCL); with gloo "
+                         "ranks may share a GPU (launch-path check on a single-GPU box)")
     ap.add_argument("--settle", type=int, default=150,
                     help="untimed steps before the W warm-up steps: the first ~10 ms after an idle period run at "
                          "ramping clocks (measured 0.21-0.23 ms/step vs 0.193 settled); reported in config")
     args = ap.parse_args()
+    if args.gpus < 1 or args.steps < 1:
+        ap.error("--gpus and --steps must be >= 1")
+
+    world_env = os.environ.get("WORLD_SIZE")
+    if world_env is None and args.gpus > 1:
+        sys.exit(spawn_ranks(args))                              # before torch / HIP are even imported
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(world_env or "1")
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d: launch with --nproc-per-node equal to --gpus" % (args.gpus, world))
 
     import torch
     import rtl_sdr_rs_amd as fmd
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+    ndev = torch.cuda.device_count()
+    if ndev < 1 or fmd.device_count() < 1:
+        raise RuntimeError("bench.py: no gfx950 device; the product has no CPU path")
+    if world > ndev and args.backend == "nccl":
+        raise SystemExit("bench.py: --gpus %d but only %d device(s) visible (one rank per GPU; --backend gloo lets ranks "
+                         "share a GPU for a launch-path check)" % (world, ndev))
     dist = None
-    # one rank per GPU; `--backend gloo` (ranks may then share a GPU) exists to exercise this launch path on a
-    # single-GPU box -- the driver's multi-GPU runs use the default, RCCL ("nccl")
-    dev_index = local_rank % max(1, torch.cuda.device_count())
+    dev_index = local_rank % ndev
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -102,16 +217,13 @@ def main():
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", dev_index))
         else:
             dist.init_process_group(args.backend, rank=rank, world_size=world)
-    if fmd.device_count() < 1:
-        raise RuntimeError("bench.py: no gfx950 device; the product has no CPU path")
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
-    local_rank = dev_index
 
     cfg = fmd.DemodConfig(FAST, FAST, SLOW, D, max(1, (1 << 15) // (128 * D)))
     nch = args.channels
     lo, hi = fmd.shard.channel_range(nch * world, world, rank)          # this rank's global channel ids
-    bank = fmd.DemodBank(cfg, nch, device_id=local_rank)
+    bank = fmd.DemodBank(cfg, nch, device_id=dev_index)
     if args.kt:
         bank.set_tiling(args.kt)
     cap = bank.out_cap(BLOCK)
@@ -119,7 +231,7 @@ def main():
     bufs = []
     for b in range(args.nbuf):
         t = torch.empty((nch, BLOCK), dtype=torch.uint8, device=dev)
-        fmd.synth.fill_device(t.data_ptr(), nch, BLOCK, sample_offset=b * (BLOCK // 2), device_id=local_rank,
+        fmd.synth.fill_device(t.data_ptr(), nch, BLOCK, sample_offset=b * (BLOCK // 2), device_id=dev_index,
                               stream=stream, seed=fmd.synth.DEFAULTS["seed"] + lo)
         bufs.append(t)
     out = torch.zeros((nch, cap), dtype=torch.int16, device=dev)
@@ -133,33 +245,52 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    def max_over_ranks(x):
+        if dist is None:
+            return x
+        tt = torch.tensor([x], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        return float(tt.item())
+
     for i in range(args.settle):
         step(i)
     for i in range(args.warmup):
         step(i)
-    fence()
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    t0 = time.perf_counter()
-    ev0.record()
-    for i in range(args.steps):
-        step(args.warmup + i)
-    ev1.record()
-    fence()
-    t1 = time.perf_counter()
-    elapsed = t1 - t0
-    if dist is not None:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
-    kern_ms_region = ev0.elapsed_time(ev1) / args.steps            # HIP events on the launch stream
+    n_done = args.warmup
 
-    # per-launch event pairs (outside the timed region): isolates the kernel from inter-launch gaps
+    def timed_region():
+        """EXACTLY --steps steps, barrier + synchronize on both sides; returns (wall s [max over ranks], own wall s,
+        HIP-event ms per step on the launch stream)."""
+        nonlocal n_done
+        fence()
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t0 = time.perf_counter()
+        ev0.record()
+        for i in range(args.steps):
+            step(n_done + i)
+        ev1.record()
+        fence()
+        own = time.perf_counter() - t0
+        n_done += args.steps
+        return max_over_ranks(own), own, ev0.elapsed_time(ev1) / args.steps
+
+    regions = [timed_region()]
+    reps = min(400, max(1, int(math.ceil(MIN_TIMED_S / regions[0][0]))))    # same on every rank (all-reduced time)
+    for _ in range(reps - 1):
+        regions.append(timed_region())
+    walls = sorted(r[0] for r in regions)
+    elapsed = walls[len(walls) // 2]                                        # median region
+    own_med = sorted(r[1] for r in regions)[len(regions) // 2]
+    kern_ms_region = sorted(r[2] for r in regions)[len(regions) // 2]
+
+    # per-launch event pairs (outside the timed regions): isolates the kernel from inter-launch gaps
     pairs = []
-    for i in range(min(args.steps, 20)):
+    for i in range(40):
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         a.record(); step(i); b.record()
         pairs.append((a, b))
     torch.cuda.synchronize()
+    bank.check()                                                            # device-side sizing assertions (d_err)
     per_launch = sorted(a.elapsed_time(b) for a, b in pairs)
     kern_ms_pair = per_launch[len(per_launch) // 2]
 
@@ -168,15 +299,28 @@ def main():
     alg_bytes = nch * BLOCK + 2 * int(lens.sum())                 # u8 in once + s16 out (2.0267 B/sample)
     achieved = alg_bytes / (kern_ms_region * 1e-3) / 1e9
     value = world * samples_per_step * args.steps / elapsed / 1e6
+    per_gpu = [samples_per_step * args.steps / own_med / 1e6]
+    if dist is not None:
+        mine = torch.tensor([per_gpu[0]], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
+        every = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(every, mine)
+        per_gpu = [float(t.item()) for t in every]
 
-    # HBM bytes per launch from the committed PMC passes of this same command (scripts/gpu_pmc.sh ->
-    # profiles/r01_pmc_summary.json; FETCH_SIZE x2 on gfx950 as MI355X_MICROARCH.md prescribes, + WRITE_SIZE).
-    traffic = None
+    # HBM bytes per launch: NOT measured by this run -- taken from the committed PMC passes of this same command
+    # (scripts/gpu_pmc.sh -> profiles/r02_pmc_summary.json; FETCH_SIZE x2 on gfx950 as MI355X_MICROARCH.md
+    # prescribes, + WRITE_SIZE), and only when that summary was taken on these very kernel sources.
+    traffic, traffic_src = None, None
     try:
-        with open(os.path.join(ROOT, "profiles", "r01_pmc_summary.json")) as f:
+        with open(os.path.join(ROOT, PMC_SUMMARY)) as f:
             pmc = json.load(f)
-        if nch == CHANNELS and abs(pmc["hbm_traffic"]["algorithmic_bytes_per_launch"] - alg_bytes) < 1e-3 * alg_bytes:
+        same_code = pmc.get("kernel_source_sha16") == kernel_source_hash()
+        same_work = abs(pmc["hbm_traffic"]["algorithmic_bytes_per_launch"] - alg_bytes) < 1e-3 * alg_bytes
+        if nch == CHANNELS and same_code and same_work:
             traffic = int(pmc["hbm_traffic"]["bytes_per_launch"])
+            traffic_src = "%s (committed rocprofv3 --pmc passes of this command on these kernel sources, sha16 %s; not re-measured by this run)" % (
+                PMC_SUMMARY, pmc["kernel_source_sha16"])
+        elif not same_code:
+            traffic_src = "null: %s was taken on other kernel sources" % PMC_SUMMARY
     except (OSError, KeyError, ValueError):
         pass
 
@@ -193,14 +337,30 @@ def main():
                        "rate_resample": SLOW, "audio_per_call": int(lens[0]), "tiling": bank.tiling(),
                        "settle_steps_untimed": args.settle,
                        "parallelism": "channels sharded x%d, no collective" % world},
+            "timing": {"regions": len(regions), "steps_per_region": args.steps, "statistic": "median region, max over ranks",
+                       "ms_per_step_min": round(walls[0] / args.steps * 1e3, 4),
+                       "ms_per_step_max": round(walls[-1] / args.steps * 1e3, 4),
+                       "timed_ms_total": round(sum(walls) * 1e3, 2)},
+            "per_gpu_msamples_per_s": [round(v, 1) for v in per_gpu],
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "kernel": KERNEL,
-                         "algorithmic_bytes_per_launch": alg_bytes,
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
+                         "kernel": KERNEL, "algorithmic_bytes_per_launch": alg_bytes,
                          # BASELINE's "% HBM-read roofline" (SURVEY 8d): 2 B per IQ sample only, writes not counted
                          "hbm_read_frac": round(nch * BLOCK / (kern_ms_region * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                          "kernel_ms_events_region": round(kern_ms_region, 4),
-                         "kernel_ms_events_per_launch_median": round(kern_ms_pair, 4)},
+                         "kernel_ms_events_per_launch_median": round(kern_ms_pair, 4),
+                         "kernel_ms_events_per_launch_min_max": [round(per_launch[0], 4), round(per_launch[-1], 4)]},
         }
+        if world == 1 and not args.no_extra:
+            del bufs[1:]
+            res["extra"] = {}
+            for name, fused in (("config4_fir", False), ("config4_fir_demod_fused", True)):
+                try:
+                    if fused and not hasattr(fmd, "FirDemodBank"):
+                        continue
+                    res["extra"][name] = extra_config4(fmd, torch, dev, stream, fused)
+                except Exception as e:          # side lines never break the headline
+                    res["extra"][name] = {"error": repr(e)}
         if world == 1 and not args.no_cpu:
             try:
                 res["cpu_baseline"] = cpu_baseline(fmd, torch, cfg, bufs[0])

@@ -7,7 +7,10 @@
  * reference interface it replaces.  Plain pointers and sizes only; no C++/torch types.
  *
  * Threading: a handle is like the reference's `&mut Demod` -- one caller at a time.
- * Use one handle per host thread / per GPU.  All functions return FMD_OK (0) or a negative
+ * Use one handle per host thread / per GPU.  Consecutive launches of one handle may go to different streams:
+ * the library orders them (the new stream waits for the handle's previous launch); a stream handed to a
+ * *_device entry point must stay alive until the handle's next call or fmd_demod_check.  Every entry point
+ * leaves the caller's current HIP device as it found it.  All functions return FMD_OK (0) or a negative
  * fmd_status; nothing panics or aborts where the reference would.
  *
  * There is NO CPU fallback in this library: without a usable gfx950 device fmd_demod_new
@@ -24,7 +27,7 @@ extern "C" {
 #endif
 
 #define FMD_VERSION_MAJOR 0
-#define FMD_VERSION_MINOR 1
+#define FMD_VERSION_MINOR 2
 
 /* DEFAULT_BUF_LENGTH, src/lib.rs:25 -- the buffer size RtlSdr::read_sync callers use. */
 #define FMD_DEFAULT_BUF_LENGTH (16 * 16384)
@@ -131,6 +134,21 @@ int fmd_demod_demodulate_device(fmd_demod *d, const void *d_iq, size_t nbytes,
  * % 8 == 0 and >= 4 * downsample bytes (every block yields >= 2 decimated samples, :356);
  * 0 (the default) switches it off: one call = one reference call. */
 int fmd_demod_set_block_len(fmd_demod *d, size_t block_bytes);
+
+/* Completion + verification point for the DEVICE entry point: waits for everything this handle has enqueued,
+ * returns FMD_ERR_HIP if a device-side sizing assertion fired (fmd_last_error() has the bits), and settles the
+ * one f64 sample of every reference call (Demod::polar_discriminant, simple_fm.rs:359,370-374 -- `atan2` from
+ * the system libm in the reference): the kernel decides the axis / diagonal directions with integers and reports
+ * every other sample whose value lies within 2^-20 of an integer; those few are re-evaluated here with the HOST
+ * libm (the function the reference calls) and, if the truncated value differs, the audio sample (in the device
+ * output buffer the launch wrote, which must still be allocated) or the carried partial sum is patched.
+ * Outside that band the two results are provably equal.  The HOST entry points and fmd_demod_get_state do this
+ * themselves before returning; after fmd_demod_demodulate_device call it before reading the output (and, for
+ * the strict guarantee, before the next launch on the handle). */
+int fmd_demod_check(fmd_demod *d);
+
+/* Diagnostics of the above: f64 samples that fell into the guard band / whose value had to be patched. */
+int fmd_demod_f64_stats(const fmd_demod *d, uint64_t *guarded, uint64_t *patched);
 
 /* Per-channel sample counts of the most recent demodulate_* call (host bookkeeping). */
 int fmd_demod_last_out_len(const fmd_demod *d, size_t *out_len /* [n_channels] */);

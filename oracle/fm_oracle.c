@@ -438,3 +438,42 @@ done:
     free(buf); free(sig); free(v);
     return n;
 }
+
+/* ---- threaded FIR over a bank (test helper for BASELINE configs[3] at its real size) ----------- */
+typedef struct {
+    fmo_fir **firs; const uint8_t *iq; size_t c0, c1, len; fmo_cplx *out; size_t out_cap; uint32_t *out_len; int err;
+} fir_job;
+
+static void *fir_worker(void *arg)
+{
+    fir_job *j = (fir_job *)arg;
+    for (size_t c = j->c0; c < j->c1; c++) {
+        long n = fmo_fir_filter(j->firs[c], j->iq + c * j->len, j->len, j->out + c * j->out_cap, j->out_cap);
+        if (n < 0) { if (!j->err) j->err = (int)n; continue; }
+        j->out_len[c] = (uint32_t)n;
+    }
+    return NULL;
+}
+
+int fmo_fir_filter_batch(fmo_fir **firs, const uint8_t *iq, size_t n_channels, size_t len, fmo_cplx *out,
+                         size_t out_cap, uint32_t *out_len, int n_threads)
+{
+    if (n_threads < 1) n_threads = 1;
+    if ((size_t)n_threads > n_channels) n_threads = (int)(n_channels ? n_channels : 1);
+    pthread_t *th = (pthread_t *)calloc((size_t)n_threads, sizeof(pthread_t));
+    fir_job *jobs = (fir_job *)calloc((size_t)n_threads, sizeof(fir_job));
+    for (int t = 0; t < n_threads; t++) {
+        fir_job b = {firs, iq, n_channels * (size_t)t / (size_t)n_threads, n_channels * (size_t)(t + 1) / (size_t)n_threads,
+                     len, out, out_cap, out_len, 0};
+        jobs[t] = b;
+        if (n_threads == 1) fir_worker(&jobs[t]);
+        else pthread_create(&th[t], NULL, fir_worker, &jobs[t]);
+    }
+    int err = 0;
+    for (int t = 0; t < n_threads; t++) {
+        if (n_threads > 1) pthread_join(th[t], NULL);
+        if (jobs[t].err && !err) err = jobs[t].err;
+    }
+    free(th); free(jobs);
+    return err;
+}

@@ -131,6 +131,11 @@ void fmo_fir_free(fmo_fir *f);
 /* Returns the number of complex outputs written (capacity out_cap), -1 len % 8, -3 capacity. */
 long fmo_fir_filter(fmo_fir *f, const uint8_t *buf, size_t len, fmo_cplx *out, size_t out_cap);
 
+/* firs[c] fed iq[c] (channel-major iq[n_channels][len], out[n_channels][out_cap]) over n_threads pthreads: the
+ * config-4 check at its real size (256 channels x 2 MiB).  Returns 0 or the first negative fmo_fir_filter code. */
+int fmo_fir_filter_batch(fmo_fir **firs, const uint8_t *iq, size_t n_channels, size_t len, fmo_cplx *out,
+                         size_t out_cap, uint32_t *out_len, int n_threads);
+
 /* Test helper: demods[c].demodulate(iq[c]) for c in [0, n_channels), channel-major buffers
  * iq[n_channels][len], out[n_channels][out_cap], out_len[n_channels], over n_threads pthreads.
  * Returns 0 or the first negative fmo_demodulate code. */

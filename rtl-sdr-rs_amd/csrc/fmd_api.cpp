@@ -8,6 +8,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <cmath>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -17,6 +18,7 @@
 #include <utility>
 #include <vector>
 
+#include "fmd_host.h"
 #include "fmd_index.h"
 #include "fmd_kernels.h"
 
@@ -31,6 +33,14 @@ void set_err(const char* fmt, ...)
     vsnprintf(g_err, sizeof(g_err), fmt, ap);
     va_end(ap);
 }
+
+// Work on the handle's device; the caller's current device is restored on every exit path (fmd_host.h).
+#define ON_DEVICE(dev)                                                                       \
+    FmdDeviceGuard dev_guard_(dev);                                                          \
+    if (dev_guard_.error() != hipSuccess) {                                                  \
+        set_err("hipSetDevice(%d) failed: %s", (dev), hipGetErrorString(dev_guard_.error()));  \
+        return FMD_ERR_HIP;                                                                  \
+    }
 
 #define HIP_TRY(expr)                                                                        \
     do {                                                                                     \
@@ -66,15 +76,16 @@ struct fmd_demod {
     uint32_t lp_cap = 0, raw_cap = 0;
     uint32_t block_ns = 0;                // fmd_demod_set_block_len: samples per reference call inside one launch
     bool force_generic = false;
-    bool stream_mode = false;             // register-streaming kernel: tiling = its round size
-    uint32_t rounds_per_wave = 7;         // FMD_RPW
     int n_cus = 0;                        // compute units of the device
     uint32_t block_threads = 256;         // FMD_NT: workgroup size of the one-block-per-tile kernel
-    int persist_mode = 1;                 // FMD_PERSIST: 1 = persistent kernel when eligible, 0 = one block per tile
-    uint32_t persist_blocks = 0;          // grid of the persistent kernel for the current tiling (0 = not computed)
     FmdChanState* d_state[2] = {nullptr, nullptr};
     int cur = 0;
-    uint32_t* d_err = nullptr;
+    FmdExcBuf* d_exc = nullptr;           // device error word + guarded f64 samples (fmd_kernels.h)
+    double f64_guard = 0x1p-20;           // FMD_F64_GUARD_LOG2 (tests lower the bar to exercise the patch path)
+    int32_t f64_skew = 0;                 // FMD_F64_SKEW, honoured by -DFMD_EXPERIMENT builds only
+    uint32_t seq = 0;                     // launches enqueued
+    uint64_t f64_guarded = 0, f64_patched = 0;
+    FmdStreamOrder order;                 // cross-stream ordering of consecutive launches (fmd_host.h)
     std::vector<PhaseClass> classes;      // host mirror of the phases
     std::vector<uint32_t> chan_class;     // [C] index into classes
     uint8_t* d_chan_class = nullptr;      // device copy, valid while 1 < classes <= FMD_MAX_CLASSES
@@ -117,7 +128,6 @@ int choose_tiling(fmd_demod* d, uint32_t kt_req)
         }
     }
     r.kt = kt;
-    d->persist_blocks = 0;
     d->lp_cap = fmd_tile_lp_cap(r);
     d->raw_cap = fmd_tile_raw_cap(r);
     const size_t lds = (size_t)d->raw_cap + 6u * (size_t)d->lp_cap + 32;
@@ -125,12 +135,6 @@ int choose_tiling(fmd_demod* d, uint32_t kt_req)
         set_err("tile needs %zu bytes of LDS (kt=%u): rate_out/rate_resample x downsample too large", lds, kt);
         return FMD_ERR_UNSUPPORTED;
     }
-    return FMD_OK;
-}
-
-int use_device(const fmd_demod* d)
-{
-    HIP_TRY(hipSetDevice(d->device));
     return FMD_OK;
 }
 
@@ -241,10 +245,18 @@ int enqueue(fmd_demod* d, const void* d_iq, size_t nbytes, void* d_out, size_t o
     L.out = static_cast<int16_t*>(d_out);
     L.out_stride = out_cap;
     L.out_len = static_cast<uint32_t*>(d_out_len);
-    L.err = d->d_err;
+    L.err = &d->d_exc->err;
+    L.exc = d->d_exc;
+    L.f64_guard = d->f64_guard;
+    L.seq = d->seq + 1;
 #ifdef FMD_EXPERIMENT
     L.dbg = env_u32("FMD_DBG", 0);
+    L.f64_skew = d->f64_skew;
 #endif
+    {   // consecutive launches on different streams: the new stream waits for the previous launch (state ping-pong)
+        const hipError_t eo = d->order.before(stream);
+        if (eo != hipSuccess) { set_err("stream ordering failed: %s", hipGetErrorString(eo)); return FMD_ERR_HIP; }
+    }
     if (tile_kernel_ok(d)) {
         const FmdRates& r = d->r;
         L.tl = fmd_make_tiling(r);
@@ -265,31 +277,73 @@ int enqueue(fmd_demod* d, const void* d_iq, size_t nbytes, void* d_out, size_t o
             L.chan_class = d->d_chan_class;
         }
         L.block_threads = d->block_threads;
-        bool even_phases = true;                              // whole-dword windows in every class
-        for (const PhaseClass& pc : d->classes) even_phases &= (pc.p0 % 2 == 0);
-        if (d->stream_mode && even_phases && !d->block_ns && fmd_stream_kernel_supports(r)) {
-            L.rounds_per_wave = d->rounds_per_wave;
-            L.group_rounds = fmd_stream_group_rounds(r);
-            HIP_TRY(fmd_launch_stream(L, stream));
-            d->cur ^= 1;
-            advance_classes(d, nbytes, plans);
-            return FMD_OK;
-        }
-        if (d->persist_mode && fmd_persist_supports(d->raw_cap)) {
-            if (!d->persist_blocks) {
-                int bpc = (int)env_u32("FMD_BPC", 0);
-                if (bpc <= 0) bpc = fmd_persist_blocks_per_cu(L);
-                if (bpc > 0) d->persist_blocks = (uint32_t)bpc * (uint32_t)d->n_cus;
-            }
-            L.persist_blocks = d->persist_blocks;
-        }
         HIP_TRY(fmd_launch_tile(L, stream));
     } else {
         HIP_TRY(fmd_launch_generic(L, stream));
     }
+    d->order.after(stream);
+    d->seq += 1;
     d->cur ^= 1;
     advance_classes(d, nbytes, plans);
     return FMD_OK;
+}
+
+// Demod::polar_discriminant (simple_fm.rs:370-374) with the HOST libm -- the function the reference itself calls.
+int host_polar_f64(int cr, int ci)
+{
+    const double angle = atan2((double)ci, (double)cr);
+    return (int)(angle / 3.14159265358979323846264338327950288 * 16384.0);
+}
+
+// After the handle's work has completed: surface the device error word and re-evaluate the guarded f64 samples
+// (FmdF64Exc) with the host libm.  A sample whose host value differs from the kernel's is patched -- in `host_out`
+// ([C][host_cap], the caller's copy of the most recent launch's output) when given, else in the device buffer the
+// launch wrote -- together with the carried partial sum when it lies in the trailing group.
+int resolve_device_reports(fmd_demod* d, int16_t* host_out, size_t host_cap)
+{
+    uint32_t head[4] = {0, 0, 0, 0};                        // err, count, guarded_total, pad
+    HIP_TRY(hipMemcpy(head, d->d_exc, sizeof(head), hipMemcpyDeviceToHost));
+    if (head[0] & ~FMD_DEVERR_EXC_CAP) { set_err("device-side sizing assertion failed (bits 0x%x)", head[0]); return FMD_ERR_HIP; }
+    if (head[1] == 0) return FMD_OK;
+    const uint32_t n = head[1] < FMD_EXC_CAP ? head[1] : FMD_EXC_CAP;
+    std::vector<FmdF64Exc> recs(n);
+    HIP_TRY(hipMemcpy(recs.data(), d->d_exc->rec, n * sizeof(FmdF64Exc), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemset(d->d_exc, 0, 16));
+    d->f64_guarded += head[1];
+    int rc = FMD_OK;
+    // several guarded samples may share one audio group (block_len mode): their corrections add up
+    std::map<std::pair<uint32_t, uint64_t>, std::pair<int64_t, const FmdF64Exc*>> groups;   // (seq, out_elem) -> (delta, record)
+    for (const FmdF64Exc& e : recs) {
+        const int16_t want = (int16_t)host_polar_f64(e.cr, e.ci), have = (int16_t)e.d_gpu;
+        if (want == have) continue;
+        d->f64_patched += 1;
+        const int delta = (int)want - (int)have;
+        if (e.k >= 0) {
+            auto& g = groups[{e.seq, e.out_elem}];
+            g.first += delta; g.second = &e;
+        } else if (e.seq == d->seq) {
+            int32_t now = 0;
+            int32_t* p = &d->d_state[d->cur][e.channel].now_lpr;
+            HIP_TRY(hipMemcpy(&now, p, sizeof(now), hipMemcpyDeviceToHost));
+            now += delta;
+            HIP_TRY(hipMemcpy(p, &now, sizeof(now), hipMemcpyHostToDevice));
+        } else {
+            set_err("a guarded f64 sample of launch %u (channel %u) lies in the carried partial sum and a later launch "
+                    "has already consumed it: call fmd_demod_check() after every fmd_demod_demodulate_device", e.seq, e.channel);
+            rc = FMD_ERR_HIP;
+        }
+    }
+    for (const auto& kv : groups) {
+        const FmdF64Exc& e = *kv.second.second;
+        const int16_t fixed = (int16_t)((e.sum + (int)kv.second.first) / d->r.R);      // low_pass_real, simple_fm.rs:421
+        if (host_out && e.seq == d->seq) host_out[(size_t)e.channel * host_cap + (size_t)e.k] = fixed;
+        else HIP_TRY(hipMemcpy((void*)(uintptr_t)e.out_elem, &fixed, sizeof(fixed), hipMemcpyHostToDevice));
+    }
+    if (head[0] & FMD_DEVERR_EXC_CAP) {
+        set_err("more than %u guarded f64 samples since the last check: some were not re-evaluated", FMD_EXC_CAP);
+        rc = FMD_ERR_HIP;
+    }
+    return rc;
 }
 
 }  // namespace
@@ -390,15 +444,7 @@ int fmd_demod_new(const fmd_demod_config* config, const fmd_device_config* dev, 
     if (d->block_threads != 128 && d->block_threads != 64) d->block_threads = 256;
     // two waves per block step 2*127 windows per round: an odd downsample would flip a lane's rotation phase
     if (d->block_threads == 128 && (config->downsample & 1u)) d->block_threads = 256;
-    // Default data movement: the LDS-tile kernel.  FMD_STREAM=1 selects the register-streaming kernel with the
-    // largest round these rates allow (same results; measured 5-10 % slower in round 1, kept for A/B).
-    uint32_t kt_env = env_u32("FMD_KT", 0);
-    d->rounds_per_wave = env_u32("FMD_RPW", 4);
-    if (d->rounds_per_wave == 0) d->rounds_per_wave = 1;
-    if (kt_env == 0 && env_u32("FMD_STREAM", 0) != 0 && !d->force_generic) {
-        const uint32_t skt = fmd_stream_round_kt(r);
-        if (skt) { kt_env = skt; d->stream_mode = true; }
-    }
+    const uint32_t kt_env = env_u32("FMD_KT", 0);
     int rc = choose_tiling(d, kt_env);
     if (rc) { delete d; return rc; }
 
@@ -417,7 +463,6 @@ int fmd_demod_new(const fmd_demod_config* config, const fmd_device_config* dev, 
     }
     d->device = device;
     d->n_cus = prop.multiProcessorCount;
-    d->persist_mode = (int)env_u32("FMD_PERSIST", 0);
     reset_classes(d);
 
     auto fail = [&](hipError_t e, const char* what) {
@@ -426,14 +471,17 @@ int fmd_demod_new(const fmd_demod_config* config, const fmd_device_config* dev, 
         return e == hipErrorOutOfMemory ? FMD_ERR_NOMEM : FMD_ERR_HIP;
     };
     hipError_t e;
-    if ((e = hipSetDevice(device)) != hipSuccess) return fail(e, "hipSetDevice");
+    FmdDeviceGuard guard(device);                             // the caller's current device comes back on return
+    if ((e = guard.error()) != hipSuccess) return fail(e, "hipSetDevice");
+    if (const char* g = getenv("FMD_F64_GUARD_LOG2")) { if (*g) d->f64_guard = ldexp(1.0, atoi(g)); }
+    d->f64_skew = (int32_t)env_u32("FMD_F64_SKEW", 0);
     const size_t sbytes = sizeof(FmdChanState) * (size_t)d->C;
     for (int i = 0; i < 2; ++i) {
         if ((e = hipMalloc(&d->d_state[i], sbytes)) != hipSuccess) return fail(e, "hipMalloc(state)");
         if ((e = hipMemset(d->d_state[i], 0, sbytes)) != hipSuccess) return fail(e, "hipMemset(state)");
     }
-    if ((e = hipMalloc(&d->d_err, 64)) != hipSuccess) return fail(e, "hipMalloc(err)");
-    if ((e = hipMemset(d->d_err, 0, 64)) != hipSuccess) return fail(e, "hipMemset(err)");
+    if ((e = hipMalloc(&d->d_exc, sizeof(FmdExcBuf))) != hipSuccess) return fail(e, "hipMalloc(reports)");
+    if ((e = hipMemset(d->d_exc, 0, sizeof(FmdExcBuf))) != hipSuccess) return fail(e, "hipMemset(reports)");
     if ((e = hipStreamCreateWithFlags(&d->stream, hipStreamNonBlocking)) != hipSuccess) return fail(e, "hipStreamCreate");
     if ((e = hipDeviceSynchronize()) != hipSuccess) return fail(e, "hipDeviceSynchronize");
     *out = d;
@@ -443,10 +491,11 @@ int fmd_demod_new(const fmd_demod_config* config, const fmd_device_config* dev, 
 void fmd_demod_free(fmd_demod* d)
 {
     if (!d) return;
-    (void)hipSetDevice(d->device);
+    FmdDeviceGuard guard(d->device);
     (void)hipDeviceSynchronize();
     for (int i = 0; i < 2; ++i) if (d->d_state[i]) (void)hipFree(d->d_state[i]);
-    if (d->d_err) (void)hipFree(d->d_err);
+    if (d->d_exc) (void)hipFree(d->d_exc);
+    d->order.destroy();
     if (d->d_chan_class) (void)hipFree(d->d_chan_class);
     if (d->d_iq) (void)hipFree(d->d_iq);
     if (d->d_out) (void)hipFree(d->d_out);
@@ -457,15 +506,15 @@ void fmd_demod_free(fmd_demod* d)
 int fmd_demod_reset(fmd_demod* d)
 {
     if (!d) return FMD_ERR_INVALID_ARG;
-    int rc = use_device(d);
-    if (rc) return rc;
+    ON_DEVICE(d->device);
     HIP_TRY(hipDeviceSynchronize());
     const size_t sbytes = sizeof(FmdChanState) * (size_t)d->C;
     HIP_TRY(hipMemset(d->d_state[0], 0, sbytes));
     HIP_TRY(hipMemset(d->d_state[1], 0, sbytes));
-    HIP_TRY(hipMemset(d->d_err, 0, sizeof(uint32_t)));
+    HIP_TRY(hipMemset(d->d_exc, 0, 16));
     HIP_TRY(hipDeviceSynchronize());
     d->cur = 0;
+    d->order.reset();
     reset_classes(d);
     return FMD_OK;
 }
@@ -474,8 +523,7 @@ int fmd_demod_demodulate_device(fmd_demod* d, const void* d_iq, size_t nbytes, v
                                 void* d_out_len, void* stream)
 {
     if (!d || !d_iq || !d_out) { set_err("null argument"); return FMD_ERR_INVALID_ARG; }
-    int rc = use_device(d);
-    if (rc) return rc;
+    ON_DEVICE(d->device);
     return enqueue(d, d_iq, nbytes, d_out, out_cap, d_out_len, static_cast<hipStream_t>(stream));
 }
 
@@ -483,8 +531,8 @@ int fmd_demod_demodulate_batch(fmd_demod* d, const uint8_t* iq, size_t nbytes, i
                                size_t* out_len)
 {
     if (!d || !iq || !out || !out_len) { set_err("null argument"); return FMD_ERR_INVALID_ARG; }
-    int rc = use_device(d);
-    if (rc) return rc;
+    ON_DEVICE(d->device);
+    int rc;
     {   // validate before touching the staging buffers
         std::vector<FmdClassPlan> plans; uint32_t tiles;
         rc = plan_call(d, nbytes, out_cap, plans, &tiles);
@@ -518,11 +566,8 @@ int fmd_demod_demodulate_batch(fmd_demod* d, const uint8_t* iq, size_t nbytes, i
         HIP_TRY(hipMemcpy2DAsync(out, out_cap * sizeof(int16_t), d->d_out, out_cap * sizeof(int16_t),
                                  (size_t)kmax * sizeof(int16_t), d->C, hipMemcpyDeviceToHost, d->stream));
     }
-    uint32_t err = 0;
-    HIP_TRY(hipMemcpyAsync(&err, d->d_err, sizeof(err), hipMemcpyDeviceToHost, d->stream));
     HIP_TRY(hipStreamSynchronize(d->stream));
-    if (err) { set_err("device-side sizing assertion failed (bits 0x%x)", err); return FMD_ERR_HIP; }
-    return FMD_OK;
+    return resolve_device_reports(d, out, out_cap);   // device assertions + guarded f64 samples (patched in `out`)
 }
 
 int fmd_demod_demodulate(fmd_demod* d, const uint8_t* iq, size_t nbytes, int16_t* out, size_t out_cap,
@@ -575,17 +620,31 @@ int fmd_demod_last_out_len(const fmd_demod* d, size_t* out_len)
     return FMD_OK;
 }
 
+int fmd_demod_check(fmd_demod* d)
+{
+    if (!d) { set_err("null argument"); return FMD_ERR_INVALID_ARG; }
+    ON_DEVICE(d->device);
+    HIP_TRY(hipDeviceSynchronize());
+    return resolve_device_reports(d, nullptr, 0);
+}
+
+int fmd_demod_f64_stats(const fmd_demod* d, uint64_t* guarded, uint64_t* patched)
+{
+    if (!d) return FMD_ERR_INVALID_ARG;
+    if (guarded) *guarded = d->f64_guarded;
+    if (patched) *patched = d->f64_patched;
+    return FMD_OK;
+}
+
 int fmd_demod_get_state(fmd_demod* d, uint32_t channel, fmd_demod_state* state)
 {
     if (!d || !state || channel >= d->C) { set_err("bad argument"); return FMD_ERR_INVALID_ARG; }
-    int rc = use_device(d);
-    if (rc) return rc;
+    ON_DEVICE(d->device);
     HIP_TRY(hipDeviceSynchronize());
+    int rc = resolve_device_reports(d, nullptr, 0);
+    if (rc) return rc;
     FmdChanState s;
     HIP_TRY(hipMemcpy(&s, d->d_state[d->cur] + channel, sizeof(s), hipMemcpyDeviceToHost));
-    uint32_t err = 0;
-    HIP_TRY(hipMemcpy(&err, d->d_err, sizeof(err), hipMemcpyDeviceToHost));
-    if (err) { set_err("device-side sizing assertion failed (bits 0x%x)", err); return FMD_ERR_HIP; }
     state->prev_index = s.prev_index;
     state->now_lpr = s.now_lpr;
     state->prev_lpr_index = (int32_t)(s.lpr_index_r * d->r.g);
@@ -608,9 +667,12 @@ int fmd_demod_set_state(fmd_demod* d, uint32_t channel, const fmd_demod_state* s
         set_err("state not reachable from Demod::new by demodulate calls");
         return FMD_ERR_BAD_STATE;
     }
-    int rc = use_device(d);
-    if (rc) return rc;
+    ON_DEVICE(d->device);
     HIP_TRY(hipDeviceSynchronize());
+    {
+        const int rr = resolve_device_reports(d, nullptr, 0);   // a pending patch of the carried sum comes first
+        if (rr) return rr;
+    }
     FmdChanState s{};
     s.prev_index = state->prev_index;
     s.lpr_index_r = (uint32_t)state->prev_lpr_index / r.g;
@@ -650,7 +712,9 @@ int fmd_synth_fill_device(int device_id, void* d_iq, uint32_t n_channels, size_t
     if (!d_iq || !p || n_channels == 0) { set_err("null argument"); return FMD_ERR_INVALID_ARG; }
     if (nbytes % 8 != 0) { set_err("nbytes %% 8 != 0"); return FMD_ERR_BAD_LENGTH; }
     if (p->amplitude > 120 || p->noise > 64 || p->mod_period < 2) { set_err("synth parameters out of range"); return FMD_ERR_INVALID_ARG; }
-    if (device_id >= 0) HIP_TRY(hipSetDevice(device_id));
+    int dev_now = device_id;
+    if (dev_now < 0 && hipGetDevice(&dev_now) != hipSuccess) dev_now = 0;
+    ON_DEVICE(dev_now);
     if (nbytes == 0) return FMD_OK;
     FmdSynthLaunch S{};
     S.iq = static_cast<uint8_t*>(d_iq);

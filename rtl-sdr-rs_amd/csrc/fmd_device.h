@@ -7,6 +7,7 @@
 #include <stdint.h>
 
 #include "fmd_index.h"
+#include "fmd_kernels.h"
 
 namespace fmd_dev {
 
@@ -44,10 +45,46 @@ __device__ __forceinline__ void lds_window_sum(const uint32_t* __restrict__ raw_
 
 // Demod::polar_discriminant (:370-374) on the already-formed product c = a * conj(b): the one f64
 // atan2 sample of every call (:359).  Kept out of line: it runs on one lane per channel-call.
-static __device__ __noinline__ int polar_f64(int cr, int ci)
+// Exact directions first (integer decisions; libm and ocml both return the exact f64 there, so the reference's
+// values are 0, +-4096, +-8192, +-12288, 16384 -- tests/test_oracle_kat.py pins that table against the host libm).
+// Otherwise `*guarded` reports whether the value lies within `guard` of an integer (see FmdF64Exc, fmd_kernels.h).
+static __device__ __noinline__ int polar_f64(int cr, int ci, double guard, bool* guarded)
 {
+    *guarded = false;
+    if (ci == 0) return cr >= 0 ? 0 : 16384;                 // atan2(+-0, x): 0 or pi (0, 0 -> 0)
+    if (cr == 0) return ci > 0 ? 8192 : -8192;               // +-pi/2
+    if (cr == ci) return cr > 0 ? 4096 : -12288;             // pi/4, -3pi/4
+    if (cr == -ci) return cr > 0 ? -4096 : 12288;            // -pi/4, 3pi/4
     const double angle = atan2((double)ci, (double)cr);
-    return (int)(angle / kPi * 16384.0);
+    const double v = angle / kPi * 16384.0;
+    *guarded = fabs(v - rint(v)) < guard;
+    return (int)v;
+}
+
+// Append the record of one guarded sample (one lane, after the tile's d16[] is complete: d16[j - jfirst] holds
+// discriminator sample j for every j of the audio groups this tile owns).  (i0r, K): resampler phase / audio
+// count of this channel-call.
+static __device__ __noinline__ void exc_emit(const FmdLaunch& L, uint32_t c, uint32_t i0r, uint32_t K, int now_lpr_in,
+                                            const int16_t* d16, int jfirst, int j, int cr, int ci)
+{
+    const FmdRates& r = L.r;
+    FmdF64Exc e{};
+    e.channel = c; e.cr = cr; e.ci = ci;
+    e.d_gpu = d16[j - jfirst];
+    e.seq = L.seq;
+    const uint32_t k = ((uint32_t)j * r.sr + i0r) / r.fr;            // the audio sample whose group contains j
+    if (k < K) {
+        const int hi = (int)fmd_audio_end(r, i0r, k), lo = k == 0 ? 0 : (int)fmd_audio_end(r, i0r, k - 1) + 1;
+        int sum = k == 0 ? now_lpr_in : 0;
+        for (int jj = lo; jj <= hi; ++jj) sum += d16[jj - jfirst];
+        e.k = (int)k; e.sum = sum;
+        e.out_elem = (uint64_t)(uintptr_t)(L.out + (uint64_t)c * L.out_stride + k);
+    } else {
+        e.k = -1;                                                     // lies in the partial group carried in now_lpr
+    }
+    atomicAdd(&L.exc->guarded_total, 1u);
+    const uint32_t slot = atomicAdd(&L.exc->count, 1u);
+    if (slot < FMD_EXC_CAP) L.exc->rec[slot] = e; else atomicOr(L.err, FMD_DEVERR_EXC_CAP);
 }
 
 // Decimated samples travel packed: re in the low, im in the high 16 bits (|lp| <= 128 * D <= 16384).

@@ -32,7 +32,7 @@
 #include <new>
 #include <vector>
 
-void fmd_internal_set_err(const char* msg);
+#include "fmd_host.h"
 
 namespace {
 
@@ -336,6 +336,10 @@ __global__ void __launch_bounds__(kFirThreads) fmd_fir_hist_kernel(const FirLaun
         }                                                                                   \
     } while (0)
 
+#define FIR_ON_DEVICE(dev)                                                                  \
+    FmdDeviceGuard dev_guard_(dev);                                                         \
+    if (dev_guard_.error() != hipSuccess) { fmd_internal_set_err("hipSetDevice failed"); return FMD_ERR_HIP; }
+
 }  // namespace
 
 struct fmd_fir {
@@ -350,6 +354,7 @@ struct fmd_fir {
     int cur = 0;
     int32_t cre[2] = {0, 0}, cim[2] = {0, 0};
     hipStream_t stream = nullptr;
+    FmdStreamOrder order;                                 // consecutive launches on different streams (fmd_host.h)
     uint8_t* d_iq = nullptr; size_t d_iq_cap = 0;
     int32_t* d_out = nullptr; size_t d_out_cap = 0;
 };
@@ -373,6 +378,7 @@ int fir_enqueue(fmd_fir* f, const void* d_iq, size_t nbytes, void* d_out, size_t
     fir_counts(f, ns, &m0, &m1);
     const uint64_t n_out = m1 - m0;
     if (n_out > out_cap) { fmd_internal_set_err("out_cap too small"); return FMD_ERR_CAPACITY; }
+    FIR_TRY(f->order.before(stream));                     // the history ping-pong orders launch n+1 behind launch n
     FirLaunch L{};
     L.iq = static_cast<const uint32_t*>(d_iq);
     L.stride_w = nbytes / 4;
@@ -431,6 +437,7 @@ int fir_enqueue(fmd_fir* f, const void* d_iq, size_t nbytes, void* d_out, size_t
         hipLaunchKernelGGL(fmd_fir_hist_kernel, dim3((uint32_t)((th + kFirThreads - 1) / kFirThreads)), dim3(kFirThreads), 0, stream, L);
         FIR_TRY(hipGetLastError());
     }
+    f->order.after(stream);
     if (f->Hw) f->cur ^= 1;
     f->pos += ns;
     if (n_each) *n_each = (size_t)n_out;
@@ -530,7 +537,8 @@ int fmd_fir_new(const int16_t* taps, uint32_t n_taps, uint32_t decim, const fmd_
         }
     }
     auto fail = [&](const char* what) { fmd_internal_set_err(what); fmd_fir_free(f); return FMD_ERR_HIP; };
-    if (hipSetDevice(device) != hipSuccess) return fail("hipSetDevice");
+    FmdDeviceGuard guard(device);                         // the caller's current device comes back on return
+    if (guard.error() != hipSuccess) return fail("hipSetDevice");
     if (!amat.empty()) {
         if (hipMalloc(&f->d_amat, amat.size() * 4) != hipSuccess) return fail("hipMalloc(tap matrix)");
         if (hipMemcpy(f->d_amat, amat.data(), amat.size() * 4, hipMemcpyHostToDevice) != hipSuccess) return fail("hipMemcpy(tap matrix)");
@@ -552,8 +560,9 @@ int fmd_fir_new(const int16_t* taps, uint32_t n_taps, uint32_t decim, const fmd_
 void fmd_fir_free(fmd_fir* f)
 {
     if (!f) return;
-    (void)hipSetDevice(f->device);
+    FmdDeviceGuard guard(f->device);
     (void)hipDeviceSynchronize();
+    f->order.destroy();
     if (f->d_wre) (void)hipFree(f->d_wre);
     if (f->d_wim) (void)hipFree(f->d_wim);
     if (f->d_amat) (void)hipFree(f->d_amat);
@@ -567,8 +576,9 @@ void fmd_fir_free(fmd_fir* f)
 int fmd_fir_reset(fmd_fir* f)
 {
     if (!f) return FMD_ERR_INVALID_ARG;
-    FIR_TRY(hipSetDevice(f->device));
+    FIR_ON_DEVICE(f->device);
     FIR_TRY(hipDeviceSynchronize());
+    f->order.reset();
     const size_t hb = (size_t)f->C * (f->Hw ? f->Hw : 1) * 4;
     FIR_TRY(hipMemset(f->d_hist[0], 0, hb));
     FIR_TRY(hipMemset(f->d_hist[1], 0, hb));
@@ -581,14 +591,14 @@ int fmd_fir_filter_device(fmd_fir* f, const void* d_iq, size_t nbytes, void* d_o
                           void* stream)
 {
     if (!f || !d_iq || !d_out) { fmd_internal_set_err("null argument"); return FMD_ERR_INVALID_ARG; }
-    FIR_TRY(hipSetDevice(f->device));
+    FIR_ON_DEVICE(f->device);
     return fir_enqueue(f, d_iq, nbytes, d_out, out_cap, out_len_each, static_cast<hipStream_t>(stream));
 }
 
 int fmd_fir_filter_batch(fmd_fir* f, const uint8_t* iq, size_t nbytes, int32_t* out, size_t out_cap, size_t* out_len)
 {
     if (!f || !iq || !out || !out_len) { fmd_internal_set_err("null argument"); return FMD_ERR_INVALID_ARG; }
-    FIR_TRY(hipSetDevice(f->device));
+    FIR_ON_DEVICE(f->device);
     if (nbytes % 8 != 0) { fmd_internal_set_err("nbytes % 8 != 0"); return FMD_ERR_BAD_LENGTH; }
     uint64_t m0, m1;
     fir_counts(f, nbytes / 2, &m0, &m1);

@@ -4,8 +4,8 @@
 // The generic kernel fuses every pass of Demod::demodulate (examples/simple_fm.rs:256-269) exactly
 // like the production tile kernel (fmd_tile_kernel.hip) but makes no assumption beyond
 // fmd_ranges_fit32(): any downsample <= 128, any phase per channel, any tiling.  It is what runs
-// when the phase-class plans do not apply (> FMD_MAX_CLASSES distinct phases in one bank, tiling
-// not a multiple of the reduced resample rate, downsample > 64).
+// when the phase-class plans do not apply (> FMD_MAX_CLASSES distinct phases in one bank, or reduced
+// rates beyond the exact-small-divide range of the tile kernel) and under FMD_FORCE_GENERIC=1.
 #include "fmd_device.h"
 #include "fmd_kernels.h"
 
@@ -81,8 +81,13 @@ __global__ void __launch_bounds__(FMD_BLOCK_THREADS) fmd_demod_generic_kernel(co
         int cr, ci;
         fmd_mul_conj(lp_re(a), lp_im(a), lp_re(b), lp_im(b), cr, ci);
         int pcm;
-        if (jfirst + i == 0) pcm = polar_f64(cr, ci);       // first sample of the call (:359)
-        else                 pcm = fmd_fast_atan2(ci, cr);  // (:362)
+        if (jfirst + i == 0) {                               // first sample of the call (:359)
+            bool g;
+            pcm = polar_f64(cr, ci, L.f64_guard, &g);
+#ifdef FMD_EXPERIMENT
+            if (g) pcm += L.f64_skew;
+#endif
+        } else pcm = fmd_fast_atan2(ci, cr);                 // (:362)
         d16[i] = (int16_t)pcm;
     }
     __syncthreads();
@@ -96,6 +101,16 @@ __global__ void __launch_bounds__(FMD_BLOCK_THREADS) fmd_demod_generic_kernel(co
         int sum = (T.k0 + q == 0) ? st.now_lpr : 0;
         for (int j = s; j <= e; ++j) sum += d16[j - jfirst];
         outc[T.k0 + q] = (int16_t)(sum / r.R);
+    }
+
+    // guarded f64 sample (FmdF64Exc, fmd_kernels.h): the record needs the finished group sums
+    if (jfirst < 0 && tid == 0) {
+        const uint32_t a = lp_pk[1], b = lp_pk[0];
+        int cr, ci;
+        fmd_mul_conj(lp_re(a), lp_im(a), lp_re(b), lp_im(b), cr, ci);
+        bool g;
+        (void)polar_f64(cr, ci, L.f64_guard, &g);
+        if (g) exc_emit(L, c, i0r, K, st.now_lpr, d16, jfirst, 0, cr, ci);
     }
 
     // ---- Demod state after the call (last tile only; :232-239) --------------------------------

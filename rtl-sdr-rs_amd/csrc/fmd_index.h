@@ -5,7 +5,7 @@
 // the discriminator (fm_demod :355-367) and the fractional boxcar resampler (low_pass_real
 // :408-426).  None of their *index* state depends on sample values, so every output is a
 // pure function of (call-start phases, position).  This header is that algebra; the HIP
-// kernels (fmd_kernels.hip), the host bookkeeping (fmd_api.cpp) and the CPU closed-form
+// kernels (fmd_tile_kernel.hip, fmd_generic_kernel.hip), the host bookkeeping (fmd_api.cpp) and the CPU closed-form
 // model used by the tests (oracle/closed_form.cpp) all include it, so the tests exercise
 // the very expressions the kernel uses.
 //
@@ -27,7 +27,7 @@
 
 #include <stdint.h>
 
-#if defined(__HIPCC__) || defined(__CUDACC__)
+#if defined(__HIPCC__)
 #define FMD_HD __host__ __device__ __forceinline__
 #else
 #define FMD_HD inline

@@ -1,4 +1,4 @@
-// fmd_kernels.h -- launch descriptors shared by fmd_kernels.hip and fmd_api.cpp.
+// fmd_kernels.h -- launch descriptors shared by the kernels (fmd_tile_kernel.hip, fmd_generic_kernel.hip) and fmd_api.cpp.
 #ifndef FMD_KERNELS_H
 #define FMD_KERNELS_H
 
@@ -16,6 +16,35 @@
 // Device-side error bits (FmdLaunch::err), all "cannot happen" conditions.
 #define FMD_DEVERR_LP_CAP  1u
 #define FMD_DEVERR_RAW_CAP 2u
+#define FMD_DEVERR_EXC_CAP 4u     /* more guarded f64 samples than the exception buffer holds */
+
+// ---- guarded f64 sample (Demod::polar_discriminant, simple_fm.rs:370-374) ------------------------------------
+// The one f64 sample of every reference call is `(atan2(im, re) / PI * 16384.0) as i32`: the reference takes
+// atan2 from the system libm, the kernel from ocml.  Two faithful atan2 implementations (a few ulp each) can
+// only truncate differently when angle / PI * 16384 lies within ~2^-35 of an integer.  The kernel therefore
+//   * decides the 8 axis / diagonal directions (and 0, 0) with integers (both libraries are exact there),
+//   * and for every other sample whose value lies within f64_guard (default 2^-20) of an integer appends a
+//     record here; the host re-evaluates those few with ITS libm -- the function the reference calls -- and
+//     patches the audio sample (or the carried partial sum) that contains it.  Outside the guard band the two
+//     results are provably equal, so the s16 output never depends on ocml's last bits.
+#define FMD_EXC_CAP 1024u
+struct FmdF64Exc {
+    uint32_t channel;
+    int32_t  k;          // audio sample of this launch that contains the f64 sample; -1: the trailing partial group (now_lpr)
+    int32_t  cr, ci;     // the product a * conj(b) the sample is the angle of
+    int32_t  d_gpu;      // what the kernel used
+    int32_t  sum;        // k >= 0: the group's sum including d_gpu (audio = sum / R)
+    uint32_t seq;        // launch sequence number of the handle
+    uint32_t pad;
+    uint64_t out_elem;   // device address of out[channel][k]
+    uint64_t pad2;
+};
+struct FmdExcBuf {
+    uint32_t err;        // FMD_DEVERR_* bits
+    uint32_t count;      // records appended (may exceed FMD_EXC_CAP: then FMD_DEVERR_EXC_CAP is set too)
+    uint32_t guarded_total, pad;
+    FmdF64Exc rec[FMD_EXC_CAP];
+};
 
 struct FmdLaunch {
     const uint8_t* iq;        // [n_channels][chan_stride] interleaved u8 IQ, 16-byte aligned base
@@ -23,7 +52,8 @@ struct FmdLaunch {
     uint64_t total_bytes;     // n_channels * chan_stride
     FmdRates r;
     uint32_t ns;              // complex samples per channel this call
-    uint32_t xcd_swizzle;     // tile kernel: 0 plain, 1 / 2 XCD-aware block -> (channel, tile) mapping (FMD_XCD, default 2)
+    uint32_t xcd_swizzle;     // tile kernel: 0 plain; 1 / 2 XCD-aware block -> (channel, tile) mapping by index arithmetic (FMD_XCD);
+                              // 3 (what runs by default, set by fmd_launch_tile): the same mapping through the grid shape (8, tiles, ceil(C/8))
     uint32_t block_ns;        // > 0: the call is ns / block_ns consecutive reference calls of block_ns samples each
     uint32_t n_channels;
     uint32_t tiles;           // grid tiles per channel (>= every channel's own tile count)
@@ -34,12 +64,13 @@ struct FmdLaunch {
     int16_t* out;             // [n_channels][out_stride]
     uint64_t out_stride;      // samples
     uint32_t* out_len;        // [n_channels] or nullptr
-    uint32_t* err;            // device error word
+    uint32_t* err;            // device error word (= &exc->err)
+    FmdExcBuf* exc;           // guarded f64 samples of this handle
+    double    f64_guard;      // half-width of the guard band around integers (see above)
+    uint32_t  seq;            // launch sequence number (FmdF64Exc::seq)
+    int32_t   f64_skew;       // -DFMD_EXPERIMENT builds only: added to the kernel's value of guarded samples (patch-path test)
     uint32_t dbg;             // ablation bits, honoured only by -DFMD_EXPERIMENT builds (tuning; never shipped)
-    uint32_t persist_blocks;  // > 0: persistent kernel with this many blocks; 0: one block per tile
     uint32_t block_threads;   // one-block-per-tile kernel: 64, 128 or 256 (default) threads
-    uint32_t rounds_per_wave; // streaming kernel: consecutive rounds (tiles of kt audio samples) one wave walks
-    uint32_t group_rounds;    // streaming kernel: rounds whose audio samples are produced together (<= 64 / kt)
     // ---- tile kernel only (phase-class plans; see fmd_index.h) ----
     uint32_t Qt;              // decimated samples per full tile = kt * fr / sr (== tl.Qt)
     FmdTiling tl;             // tiling constants of fmd_tile_fast
@@ -61,20 +92,10 @@ struct FmdSynthLaunch {
 // Can the division-free tile kernel run this configuration?  (Otherwise the generic kernel does.)
 bool fmd_tile_kernel_supports(const FmdRates& r, uint32_t raw_cap);
 
-// The persistent kernel prefetches a whole tile in registers: FMD_PERSIST_LOADS x 16 B per lane.
-#define FMD_PERSIST_LOADS 5
-inline bool fmd_persist_supports(uint32_t raw_cap) { return raw_cap <= 16u * FMD_PERSIST_LOADS * FMD_BLOCK_THREADS; }
-int fmd_persist_blocks_per_cu(const FmdLaunch& L);   // occupancy of the persistent kernel for this config
-
 size_t fmd_generic_lds_bytes(const FmdLaunch& L);
 size_t fmd_tile_lds_bytes(const FmdLaunch& L);
 hipError_t fmd_launch_generic(const FmdLaunch& L, hipStream_t stream);
 hipError_t fmd_launch_tile(const FmdLaunch& L, hipStream_t stream);
-// Register-streaming kernel (fmd_stream_kernel.hip): no LDS staging, a wave walks consecutive rounds.
-bool fmd_stream_kernel_supports(const FmdRates& r);       // for r.kt = the round size
-uint32_t fmd_stream_round_kt(const FmdRates& r);          // largest supported round size, 0 = none
-uint32_t fmd_stream_group_rounds(const FmdRates& r);      // rounds per audio group for r.kt
-hipError_t fmd_launch_stream(const FmdLaunch& L, hipStream_t stream);
 hipError_t fmd_launch_synth(const FmdSynthLaunch& S, hipStream_t stream);
 
 #endif

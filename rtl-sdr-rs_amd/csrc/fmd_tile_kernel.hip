@@ -22,9 +22,7 @@
 //     * discriminator: complex multiply by 2 x v_dot2_i32_i16 on packed (re, im); branch-free
 //       fast_atan2 with an exact f32-reciprocal divide;
 //     * resampler: one audio sample per lane from the tile's discriminator samples in LDS.
-//   fmd_demod_tile_kernel (default): one block per tile, LDS-DMA staging (global_load_lds_dwordx4).
-//   fmd_demod_persist_kernel (FMD_PERSIST=1, measured slower): grid = CUs x resident blocks; each block walks
-//     tiles lin, lin + G, ... with the NEXT tile's 16-byte loads in flight in registers during compute.
+//   fmd_demod_tile_kernel: one block per tile, LDS-DMA staging (global_load_lds_dwordx4).
 #include "fmd_device.h"
 #include "fmd_kernels.h"
 
@@ -36,8 +34,10 @@ using namespace fmd_dev;
 // library compiles them to `false`.
 #ifdef FMD_EXPERIMENT
 #define FMD_ABLATE(bit) ((L.dbg >> (bit)) & 1u)
+#define FMD_F64_SKEW (L.f64_skew)      /* test hook: make the kernel's value of a guarded f64 sample wrong on purpose */
 #else
 #define FMD_ABLATE(bit) false
+#define FMD_F64_SKEW 0
 #endif
 
 // Explicit address spaces exist only in the device pass (the host pass parses the same bodies).
@@ -214,6 +214,46 @@ __device__ __forceinline__ void stage_slow(const FmdLaunch& L, const TileCtx& X,
     }
 }
 
+// Rare path (one lane): walk the tile's f64 samples again -- the call-start sample and, in block_len mode, every
+// reference-call boundary inside the tile -- and append a record for each guarded one.  Recomputing the products
+// here keeps the common path free of bookkeeping (no LDS list, no live registers).
+static __device__ __noinline__ void tile_exc_flush(const FmdLaunch& L, const TileCtx& X, const FmdChanState& st,
+                                                  const uint32_t* raw_w, const int16_t* d16)
+{
+    const FmdRates& r = L.r;
+    const FmdClassPlan& P = L.cls[X.cls];
+    const FmdTile& T = X.T;
+    const uint32_t p0 = P.p0;
+    const int jfirst = X.jfirst, wofs = X.wofs;
+    bool g;
+    if (jfirst < 0) {
+        int r0, i0, cr, ci;
+        lds_window_sum(raw_w, wofs, 0, fmd_win_end(r.D, p0, 0), r0, i0);
+        r0 += st.lp_now_re; i0 += st.lp_now_im;
+        fmd_mul_conj(r0, i0, st.demod_pre_re, st.demod_pre_im, cr, ci);
+        (void)polar_f64(cr, ci, L.f64_guard, &g);
+        if (g) exc_emit(L, X.c, P.i0r, P.K, st.now_lpr, d16, jfirst, 0, cr, ci);
+    }
+    if (L.block_ns) {
+        const uint32_t D = r.D, nb = L.block_ns;
+        const uint32_t lo = (uint32_t)(T.jA > 1 ? T.jA : 1) * D;
+        uint32_t b = lo > p0 ? (lo - p0 + nb - 1u) / nb : 1u;
+        if (b == 0u) b = 1u;
+        for (; (uint64_t)b * nb < L.ns; ++b) {
+            const int j = (int)((p0 + b * nb) / D);
+            if (j > T.jB) break;
+            if (j < T.jA) continue;
+            int ar, ai, br, bi, cr, ci;
+            lds_window_sum(raw_w, wofs, fmd_win_begin(D, p0, j), fmd_win_end(D, p0, j), ar, ai);
+            lds_window_sum(raw_w, wofs, fmd_win_begin(D, p0, j - 1), fmd_win_end(D, p0, j - 1), br, bi);
+            if (j - 1 == 0) { br += st.lp_now_re; bi += st.lp_now_im; }
+            fmd_mul_conj(ar, ai, br, bi, cr, ci);
+            (void)polar_f64(cr, ci, L.f64_guard, &g);
+            if (g) exc_emit(L, X.c, P.i0r, P.K, st.now_lpr, d16, jfirst, j, cr, ci);
+        }
+    }
+}
+
 // Everything after the tile's bytes are visible in LDS.  Contains one __syncthreads().
 template <int DH, int NT>
 __device__ __forceinline__ void tile_body(const FmdLaunch& L, const TileCtx& X, unsigned char* smem)
@@ -377,6 +417,7 @@ __device__ __forceinline__ void tile_body(const FmdLaunch& L, const TileCtx& X, 
     // Call start (at most once per channel-call, one lane): lp[-1] is demod_pre, lp[0] is the clipped first
     // window plus lp_now, d[0] takes the f64 path (:359); d[0] and d[1] are rewritten with them.  Same
     // wave as the loop's own stores to these entries, so program order makes the patch win.
+    bool any_guard = false;                                  // a guarded f64 sample in this tile (FmdF64Exc, fmd_kernels.h)
     if (jfirst <= 0 && tid == 0) {
         int r0, i0, r1, i1w, cr, ci;
         lds_window_sum(raw_w, wofs, 0, fmd_win_end(r.D, p0, 0), r0, i0);
@@ -384,7 +425,10 @@ __device__ __forceinline__ void tile_body(const FmdLaunch& L, const TileCtx& X, 
         lds_window_sum(raw_w, wofs, fmd_win_begin(r.D, p0, 1), fmd_win_end(r.D, p0, 1), r1, i1w);
         if (jfirst < 0) {
             fmd_mul_conj(r0, i0, st.demod_pre_re, st.demod_pre_im, cr, ci);
-            d16[1] = (int16_t)polar_f64(cr, ci);
+            bool g;
+            const int v = polar_f64(cr, ci, L.f64_guard, &g);
+            d16[1] = (int16_t)(v + (g ? FMD_F64_SKEW : 0));
+            any_guard = g;
         }
         fmd_mul_conj(r1, i1w, r0, i0, cr, ci);
         d16[1 - jfirst] = (int16_t)fmd_fast_atan2(ci, cr);
@@ -409,7 +453,10 @@ __device__ __forceinline__ void tile_body(const FmdLaunch& L, const TileCtx& X, 
             lds_window_sum(raw_w, wofs, fmd_win_begin(D, p0, j - 1), fmd_win_end(D, p0, j - 1), br, bi);
             if (j - 1 == 0) { br += st.lp_now_re; bi += st.lp_now_im; }
             fmd_mul_conj(ar, ai, br, bi, cr, ci);
-            d16[j - jfirst] = (int16_t)polar_f64(cr, ci);
+            bool g;
+            const int v = polar_f64(cr, ci, L.f64_guard, &g);
+            d16[j - jfirst] = (int16_t)(v + (g ? FMD_F64_SKEW : 0));
+            any_guard |= g;
         }
     }
     if (L.block_ns) __syncthreads();
@@ -456,6 +503,9 @@ __device__ __forceinline__ void tile_body(const FmdLaunch& L, const TileCtx& X, 
         for (int jj = 0; jj <= e; ++jj) sum += d16[jj - jfirst];
         outc[0] = (int16_t)fmd_sdiv_small(sum, r.R, L.inv_R);
     }
+
+    // Guarded f64 samples (rare: within 2^-20 of an integer): their records need the finished group sums.
+    if ((jfirst < 0 || L.block_ns) && tid == 0 && any_guard) tile_exc_flush(L, X, st, raw_w, d16);
 
     // ---- Demod state after the call (last tile only; :232-239) -------------------------------------
     if (T.last && tid == 0 && !FMD_ABLATE(5)) {
@@ -540,82 +590,6 @@ __global__ void __launch_bounds__(NT) fmd_demod_tile_kernel(const FmdLaunch L)
     tile_body<DH, NT>(L, X, smem);
 }
 
-// ---- persistent blocks, next tile's loads in flight during compute ---------------------------------------
-// FMD_PERSIST_LOADS (= 5) x 16 B per lane as NAMED members: hipcc keeps these in VGPRs, whereas a
-// `uint4 v[5]` that is conditionally (re)defined across loop iterations is demoted to scratch.
-struct TileRegs { uint4 a, b, c, d, e; };
-static_assert(FMD_PERSIST_LOADS == 5, "TileRegs holds five 16-byte chunks per lane");
-
-__device__ __forceinline__ TileRegs issue_loads(const TileCtx& X, uint32_t tid)
-{
-    // address_space(1): a pointer rebuilt from an integer is "flat" to hipcc, and flat loads also tick
-    // lgkmcnt, so the first LDS wait of the compute phase would drain the prefetch; global loads do not.
-    typedef const FMD_AS_GLOBAL uint4* gptr_t;
-    const gptr_t src = (gptr_t)(uintptr_t)X.a0;
-    const uint32_t lastc = X.nchunks - 1u;                   // surplus lanes re-read the last chunk (in bounds)
-    TileRegs v;
-    uint32_t i;
-    i = tid;                            v.a = src[i < lastc ? i : lastc];
-    i = tid + 1u * FMD_BLOCK_THREADS;   v.b = src[i < lastc ? i : lastc];
-    i = tid + 2u * FMD_BLOCK_THREADS;   v.c = src[i < lastc ? i : lastc];
-    i = tid + 3u * FMD_BLOCK_THREADS;   v.d = src[i < lastc ? i : lastc];
-    i = tid + 4u * FMD_BLOCK_THREADS;   v.e = src[i < lastc ? i : lastc];
-    return v;
-}
-
-__device__ __forceinline__ void write_loads(const TileCtx& X, const TileRegs& v, unsigned char* smem, uint32_t tid)
-{
-    uint4* dst = reinterpret_cast<uint4*>(smem) + tid;
-    const uint32_t n = X.nchunks;
-    if (tid < n) dst[0] = v.a;
-    if (tid + 1u * FMD_BLOCK_THREADS < n) dst[1 * FMD_BLOCK_THREADS] = v.b;
-    if (tid + 2u * FMD_BLOCK_THREADS < n) dst[2 * FMD_BLOCK_THREADS] = v.c;
-    if (tid + 3u * FMD_BLOCK_THREADS < n) dst[3 * FMD_BLOCK_THREADS] = v.d;
-    if (tid + 4u * FMD_BLOCK_THREADS < n) dst[4 * FMD_BLOCK_THREADS] = v.e;
-}
-
-template <int DH>
-__global__ void __launch_bounds__(FMD_BLOCK_THREADS) fmd_demod_persist_kernel(const FmdLaunch L)
-{
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const uint32_t tid = threadIdx.x;
-    const uint32_t total = L.tiles * L.n_channels, G = gridDim.x;
-    uint32_t lin = blockIdx.x;
-    if (lin >= total) return;
-    const uint32_t dq = G / L.tiles, dr = G - dq * L.tiles;   // (c, t) step of one grid stride
-    uint32_t c = lin / L.tiles, t = lin - c * L.tiles;
-
-    constexpr uint32_t kMaxChunks = FMD_PERSIST_LOADS * FMD_BLOCK_THREADS;
-    TileRegs v{};
-    {
-        const TileCtx first = tile_setup(L, c, t);
-        if (first.valid && first.whole && first.nchunks <= kMaxChunks) v = issue_loads(first, tid);
-    }
-    for (;;) {
-        // Only (c, t) and the prefetched registers are carried across iterations; the tile context is a few
-        // scalar multiply-adds and is recomputed rather than kept live.
-        const TileCtx cur = tile_setup(L, c, t);
-        if (cur.valid && !tile_fits(L, cur, tid)) return;
-        lin += G; c += dq; t += dr;
-        if (t >= L.tiles) { t -= L.tiles; ++c; }
-        const bool more = lin < total;
-        if (cur.valid) {
-            if (cur.whole && cur.nchunks <= kMaxChunks) write_loads(cur, v, smem, tid);   // loads issued a tile ago
-            else stage_slow<FMD_BLOCK_THREADS>(L, cur, smem, tid);
-        }
-        if (more) {
-            const TileCtx nxt = tile_setup(L, c, t);
-            if (nxt.valid && nxt.whole && nxt.nchunks <= kMaxChunks) v = issue_loads(nxt, tid);   // in flight during compute
-        }
-        if (cur.valid) {
-            __syncthreads();
-            if (!FMD_ABLATE(3)) tile_body<DH, FMD_BLOCK_THREADS>(L, cur, smem);
-            __syncthreads();                                          // LDS free for the next tile
-        }
-        if (!more) break;
-    }
-}
-
 template <int DH>
 void launch_one(const FmdLaunch& L, dim3 g, size_t lds, hipStream_t stream)
 {
@@ -624,21 +598,6 @@ void launch_one(const FmdLaunch& L, dim3 g, size_t lds, hipStream_t stream)
         case 64: hipLaunchKernelGGL((fmd_demod_tile_kernel<DH, 64>), g, dim3(64), lds, stream, L); break;
         default:  hipLaunchKernelGGL((fmd_demod_tile_kernel<DH, 256>), g, dim3(256), lds, stream, L); break;
     }
-}
-
-template <int DH>
-int persist_blocks_per_cu(size_t lds)
-{
-    int nb = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fmd_demod_persist_kernel<DH>, FMD_BLOCK_THREADS, lds) !=
-        hipSuccess) nb = 0;
-    return nb;
-}
-
-template <int DH>
-void launch_persist(const FmdLaunch& L, uint32_t blocks, size_t lds, hipStream_t stream)
-{
-    hipLaunchKernelGGL(fmd_demod_persist_kernel<DH>, dim3(blocks), dim3(FMD_BLOCK_THREADS), lds, stream, L);
 }
 
 }  // namespace
@@ -660,39 +619,11 @@ bool fmd_tile_kernel_supports(const FmdRates& r, uint32_t raw_cap)
     return true;
 }
 
-int fmd_persist_blocks_per_cu(const FmdLaunch& L)
-{
-    const size_t lds = fmd_tile_lds_bytes(L);
-    const uint32_t dh = (L.r.D % 2 == 0) ? L.r.D / 2 : 0;
-    switch (dh) {
-        case 1: return persist_blocks_per_cu<1>(lds);
-        case 2: return persist_blocks_per_cu<2>(lds);
-        case 3: return persist_blocks_per_cu<3>(lds);
-        case 4: return persist_blocks_per_cu<4>(lds);
-        case 5: return persist_blocks_per_cu<5>(lds);
-        default: return persist_blocks_per_cu<0>(lds);
-    }
-}
-
 hipError_t fmd_launch_tile(const FmdLaunch& L, hipStream_t stream)
 {
     const size_t lds = fmd_tile_lds_bytes(L);
     if (L.n_channels == 0 || L.tiles == 0) return hipErrorInvalidValue;
     const uint32_t dh = (L.r.D % 2 == 0) ? L.r.D / 2 : 0;
-    if (L.persist_blocks) {
-        const uint64_t total = (uint64_t)L.tiles * L.n_channels;
-        if (total > 0xFFFFFFFFull) return hipErrorInvalidValue;
-        const uint32_t blocks = total < L.persist_blocks ? (uint32_t)total : L.persist_blocks;
-        switch (dh) {
-            case 1: launch_persist<1>(L, blocks, lds, stream); break;
-            case 2: launch_persist<2>(L, blocks, lds, stream); break;
-            case 3: launch_persist<3>(L, blocks, lds, stream); break;   // cfg-ref, D = 6
-            case 4: launch_persist<4>(L, blocks, lds, stream); break;
-            case 5: launch_persist<5>(L, blocks, lds, stream); break;   // 2.4 Msps, D = 10
-            default: launch_persist<0>(L, blocks, lds, stream); break;  // generic windows
-        }
-        return hipGetLastError();
-    }
     uint32_t gy = L.n_channels < 65535u ? L.n_channels : 65535u;
     uint32_t gz = (L.n_channels + 65534u) / 65535u;
     dim3 g(L.tiles, gy, gz);

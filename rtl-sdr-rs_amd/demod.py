@@ -96,6 +96,15 @@ class DemodBank:
         """Enqueue on device pointers (ints).  Returns immediately."""
         check(lib().fmd_demod_demodulate_device(self._h, d_iq, nbytes, d_out, out_cap_, d_out_len, stream))
 
+    def check(self):
+        """fmd_demod_check: wait for the handle's launches, surface device assertions, settle guarded f64 samples."""
+        check(lib().fmd_demod_check(self._h))
+
+    def f64_stats(self):
+        g, p = C.c_uint64(), C.c_uint64()
+        check(lib().fmd_demod_f64_stats(self._h, C.byref(g), C.byref(p)))
+        return {"guarded": g.value, "patched": p.value}
+
     def last_out_len(self):
         lens = (C.c_size_t * self.n_channels)()
         check(lib().fmd_demod_last_out_len(self._h, lens))

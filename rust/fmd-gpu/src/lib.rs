@@ -49,8 +49,24 @@ pub struct DemodState {
     pub demod_pre_im: i32,
 }
 
+/// `fmd_synth_params`: the deterministic integer-only FM source that stands in for the absent capture.bin.
+#[repr(C)]
+#[derive(Clone, Copy, Debug, Default)]
+pub struct SynthParams {
+    pub seed: u64,
+    pub amplitude: u32,
+    pub noise: u32,
+    pub dev_q32: u32,
+    pub mod_period: u32,
+}
+
 #[repr(C)]
 pub struct fmd_demod {
+    _private: [u8; 0],
+}
+
+#[repr(C)]
+pub struct fmd_fir {
     _private: [u8; 0],
 }
 
@@ -63,6 +79,8 @@ extern "C" {
     pub fn fmd_demod_demodulate_batch(d: *mut fmd_demod, iq: *const u8, nbytes: usize, out: *mut i16, out_cap: usize, out_len: *mut usize) -> c_int;
     pub fn fmd_demod_demodulate_device(d: *mut fmd_demod, d_iq: *const c_void, nbytes: usize, d_out: *mut c_void, out_cap: usize, d_out_len: *mut c_void, stream: *mut c_void) -> c_int;
     pub fn fmd_demod_set_block_len(d: *mut fmd_demod, block_bytes: usize) -> c_int;
+    pub fn fmd_demod_check(d: *mut fmd_demod) -> c_int;
+    pub fn fmd_demod_f64_stats(d: *const fmd_demod, guarded: *mut u64, patched: *mut u64) -> c_int;
     pub fn fmd_demod_last_out_len(d: *const fmd_demod, out_len: *mut usize) -> c_int;
     pub fn fmd_host_alloc(nbytes: usize, ptr: *mut *mut c_void) -> c_int;
     pub fn fmd_host_free(ptr: *mut c_void) -> c_int;
@@ -73,6 +91,15 @@ extern "C" {
     pub fn fmd_last_error() -> *const c_char;
     pub fn fmd_device_count(count: *mut c_int) -> c_int;
     pub fn fmd_version() -> c_int;
+    pub fn fmd_demod_tiling(d: *const fmd_demod, audio_per_tile: *mut u32, lds_bytes: *mut u32, block_threads: *mut u32) -> c_int;
+    pub fn fmd_demod_set_tiling(d: *mut fmd_demod, audio_per_tile: u32) -> c_int;
+    pub fn fmd_synth_fill_device(device_id: c_int, d_iq: *mut c_void, n_channels: u32, nbytes: usize, sample_offset: u64, p: *const SynthParams, stream: *mut c_void) -> c_int;
+    pub fn fmd_fir_new(taps: *const i16, n_taps: u32, decim: u32, dev: *const DeviceConfig, out: *mut *mut fmd_fir) -> c_int;
+    pub fn fmd_fir_free(f: *mut fmd_fir);
+    pub fn fmd_fir_reset(f: *mut fmd_fir) -> c_int;
+    pub fn fmd_fir_out_cap(n_taps: u32, decim: u32, nbytes: usize) -> usize;
+    pub fn fmd_fir_filter_batch(f: *mut fmd_fir, iq: *const u8, nbytes: usize, out: *mut i32, out_cap: usize, out_len: *mut usize) -> c_int;
+    pub fn fmd_fir_filter_device(f: *mut fmd_fir, d_iq: *const c_void, nbytes: usize, d_out: *mut c_void, out_cap: usize, out_len_each: *mut usize, stream: *mut c_void) -> c_int;
 }
 
 /// Error in the crate's convention (`src/error.rs:8,40-44`: a Result, never a panic).

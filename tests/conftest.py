@@ -27,14 +27,17 @@ def fmd():
     return rtl_sdr_rs_amd
 
 
-def _has_gpu():
-    try:
-        import rtl_sdr_rs_amd
-        return rtl_sdr_rs_amd.device_count() > 0
-    except Exception:
-        return False
-
-
+@pytest.hookimpl(trylast=True)            # after -m / -k deselection: `items` is what will actually run
 def pytest_collection_modifyitems(config, items):
-    # A `-m gpu` run on a box without a GPU must fail loudly, not skip: the product has no CPU path.
-    pass
+    """A `-m gpu` run on a box without a usable GPU must fail loudly, not pass by deselection or skip: the product
+    has no CPU path, and a green GPU suite that never touched a GPU is worse than a red one."""
+    if not any(it.get_closest_marker("gpu") for it in items):
+        return
+    import rtl_sdr_rs_amd
+    try:
+        n = rtl_sdr_rs_amd.device_count()
+    except Exception as e:                                    # library not built / not loadable
+        pytest.exit("GPU tests selected but the HIP library does not load: %r" % (e,), returncode=3)
+    if n < 1:
+        pytest.exit("GPU tests selected (-m gpu) but no gfx950 device is visible: refusing to run them on nothing "
+                    "(the product has no CPU path)", returncode=3)

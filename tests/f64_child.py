@@ -1,0 +1,108 @@
+"""Child process of tests/test_gpu_f64_guard.py: the guard band / skew knobs of the library are read from the
+environment when a handle is created, and FMD_LIB selects the -DFMD_EXPERIMENT build, so each scenario runs in its
+own interpreter.  Prints one JSON line.  TEST INFRASTRUCTURE."""
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+import numpy as np
+
+import oracle_lib
+import rtl_sdr_rs_amd as fmd
+
+
+def mkcfg(D, fast, slow):
+    return fmd.DemodConfig(fast, fast, slow, D, max(1, (1 << 15) // (128 * D)))
+
+
+def probe_states(n, seed):
+    """(demod_pre, lp_now) pairs: the 8 exact directions at several magnitudes + random ones."""
+    rng = np.random.default_rng(seed)
+    pres, lps = [], []
+    for v in [(1, 0), (0, 1), (-1, 0), (0, -1), (1, 1), (-1, 1), (1, -1), (-1, -1)]:
+        for s in (1, 3, 100, 383):
+            pres.append((1, 0)); lps.append((v[0] * s, v[1] * s))
+            pres.append((v[0] * s, v[1] * s)); lps.append((v[0] * s, v[1] * s))
+    while len(pres) < n:
+        pres.append(tuple(int(x) for x in rng.integers(-512, 513, 2)))
+        lps.append(tuple(int(x) for x in rng.integers(-384, 385, 2)))
+    return pres[:n], lps[:n]
+
+
+def scenario_direct(device_path):
+    """fast == slow: every discriminator sample is an audio sample, so the f64 sample is out[0] itself; injected
+    predecessors make it generic (non-special) for most channels."""
+    o = oracle_lib.load()
+    D, n = 4, 600
+    cfg, ocfg = mkcfg(D, 48000, 48000), o.config(D, 48000, 48000)
+    pres, lps = probe_states(n, 5)
+    bank, obank = fmd.DemodBank(cfg, n), o.new_bank(ocfg, n)
+    for c in range(n):
+        bank.set_state(c, fmd.DemodState(prev_index=D - 1, now_lpr=0, prev_lpr_index=0, lp_now_re=lps[c][0],
+                                         lp_now_im=lps[c][1], demod_pre_re=pres[c][0], demod_pre_im=pres[c][1]))
+        obank[c].prev_index = D - 1
+        obank[c].lp_now.re, obank[c].lp_now.im = lps[c]
+        obank[c].demod_pre.re, obank[c].demod_pre.im = pres[c]
+    rng = np.random.default_rng(6)
+    bad = 0
+    for call in range(3):
+        iq = rng.integers(0, 256, (n, 64 + 8 * call), dtype=np.uint8)
+        if call == 0:
+            iq[:, 0:2] = 127
+        exp, lens = o.demodulate_batch(obank, iq)
+        if device_path:
+            import torch
+            d_iq = torch.from_numpy(iq).cuda()
+            cap = bank.out_cap(iq.shape[1])
+            d_out = torch.zeros((n, cap), dtype=torch.int16, device="cuda")
+            bank.demodulate_device(d_iq.data_ptr(), iq.shape[1], d_out.data_ptr(), cap, None, None)
+            bank.check()                                   # settles the guarded samples in d_out
+            got = d_out.cpu().numpy()
+            got = [got[c, :lens[c]] for c in range(n)]
+        else:
+            got = bank.demodulate_batch(iq)
+        bad += sum(0 if np.array_equal(got[c], exp[c, :lens[c]]) else 1 for c in range(n))
+    st_bad = sum(0 if bank.get_state(c).as_dict() == o.state_of(obank[c]) else 1 for c in range(0, n, 37))
+    return {"bad": bad, "state_bad": st_bad, "stats": bank.f64_stats()}
+
+
+def scenario_stream(D, fast, slow, block_len):
+    """Ordinary streaming (groups of several samples, the f64 sample inside a group sum or in the carried tail),
+    optionally with several reference calls per launch (set_block_len)."""
+    o = oracle_lib.load()
+    n, N = 24, 8 * 520
+    cfg, ocfg = mkcfg(D, fast, slow), o.config(D, fast, slow)
+    bank = fmd.DemodBank(cfg, n)
+    ods = [o.new(ocfg) for _ in range(n)]
+    rng = np.random.default_rng(D)
+    bad = 0
+    for call in range(6):
+        nbytes = N if not block_len else block_len * int(rng.integers(1, 9))
+        iq = rng.integers(0, 256, (n, nbytes), dtype=np.uint8)
+        if block_len:
+            bank.set_block_len(block_len)
+        got = bank.demodulate_batch(iq)
+        for c in range(n):
+            if block_len:
+                exp = np.concatenate([o.demodulate(ods[c], iq[c, b:b + block_len]) for b in range(0, nbytes, block_len)])
+            else:
+                exp = o.demodulate(ods[c], iq[c])
+            bad += 0 if np.array_equal(got[c], exp) else 1
+    st_bad = sum(0 if bank.get_state(c).as_dict() == o.state_of(ods[c]) else 1 for c in range(n))
+    return {"bad": bad, "state_bad": st_bad, "stats": bank.f64_stats()}
+
+
+if __name__ == "__main__":
+    kind = sys.argv[1]
+    if kind == "direct":
+        res = scenario_direct(False)
+    elif kind == "direct_device":
+        res = scenario_direct(True)
+    else:
+        D, fast, slow, bl = (int(x) for x in sys.argv[2:6])
+        res = scenario_stream(D, fast, slow, bl)
+    print(json.dumps(res))

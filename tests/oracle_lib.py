@@ -87,6 +87,9 @@ class Oracle:
         lib.fmo_fir_free.restype = None
         lib.fmo_fir_filter.argtypes = [C.c_void_p, u8p, C.c_size_t, C.POINTER(Cplx), C.c_size_t]
         lib.fmo_fir_filter.restype = C.c_long
+        lib.fmo_fir_filter_batch.argtypes = [C.POINTER(C.c_void_p), u8p, C.c_size_t, C.c_size_t, C.POINTER(Cplx), C.c_size_t,
+                                             C.POINTER(C.c_uint32), C.c_int]
+        lib.fmo_fir_filter_batch.restype = C.c_int
         lib.fmcf_demodulate.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(ChanState),
                                         u8p, C.c_size_t, i16p, C.c_size_t]
         lib.fmcf_demodulate.restype = C.c_long
@@ -143,6 +146,23 @@ class Oracle:
         if n < 0:
             raise ValueError("fmo_fir_filter -> %d" % n)
         return np.array([[out[i].re, out[i].im] for i in range(n)], dtype=np.int32).reshape(-1, 2)
+
+    def fir_filter_batch(self, hs, iq, threads=0, cap=None):
+        """hs: list of fmo_fir handles (one per channel, state carried); iq [C, N] uint8 -> int32 [C, n_out, 2]."""
+        import os
+        iq = np.ascontiguousarray(iq, dtype=np.uint8)
+        nch, n = iq.shape
+        cap = cap or n // 2 + 8
+        out = np.empty((nch, cap, 2), dtype=np.int32)
+        lens = np.zeros(nch, dtype=np.uint32)
+        arr = (C.c_void_p * nch)(*hs)
+        rc = self.lib.fmo_fir_filter_batch(arr, iq.ctypes.data_as(C.POINTER(C.c_uint8)), nch, n,
+                                           out.ctypes.data_as(C.POINTER(Cplx)), cap,
+                                           lens.ctypes.data_as(C.POINTER(C.c_uint32)), threads or (os.cpu_count() or 1))
+        if rc:
+            raise ValueError("fmo_fir_filter_batch -> %d" % rc)
+        assert len(set(lens.tolist())) == 1
+        return out[:, :int(lens[0]), :]
 
     def new_bank(self, cfg, n):
         bank = (Demod * n)()

@@ -96,19 +96,39 @@ def test_gpu_fir_matches_oracle(fmd, oracle, monkeypatch, form, T, M):
 
 
 @pytest.mark.gpu
-def test_gpu_fir_config4_shape(fmd, oracle):
-    """BASELINE configs[3] shape: 127 taps, decimate by 8, 2 MiB per channel-call (52.4 ms at 20 Msps); 8 of the
-    256 channels here, compared exactly."""
+def test_gpu_fir_config4_full_size(fmd, oracle):
+    """BASELINE configs[3] at its stated size: 127 taps, decimate by 8, 256 channels x 2 MiB per call (52.4 ms at
+    20 Msps), two consecutive calls (history carry), EVERY channel compared -- this is the launch the config-4 bench
+    number comes from, incl. its XCD-aware grid (8, tiles, 32) and the c = blockIdx.x * gridDim.z + blockIdx.z map."""
     rng = np.random.default_rng(4)
     taps = rng.integers(-2047, 2048, 127).astype(np.int16)
-    nch, n = 8, 2 << 20
+    nch, n = 256, 2 << 20
     bank = fmd.FirBank(taps, 8, nch)
-    iq = fmd.synth.synth_iq(nch, n)
-    got = bank.filter_batch(iq)
-    h = oracle.fir_new(taps, 8)
-    exp = oracle.fir_filter(h, iq[3])
-    oracle.lib.fmo_fir_free(h)
-    assert np.array_equal(got[3], exp)
+    hs = [oracle.fir_new(taps, 8) for _ in range(nch)]
+    for call in range(2):
+        iq = fmd.synth.synth_iq(nch, n, sample_offset=call * (n // 2), amplitude=110)
+        if call == 1:
+            iq[5::17, ::2] = 255; iq[5::17, 1::2] = 0              # some full-scale channels
+        got = bank.filter_batch(iq)
+        exp = oracle.fir_filter_batch(hs, iq, cap=n // 16 + 8)
+        assert got.shape == exp.shape and got.shape[1] in (131057, 131072)
+        bad = [c for c in range(nch) if not np.array_equal(got[c], exp[c])]
+        assert not bad, (call, bad[:8])
+    for h in hs:
+        oracle.lib.fmo_fir_free(h)
+
+
+def test_oracle_fir_batch_equals_single(oracle):
+    rng = np.random.default_rng(12)
+    taps = rng.integers(-2047, 2048, 33).astype(np.int16)
+    hs, hs1 = [oracle.fir_new(taps, 4) for _ in range(5)], [oracle.fir_new(taps, 4) for _ in range(5)]
+    for _ in range(3):
+        iq = rng.integers(0, 256, (5, 8 * int(rng.integers(20, 200))), dtype=np.uint8)
+        got = oracle.fir_filter_batch(hs, iq, threads=3)
+        for c in range(5):
+            assert np.array_equal(got[c], oracle.fir_filter(hs1[c], iq[c]))
+    for h in hs + hs1:
+        oracle.lib.fmo_fir_free(h)
 
 
 @pytest.mark.gpu

@@ -1,0 +1,142 @@
+"""GPU tests of the boundary's behaviour around the kernel: completion / verification point (fmd_demod_check),
+launch ordering when a handle is driven from different streams, several handles in one process (the in-process
+multi-GPU shape: one handle + stream per device, examples/simple_fm.rs:137 -- one Demod per stream), and that
+every entry point leaves the caller's current HIP device alone."""
+import ctypes as C
+import re
+
+import numpy as np
+import pytest
+
+from test_gpu_parity import CFG_24, CFG_REF, mkcfg
+
+pytestmark = pytest.mark.gpu
+
+
+def hip_runtime():
+    """The HIP runtime this process already uses (torch's copy; same file -> same handle)."""
+    for line in open("/proc/self/maps"):
+        m = re.search(r"(/\S*libamdhip64\.so\S*)", line)
+        if m:
+            return C.CDLL(m.group(1))
+    raise RuntimeError("libamdhip64 not loaded")
+
+
+def current_device(hip):
+    d = C.c_int(-1)
+    assert hip.hipGetDevice(C.byref(d)) == 0
+    return d.value
+
+
+def test_check_after_device_entry(fmd, oracle):
+    import torch
+    nch, N = 17, 65536
+    bank = fmd.DemodBank(mkcfg(fmd, *CFG_REF), nch)
+    obank = oracle.new_bank(oracle.config(*CFG_REF), nch)
+    cap = bank.out_cap(N)
+    d_out = torch.zeros((nch, cap), dtype=torch.int16, device="cuda")
+    for call in range(3):
+        iq = fmd.synth.synth_iq(nch, N, sample_offset=call * (N // 2))
+        d_iq = torch.from_numpy(iq).cuda()
+        bank.demodulate_device(d_iq.data_ptr(), N, d_out.data_ptr(), cap, None, None)
+        bank.check()                                        # the completion point of the device entry
+        exp, lens = oracle.demodulate_batch(obank, iq)
+        got = d_out.cpu().numpy()
+        assert np.array_equal(bank.last_out_len(), lens)
+        for c in range(nch):
+            assert np.array_equal(got[c, :lens[c]], exp[c, :lens[c]])
+    assert bank.f64_stats()["patched"] == 0
+
+
+def test_alternating_streams_and_entry_points(fmd, oracle):
+    """Consecutive launches of one handle on stream A, stream B and the handle's own stream (host entry) without any
+    synchronisation by the caller: the state ping-pong must still see launch n before launch n+1."""
+    import torch
+    nch, N = 64, 262144
+    bank = fmd.DemodBank(mkcfg(fmd, *CFG_24), nch)
+    obank = oracle.new_bank(oracle.config(*CFG_24), nch)
+    cap = bank.out_cap(N)
+    sa, sb = torch.cuda.Stream(), torch.cuda.Stream()
+    blocks = [fmd.synth.synth_iq(nch, N, sample_offset=i * (N // 2), amplitude=90) for i in range(9)]
+    d_blocks = [torch.from_numpy(b).cuda() for b in blocks]
+    d_outs = [torch.zeros((nch, cap), dtype=torch.int16, device="cuda") for _ in blocks]
+    torch.cuda.synchronize()
+    host_results = {}
+    for i in range(9):
+        if i % 3 == 2:
+            host_results[i] = bank.demodulate_batch(blocks[i])           # the handle's private stream
+        else:
+            s = sa if i % 3 == 0 else sb
+            bank.demodulate_device(d_blocks[i].data_ptr(), N, d_outs[i].data_ptr(), cap, None, s.cuda_stream)
+    bank.check()
+    for i in range(9):
+        exp, lens = oracle.demodulate_batch(obank, blocks[i])
+        got = host_results[i] if i in host_results else [d_outs[i][c, :lens[c]].cpu().numpy() for c in range(nch)]
+        for c in range(nch):
+            assert np.array_equal(got[c], exp[c, :lens[c]]), (i, c)
+    assert bank.get_state(nch - 1).as_dict() == oracle.state_of(obank[nch - 1])
+
+
+def test_two_handles_two_streams_interleaved(fmd, oracle):
+    """Two banks in one process, each with its own stream (on two GPUs where the box has them, else both on
+    device 0), launches interleaved: the shape of an in-process multi-GPU driver.  Also: the caller's current
+    device is the same before and after every call."""
+    import torch
+    hip = hip_runtime()
+    ndev = fmd.device_count()
+    devs = [0, 1 % ndev]
+    torch.cuda.set_device(0)
+    before = current_device(hip)
+    nch, N = 40, 131072
+    banks, obanks, streams, outs = [], [], [], []
+    for k, dv in enumerate(devs):
+        banks.append(fmd.DemodBank(mkcfg(fmd, *CFG_REF), nch, device_id=dv))
+        obanks.append(oracle.new_bank(oracle.config(*CFG_REF), nch))
+        with torch.cuda.device(dv):
+            streams.append(torch.cuda.Stream(device=dv))
+            outs.append(torch.zeros((nch, banks[k].out_cap(N)), dtype=torch.int16, device="cuda:%d" % dv))
+    assert current_device(hip) == before
+    cap = banks[0].out_cap(N)
+    for call in range(4):
+        iqs = [fmd.synth.synth_iq(nch, N, sample_offset=call * (N // 2), first_channel=100 * k) for k in range(2)]
+        d_iqs = [torch.from_numpy(iqs[k]).to("cuda:%d" % devs[k]) for k in range(2)]
+        torch.cuda.synchronize()
+        for k in range(2):
+            banks[k].demodulate_device(d_iqs[k].data_ptr(), N, outs[k].data_ptr(), cap, None, streams[k].cuda_stream)
+            assert current_device(hip) == before
+        for k in range(2):
+            banks[k].check()
+            assert current_device(hip) == before
+            exp, lens = oracle.demodulate_batch(obanks[k], iqs[k])
+            got = outs[k].cpu().numpy()
+            for c in range(nch):
+                assert np.array_equal(got[c, :lens[c]], exp[c, :lens[c]]), (call, k, c)
+    for k in range(2):
+        assert banks[k].get_state(7).as_dict() == oracle.state_of(obanks[k][7])
+        banks[k].close()
+    assert current_device(hip) == before
+
+
+def test_fir_alternating_streams(fmd, oracle):
+    import torch
+    rng = np.random.default_rng(9)
+    taps = rng.integers(-2047, 2048, 127).astype(np.int16)
+    nch, N = 8, 65536
+    fir = fmd.FirBank(taps, 8, nch)
+    hs = [oracle.fir_new(taps, 8) for _ in range(nch)]
+    cap = fir.out_cap(N)
+    sa, sb = torch.cuda.Stream(), torch.cuda.Stream()
+    blocks = [rng.integers(0, 256, (nch, N), dtype=np.uint8) for _ in range(6)]
+    d_blocks = [torch.from_numpy(b).cuda() for b in blocks]
+    d_outs = [torch.zeros((nch, cap, 2), dtype=torch.int32, device="cuda") for _ in blocks]
+    torch.cuda.synchronize()
+    ns = [fir.filter_device(d_blocks[i].data_ptr(), N, d_outs[i].data_ptr(), cap, (sa if i % 2 == 0 else sb).cuda_stream)
+          for i in range(6)]
+    torch.cuda.synchronize()
+    for i in range(6):
+        got = d_outs[i].cpu().numpy()
+        for c in range(nch):
+            exp = oracle.fir_filter(hs[c], blocks[i][c])
+            assert ns[i] == exp.shape[0] and np.array_equal(got[c, :ns[i]], exp), (i, c)
+    for h in hs:
+        oracle.lib.fmo_fir_free(h)

@@ -1,0 +1,62 @@
+"""The one f64 sample of every reference call (Demod::polar_discriminant, simple_fm.rs:359,370-374) must not
+depend on the last bits of the GPU's atan2: exact directions are decided with integers, every other sample within
+the guard band of an integer is re-evaluated by the host libm and patched (include/fmd.h, fmd_demod_check).
+Here the guard band is widened until EVERY generic sample takes that path (FMD_F64_GUARD_LOG2=-1: half-width 0.5),
+and the -DFMD_EXPERIMENT build additionally makes the kernel's own value wrong on purpose (FMD_F64_SKEW) so that
+the results can only be right if the host patch works -- in the audio sample, in the carried partial sum, through
+the host and the device entry points, and with several reference calls per launch."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+EXP = os.path.join(ROOT, "rtl-sdr-rs_amd", "libfmd_hip_exp.so")
+
+
+def run_child(args, guard_log2=None, skew=None):
+    env = dict(os.environ, PYTHONPATH=ROOT)
+    if guard_log2 is not None:
+        env["FMD_F64_GUARD_LOG2"] = str(guard_log2)
+    if skew is not None:
+        assert os.path.exists(EXP), "build() makes libfmd_hip_exp.so (make -C rtl-sdr-rs_amd/csrc exp)"
+        env["FMD_LIB"] = EXP
+        env["FMD_F64_SKEW"] = str(skew)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "f64_child.py")] + [str(a) for a in args],
+                       capture_output=True, env=env, timeout=600)
+    assert p.returncode == 0, p.stderr.decode()[-3000:]
+    return json.loads(p.stdout.decode().strip().splitlines()[-1])
+
+
+def test_default_guard_band_is_quiet():
+    r = run_child(["direct"])
+    assert r["bad"] == 0 and r["state_bad"] == 0
+    assert r["stats"]["guarded"] == 0 and r["stats"]["patched"] == 0     # 2^-20: nothing among 600 random samples
+
+
+@pytest.mark.parametrize("kind", ["direct", "direct_device"])
+def test_every_generic_sample_guarded_values_agree(kind):
+    r = run_child([kind], guard_log2=-1)
+    assert r["bad"] == 0 and r["state_bad"] == 0
+    assert r["stats"]["guarded"] > 500 and r["stats"]["patched"] == 0    # ocml == libm after truncation: no patch needed
+
+
+@pytest.mark.parametrize("kind", ["direct", "direct_device"])
+def test_patch_repairs_a_wrong_gpu_value(kind):
+    r = run_child([kind], guard_log2=-1, skew=3)
+    assert r["bad"] == 0 and r["state_bad"] == 0
+    assert r["stats"]["guarded"] > 500 and r["stats"]["patched"] == r["stats"]["guarded"]
+
+
+@pytest.mark.parametrize("D,fast,slow,block_len", [(6, 170000, 32000, 0), (10, 240000, 32000, 0), (3, 48000, 44100, 0),
+                                                   (6, 170000, 32000, 8 * 40), (10, 240000, 32000, 8 * 25),
+                                                   (2, 500000, 8000, 0)])
+def test_patch_inside_group_sums_and_carried_tail(D, fast, slow, block_len):
+    """Groups of several discriminator samples: the patched value enters sum / R; (2, 500000, 8000): 62-sample
+    groups, so the f64 sample of most calls lies in the carried partial sum (now_lpr) -> the state patch."""
+    r = run_child(["stream", D, fast, slow, block_len], guard_log2=-1, skew=5)
+    assert r["bad"] == 0 and r["state_bad"] == 0
+    assert r["stats"]["guarded"] > 0 and r["stats"]["patched"] == r["stats"]["guarded"]

@@ -179,7 +179,8 @@ def test_state_checkpoint_resume(fmd, oracle):
     g2.set_state(1, st)
     got = g2.demodulate_batch(np.stack([b, b, b]))
     assert np.array_equal(got[1], exp_b)
-    assert not np.array_equal(got[0], exp_b) or True     # channel 0 started from zero state
+    exp0 = oracle.demodulate(oracle.new(oracle.config(D, fast, slow)), b)   # channel 0 started from the zero state
+    assert np.array_equal(got[0], exp0) and np.array_equal(got[2], exp0)
     assert g2.get_state(1).as_dict() == oracle.state_of(od)
     bad = fmd.DemodState(prev_index=D)                   # unreachable phase
     with pytest.raises(fmd.FmdError) as ei:

@@ -1,6 +1,7 @@
 """GPU parity of the non-default kernel variants (same results by construction, selected by environment at
-Demod creation): the register-streaming kernel (FMD_STREAM=1), the persistent tile kernel (FMD_PERSIST=1),
-64/128-thread tile blocks (FMD_NT)."""
+Demod creation): 64/128-thread tile blocks (FMD_NT), the plain and index-arithmetic block mappings (FMD_XCD),
+the generic fallback kernel (FMD_FORCE_GENERIC).  The register-streaming and persistent kernels of round 1
+(measured slower) were removed in round 2."""
 import numpy as np
 import pytest
 
@@ -21,17 +22,11 @@ def blocks_for(fmd, nch, ncalls, seed, n=None):
     return out
 
 
-@pytest.mark.parametrize("env", [{"FMD_STREAM": "1"}, {"FMD_STREAM": "1", "FMD_RPW": "9"},
-                                 {"FMD_PERSIST": "1"}, {"FMD_NT": "128"}, {"FMD_NT": "64"}])
+@pytest.mark.parametrize("env", [{"FMD_NT": "128"}, {"FMD_NT": "64"}, {"FMD_XCD": "0"}, {"FMD_XCD": "1"},
+                                 {"FMD_FORCE_GENERIC": "1"}])
 @pytest.mark.parametrize("cfg", [CFG_24, CFG_REF, (4, 300000, 50000), (16, 62500, 31250)])
 def test_kernel_variants_bit_exact(fmd, oracle, monkeypatch, env, cfg):
     for k, v in env.items():
         monkeypatch.setenv(k, v)
     check_stream(fmd, oracle, *cfg, blocks_for(fmd, 7, 3, seed=cfg[0]), n_channels=7)
     check_stream(fmd, oracle, *cfg, blocks_for(fmd, 3, 3, seed=cfg[0] + 1, n=8 * 517), n_channels=3)   # ragged small calls
-
-
-def test_stream_kernel_large_single_channel(fmd, oracle, monkeypatch):
-    monkeypatch.setenv("FMD_STREAM", "1")
-    rng = np.random.default_rng(11)
-    check_stream(fmd, oracle, *CFG_24, [rng.integers(0, 256, (1, 4 << 20), dtype=np.uint8)])
