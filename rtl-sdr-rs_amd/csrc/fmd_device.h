@@ -63,28 +63,45 @@ static __device__ __noinline__ int polar_f64(int cr, int ci, double guard, bool*
 
 // Append the record of one guarded sample (one lane, after the tile's d16[] is complete: d16[j - jfirst] holds
 // discriminator sample j for every j of the audio groups this tile owns).  (i0r, K): resampler phase / audio
-// count of this channel-call.
-static __device__ __noinline__ void exc_emit(const FmdLaunch& L, uint32_t c, uint32_t i0r, uint32_t K, int now_lpr_in,
-                                            const int16_t* d16, int jfirst, int j, int cr, int ci)
+// count of this channel-call.  Everything travels BY VALUE: a noinline callee that took the launch descriptor by
+// reference would force the whole kernel-argument block into scratch memory on every lane (measured: 15x slower).
+struct FmdExcArgs {
+    uint32_t sr, fr, i0r, K, c, seq;
+    int now_lpr_in, jfirst;
+    const int16_t* d16;
+    int16_t* out_c;          // &out[c][0]
+    FmdExcBuf* exc;
+};
+
+static __device__ __noinline__ void exc_emit(FmdExcArgs a, int j, int cr, int ci)
 {
-    const FmdRates& r = L.r;
     FmdF64Exc e{};
-    e.channel = c; e.cr = cr; e.ci = ci;
-    e.d_gpu = d16[j - jfirst];
-    e.seq = L.seq;
-    const uint32_t k = ((uint32_t)j * r.sr + i0r) / r.fr;            // the audio sample whose group contains j
-    if (k < K) {
-        const int hi = (int)fmd_audio_end(r, i0r, k), lo = k == 0 ? 0 : (int)fmd_audio_end(r, i0r, k - 1) + 1;
-        int sum = k == 0 ? now_lpr_in : 0;
-        for (int jj = lo; jj <= hi; ++jj) sum += d16[jj - jfirst];
+    e.channel = a.c; e.cr = cr; e.ci = ci;
+    e.d_gpu = a.d16[j - a.jfirst];
+    e.seq = a.seq;
+    const uint32_t k = ((uint32_t)j * a.sr + a.i0r) / a.fr;          // the audio sample whose group contains j
+    if (k < a.K) {                                                    // e(k) = ((k + 1) * fr - i0r - 1) / sr (fmd_audio_end)
+        const int hi = (int)(((k + 1) * a.fr - a.i0r - 1) / a.sr), lo = k == 0 ? 0 : (int)((k * a.fr - a.i0r - 1) / a.sr) + 1;
+        int sum = k == 0 ? a.now_lpr_in : 0;
+        for (int jj = lo; jj <= hi; ++jj) sum += a.d16[jj - a.jfirst];
         e.k = (int)k; e.sum = sum;
-        e.out_elem = (uint64_t)(uintptr_t)(L.out + (uint64_t)c * L.out_stride + k);
+        e.out_elem = (uint64_t)(uintptr_t)(a.out_c + k);
     } else {
         e.k = -1;                                                     // lies in the partial group carried in now_lpr
     }
-    atomicAdd(&L.exc->guarded_total, 1u);
-    const uint32_t slot = atomicAdd(&L.exc->count, 1u);
-    if (slot < FMD_EXC_CAP) L.exc->rec[slot] = e; else atomicOr(L.err, FMD_DEVERR_EXC_CAP);
+    atomicAdd(&a.exc->guarded_total, 1u);
+    const uint32_t slot = atomicAdd(&a.exc->count, 1u);
+    if (slot < FMD_EXC_CAP) a.exc->rec[slot] = e; else atomicOr(&a.exc->err, FMD_DEVERR_EXC_CAP);
+}
+
+__device__ __forceinline__ FmdExcArgs exc_args(const FmdLaunch& L, uint32_t c, uint32_t i0r, uint32_t K, int now_lpr_in,
+                                               const int16_t* d16, int jfirst)
+{
+    FmdExcArgs a;
+    a.sr = L.r.sr; a.fr = L.r.fr; a.i0r = i0r; a.K = K; a.c = c; a.seq = L.seq;
+    a.now_lpr_in = now_lpr_in; a.jfirst = jfirst; a.d16 = d16;
+    a.out_c = L.out + (uint64_t)c * L.out_stride; a.exc = L.exc;
+    return a;
 }
 
 // Decimated samples travel packed: re in the low, im in the high 16 bits (|lp| <= 128 * D <= 16384).

@@ -110,7 +110,7 @@ __global__ void __launch_bounds__(FMD_BLOCK_THREADS) fmd_demod_generic_kernel(co
         fmd_mul_conj(lp_re(a), lp_im(a), lp_re(b), lp_im(b), cr, ci);
         bool g;
         (void)polar_f64(cr, ci, L.f64_guard, &g);
-        if (g) exc_emit(L, c, i0r, K, st.now_lpr, d16, jfirst, 0, cr, ci);
+        if (g) exc_emit(exc_args(L, c, i0r, K, st.now_lpr, d16, jfirst), 0, cr, ci);
     }
 
     // ---- Demod state after the call (last tile only; :232-239) --------------------------------

@@ -46,7 +46,32 @@ struct FmdExcBuf {
     FmdF64Exc rec[FMD_EXC_CAP];
 };
 
+// Fast tile geometry.  When a bank is one phase class and the tile length is a multiple of the reduced resample
+// rate (kt * fr % sr == 0: true for the reference's rates and for the 2.4 Msps configuration), tile t of every
+// channel is tile 0 shifted by t * Qt decimated samples, so where a tile's bytes are is a multiply-add of host
+// constants.  They sit in the FIRST 64 bytes of the kernel arguments: a fresh block fetches them with one scalar
+// load and issues its LDS-DMAs a few dozen scalar instructions later (the general prologue walks through a dozen
+// dependent scalar loads first; a block holds its LDS the whole time).
+struct FmdFastGeo {
+    uint64_t iq;              // device address of the input
+    uint64_t iq_end;          // iq + n_channels * chan_stride
+    uint64_t chan_stride;     // bytes
+    uint32_t n_channels;
+    uint32_t per;             // ceil(n_channels / 8): gridDim.z of the XCD-aware grid (8, tiles, per)
+    uint32_t nt;              // tiles per channel
+    uint32_t step2;           // 2 * D * Qt: input bytes from one tile to the next
+    int32_t  lo_off2;         // first byte of tile t = max(0, t * step2 + lo_off2)
+    int32_t  hi_off2;         // end byte of tile t   = t * step2 + hi_off2 (the last tile ends at ns2)
+    uint32_t ns2;             // bytes per channel-call
+    uint32_t Qt;              // decimated samples per tile step
+    int32_t  jA_off, jB_off;  // jA = max(0, t * Qt + jA_off); jB = t * Qt + jB_off (last tile: M - 1)
+};
+static_assert(sizeof(FmdFastGeo) == 64, "one s_load_dwordx16");
+
 struct FmdLaunch {
+    FmdFastGeo fg;            // valid when `fast` (must stay the first member)
+    uint32_t fast;            // 1: fmd_demod_tile_kernel<.., true> with the geometry above
+    uint32_t pad0;
     const uint8_t* iq;        // [n_channels][chan_stride] interleaved u8 IQ, 16-byte aligned base
     uint64_t chan_stride;     // bytes per channel (= nbytes of the call)
     uint64_t total_bytes;     // n_channels * chan_stride

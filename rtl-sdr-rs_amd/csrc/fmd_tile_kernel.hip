@@ -26,6 +26,8 @@
 #include "fmd_device.h"
 #include "fmd_kernels.h"
 
+#include <cstdlib>
+
 namespace {
 
 using namespace fmd_dev;
@@ -216,9 +218,10 @@ __device__ __forceinline__ void stage_slow(const FmdLaunch& L, const TileCtx& X,
 
 // Rare path (one lane): walk the tile's f64 samples again -- the call-start sample and, in block_len mode, every
 // reference-call boundary inside the tile -- and append a record for each guarded one.  Recomputing the products
-// here keeps the common path free of bookkeeping (no LDS list, no live registers).
-static __device__ __noinline__ void tile_exc_flush(const FmdLaunch& L, const TileCtx& X, const FmdChanState& st,
-                                                  const uint32_t* raw_w, const int16_t* d16)
+// here keeps the common path free of bookkeeping (no LDS list, no live registers).  Inlined on purpose (it reads the
+// launch descriptor, which must stay in SGPRs); only polar_f64 and exc_emit, which take plain values, are calls.
+__device__ __forceinline__ void tile_exc_flush(const FmdLaunch& L, const TileCtx& X, const FmdChanState& st,
+                                               const uint32_t* raw_w, const int16_t* d16)
 {
     const FmdRates& r = L.r;
     const FmdClassPlan& P = L.cls[X.cls];
@@ -232,7 +235,7 @@ static __device__ __noinline__ void tile_exc_flush(const FmdLaunch& L, const Til
         r0 += st.lp_now_re; i0 += st.lp_now_im;
         fmd_mul_conj(r0, i0, st.demod_pre_re, st.demod_pre_im, cr, ci);
         (void)polar_f64(cr, ci, L.f64_guard, &g);
-        if (g) exc_emit(L, X.c, P.i0r, P.K, st.now_lpr, d16, jfirst, 0, cr, ci);
+        if (g) exc_emit(exc_args(L, X.c, P.i0r, P.K, st.now_lpr, d16, jfirst), 0, cr, ci);
     }
     if (L.block_ns) {
         const uint32_t D = r.D, nb = L.block_ns;
@@ -249,7 +252,7 @@ static __device__ __noinline__ void tile_exc_flush(const FmdLaunch& L, const Til
             if (j - 1 == 0) { br += st.lp_now_re; bi += st.lp_now_im; }
             fmd_mul_conj(ar, ai, br, bi, cr, ci);
             (void)polar_f64(cr, ci, L.f64_guard, &g);
-            if (g) exc_emit(L, X.c, P.i0r, P.K, st.now_lpr, d16, jfirst, j, cr, ci);
+            if (g) exc_emit(exc_args(L, X.c, P.i0r, P.K, st.now_lpr, d16, jfirst), j, cr, ci);
         }
     }
 }
@@ -537,15 +540,101 @@ __device__ __forceinline__ bool tile_fits(const FmdLaunch& L, const TileCtx& X, 
     return true;
 }
 
+// Fast geometry (FmdFastGeo, fmd_kernels.h): where the tile's bytes are, from the first 64 bytes of the kernel
+// arguments alone -- everything a fresh block needs before its DMAs can go out.
+struct FastAddr {
+    uint32_t c, t;
+    uint32_t lo2, hi2;       // byte range [lo2, hi2) of the channel-call the tile reads
+    uint64_t gbase, a0;
+    uint32_t nchunks;
+    bool whole;
+};
+
+__device__ __forceinline__ FastAddr fast_addr(const FmdFastGeo& g)
+{
+    FastAddr A;
+    A.c = blockIdx.x * g.per + blockIdx.z;                   // grid (8, tiles, per): blockIdx.x is the XCD
+    A.t = blockIdx.y;
+    const int32_t base = (int32_t)(A.t * g.step2);
+    const int32_t lo = base + g.lo_off2, hi = base + g.hi_off2;
+    A.lo2 = (uint32_t)(lo > 0 ? lo : 0);
+    A.hi2 = A.t + 1u == g.nt ? g.ns2 : (uint32_t)hi;
+    A.gbase = g.iq + (uint64_t)A.c * g.chan_stride;
+    A.a0 = (A.gbase + A.lo2) & ~15ull;
+    A.nchunks = (uint32_t)((A.gbase + A.hi2 - A.a0 + 15) >> 4);
+    A.whole = A.a0 + 16ull * A.nchunks <= g.iq_end;
+    return A;
+}
+
+// The rest of the tile context, computed while the DMAs are in flight.
+__device__ __forceinline__ TileCtx fast_ctx(const FmdLaunch& L, const FastAddr& A)
+{
+    const FmdFastGeo& g = L.fg;
+    const FmdClassPlan& P = L.cls[0];
+    TileCtx X;
+    X.c = A.c; X.cls = 0u; X.valid = true; X.whole = A.whole;
+    X.a0 = A.a0; X.nchunks = A.nchunks;
+    X.wofs = (int)((int64_t)(A.gbase - A.a0) >> 2);
+    FmdTile& T = X.T;
+    const uint32_t t = A.t;
+    T.last = t + 1u == g.nt;
+    T.k0 = t * L.r.kt;
+    T.k1 = T.k0 + L.r.kt < P.K ? T.k0 + L.r.kt : P.K;
+    T.eq = t * g.Qt + P.eq0;
+    T.er = P.er0;
+    const int32_t ja = (int32_t)(t * g.Qt) + g.jA_off;
+    T.jA = ja > 0 ? ja : 0;
+    T.jB = T.last ? (int32_t)P.M - 1 : (int32_t)(t * g.Qt) + g.jB_off;
+    T.nLo = (int32_t)(A.lo2 >> 1); T.nHi = (int32_t)(A.hi2 >> 1);
+    X.jfirst = T.jA - 1;
+    X.cnt = T.jB - X.jfirst + 1;
+    return X;
+}
+
+template <int NT>
+__device__ __forceinline__ void issue_dma(uint64_t a0, uint32_t nchunks, unsigned char* smem, uint32_t tid)
+{
+    // global_load_lds_dwordx4: 1 KiB per wave-instruction straight into the tile image, destination =
+    // wave-uniform base (M0) + lane * 16; no VGPR round trip, no ds_write pass, one wait for all.
+    const unsigned char* src = reinterpret_cast<const unsigned char*>((uintptr_t)a0) + 16u * tid;
+    unsigned char* dst = smem + 1024u * (tid >> 6);
+    const uint32_t nfull = nchunks / NT, ntail = nchunks - nfull * NT;
+    for (uint32_t l = 0; l < nfull; ++l) lds_dma16(src + (16u * NT) * l, dst + (16u * NT) * l);
+    if (tid < ntail) lds_dma16(src + (16u * NT) * nfull, dst + (16u * NT) * nfull);
+}
+
 // ---- one block per tile, LDS-DMA staging ------------------------------------------------------------
-template <int DH, int NT>
+template <int DH, int NT, bool FAST>
 __global__ void __launch_bounds__(NT) fmd_demod_tile_kernel(const FmdLaunch L)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const uint32_t tid = threadIdx.x, wave = tid >> 6;
+    const uint32_t tid = threadIdx.x;
     // A freshly dispatched block's only job is to get its loads out: let it win issue arbitration against the
     // computing waves of the other resident blocks until the DMAs are queued (measured -1.8 % launch time).
     __builtin_amdgcn_s_setprio(3);
+    if constexpr (FAST) {
+        // One phase class, tiles that repeat exactly (kt * fr % sr == 0), XCD-aware grid (8, tiles, ceil(C / 8)):
+        // the byte range of the tile is a multiply-add of the first 64 bytes of the kernel arguments.  The host has
+        // checked the LDS sizing of every tile of this launch (fmd_fast_geometry), so there is nothing to assert.
+        const FastAddr A = fast_addr(L.fg);
+        if (A.c >= L.fg.n_channels) return;
+        if (FMD_ABLATE(4)) {
+        } else if (A.whole) {
+            issue_dma<NT>(A.a0, A.nchunks, smem, tid);
+        }
+        const TileCtx X = fast_ctx(L, A);                    // scalar work under the load latency
+        if (!A.whole && !FMD_ABLATE(4)) stage_slow<NT>(L, X, smem, tid);
+        if (FMD_ABLATE(3)) {                                 // ablation: staging skeleton only
+            __syncthreads();
+            if (tid == 0) L.out[(uint64_t)X.c * L.out_stride + X.T.k0] = (int16_t)reinterpret_cast<uint32_t*>(smem)[blockIdx.y & 63u];
+            return;
+        }
+        __builtin_amdgcn_s_waitcnt(0x0F70);
+        __syncthreads();
+        __builtin_amdgcn_s_setprio(0);
+        tile_body<DH, NT>(L, X, smem);
+        return;
+    }
     uint32_t c = blockIdx.z * 65535u + blockIdx.y, tix = blockIdx.x;
     // XCD-aware block -> (channel, tile) mapping.  Workgroups go to the 8 XCDs (each with its own L2) round-robin
     // in dispatch order, so with the plain mapping the 15 tiles of one channel's 256 KiB are spread over all XCDs.
@@ -565,13 +654,7 @@ __global__ void __launch_bounds__(NT) fmd_demod_tile_kernel(const FmdLaunch L)
     if (!X.valid || !tile_fits(L, X, tid)) return;
     if (FMD_ABLATE(4)) {                                     // ablation: no loads at all (compute on LDS garbage)
     } else if (X.whole) {
-        // global_load_lds_dwordx4: 1 KiB per wave-instruction straight into the tile image, destination =
-        // wave-uniform base (M0) + lane * 16; no VGPR round trip, no ds_write pass, one wait for all.
-        const unsigned char* src = reinterpret_cast<const unsigned char*>((uintptr_t)X.a0) + 16u * tid;
-        unsigned char* dst = smem + 1024u * wave;
-        const uint32_t nfull = X.nchunks / NT, ntail = X.nchunks - nfull * NT;
-        for (uint32_t l = 0; l < nfull; ++l) lds_dma16(src + (16u * NT) * l, dst + (16u * NT) * l);
-        if (tid < ntail) lds_dma16(src + (16u * NT) * nfull, dst + (16u * NT) * nfull);
+        issue_dma<NT>(X.a0, X.nchunks, smem, tid);
     } else {
         stage_slow<NT>(L, X, smem, tid);
     }
@@ -594,9 +677,12 @@ template <int DH>
 void launch_one(const FmdLaunch& L, dim3 g, size_t lds, hipStream_t stream)
 {
     switch (L.block_threads) {
-        case 128: hipLaunchKernelGGL((fmd_demod_tile_kernel<DH, 128>), g, dim3(128), lds, stream, L); break;
-        case 64: hipLaunchKernelGGL((fmd_demod_tile_kernel<DH, 64>), g, dim3(64), lds, stream, L); break;
-        default:  hipLaunchKernelGGL((fmd_demod_tile_kernel<DH, 256>), g, dim3(256), lds, stream, L); break;
+        case 128: hipLaunchKernelGGL((fmd_demod_tile_kernel<DH, 128, false>), g, dim3(128), lds, stream, L); break;
+        case 64: hipLaunchKernelGGL((fmd_demod_tile_kernel<DH, 64, false>), g, dim3(64), lds, stream, L); break;
+        default:
+            if (L.fast) hipLaunchKernelGGL((fmd_demod_tile_kernel<DH, 256, true>), g, dim3(256), lds, stream, L);
+            else hipLaunchKernelGGL((fmd_demod_tile_kernel<DH, 256, false>), g, dim3(256), lds, stream, L);
+            break;
     }
 }
 
@@ -619,6 +705,37 @@ bool fmd_tile_kernel_supports(const FmdRates& r, uint32_t raw_cap)
     return true;
 }
 
+// Fills L.fg when the launch qualifies for the fast prologue: one phase class, tiles that repeat exactly, 256-thread
+// blocks, and every tile of the launch within the LDS sizing (checked here, once, instead of by every block).
+static bool fmd_fast_geometry(FmdLaunch& L, uint32_t per)
+{
+    if (!L.fast || L.chan_class || L.tl.Rt != 0u || L.block_threads != 256u) return false;   // L.fast: allowed (FMD_FAST != 0)
+    const FmdRates& r = L.r;
+    const FmdClassPlan& P = L.cls[0];
+    if (P.nt != L.tiles || P.nt == 0u) return false;
+    const FmdTiling& tl = L.tl;
+    const int64_t jA_off = (int64_t)P.eq0 - tl.fq + (P.er0 >= tl.frr ? 1 : 0);
+    const int64_t jB_off = (int64_t)P.eq0 + tl.Bq + (P.er0 + tl.Br >= r.sr ? 1 : 0);
+    const int64_t lo_off2 = 2 * ((int64_t)r.D * (jA_off - 1) - P.p0), hi_off2 = 2 * ((int64_t)r.D * (jB_off + 1) - P.p0);
+    const uint64_t step2 = 2ull * r.D * tl.Qt, ns2 = 2ull * L.ns;
+    if (jA_off > 0 || step2 * P.nt + (uint64_t)(hi_off2 > 0 ? hi_off2 : 0) >= (1ull << 31) || ns2 >= (1ull << 31)) return false;
+    // every tile: the same expressions as fmd_tile_fast (tests/test_plan_and_divides.py proves that one), plus the LDS sizing
+    for (uint32_t t = 0; t < P.nt; ++t) {
+        const FmdTile T = fmd_tile_fast(r, P, tl, L.ns, t);
+        const int64_t ja = (int64_t)t * tl.Qt + jA_off, lo = (int64_t)t * step2 + lo_off2;
+        const int64_t jA = ja > 0 ? ja : 0, jB = T.last ? (int64_t)P.M - 1 : (int64_t)t * tl.Qt + jB_off;
+        const int64_t nLo2 = lo > 0 ? lo : 0, nHi2 = T.last ? (int64_t)ns2 : (int64_t)t * step2 + hi_off2;
+        if (jA != T.jA || jB != T.jB || nLo2 != 2ll * T.nLo || nHi2 != 2ll * T.nHi) return false;
+        if ((uint64_t)(jB - jA + 2) > L.lp_cap || (uint64_t)(nHi2 - nLo2) + 30u > L.raw_cap) return false;
+    }
+    FmdFastGeo& g = L.fg;
+    g.iq = (uint64_t)(uintptr_t)L.iq; g.iq_end = g.iq + L.total_bytes; g.chan_stride = L.chan_stride;
+    g.n_channels = L.n_channels; g.per = per; g.nt = P.nt;
+    g.step2 = (uint32_t)step2; g.lo_off2 = (int32_t)lo_off2; g.hi_off2 = (int32_t)hi_off2; g.ns2 = (uint32_t)ns2;
+    g.Qt = tl.Qt; g.jA_off = (int32_t)jA_off; g.jB_off = (int32_t)jB_off;
+    return true;
+}
+
 hipError_t fmd_launch_tile(const FmdLaunch& L, hipStream_t stream)
 {
     const size_t lds = fmd_tile_lds_bytes(L);
@@ -634,7 +751,8 @@ hipError_t fmd_launch_tile(const FmdLaunch& L, hipStream_t stream)
     if (L.xcd_swizzle && L.n_channels >= 8u && L.tiles <= 65535u && per <= 65535u) {
         g = dim3(8u, L.tiles, per);
         K.xcd_swizzle = 3u;
-    }
+        K.fast = fmd_fast_geometry(K, per) ? 1u : 0u;
+    } else K.fast = 0u;
     switch (dh) {
         case 1: launch_one<1>(K, g, lds, stream); break;
         case 2: launch_one<2>(K, g, lds, stream); break;

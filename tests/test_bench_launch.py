@@ -56,6 +56,6 @@ def test_two_ranks_on_one_box():
     assert "cpu_baseline" not in two and two["scaling"] == "weak"
     # both ranks share ONE GPU here, so the aggregate is about the one-rank rate (never 2x, never a silent 1-rank run)
     assert 0.4 * one["value"] < two["value"] < 1.6 * one["value"], (one["value"], two["value"])
-    assert one["timing"]["regions"] >= 2 and one["timing"]["timed_ms_total"] >= 45.0
+    assert one["timing"]["regions"] >= 2 and one["timing"]["timed_ms_total"] >= 40.0
     for r in (one, two):
         assert 0.05 < r["roofline"]["frac"] < 1.0 and r["roofline"]["bound"] == "hbm"
