@@ -41,6 +41,9 @@ using namespace fmd_dev;
 #define FMD_ABLATE(bit) false
 #define FMD_F64_SKEW 0
 #endif
+#ifndef FMD_USE_F32
+#define FMD_USE_F32 1            /* 0: integer discriminator everywhere (A/B builds) */
+#endif
 
 // Explicit address spaces exist only in the device pass (the host pass parses the same bodies).
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -144,6 +147,47 @@ __device__ __forceinline__ int disc_nosel(uint32_t a, uint32_t b)
     const uint32_t angle = (1u << 12) + (mx & (2u << 12)) - qs;
     const uint32_t res = (angle ^ my) - my;
     return (int)(res & (uint32_t)((int)(0u - den) >> 31));               // x == 0 && y == 0 -> 0 (:388)
+}
+
+// The same function in f32, for downsample <= 11 (FMD_DISC_F32_MAX_D): there |x| + |y| < 2^23, so every quantity
+// below is an integer that f32 holds exactly.  Why: on gfx950 only add / sub / and / or / xor / shift-right and f32
+// add / sub / mul (with their free abs / neg / clamp modifiers) issue in 2 cycles per wave; selects, compares,
+// conversions, integer multiplies, max ... take 4 (tools/valubench.hip).  This form is ~100 cycles against ~124 for
+// the integer one (-10 % on the whole launch at the reference's own rates).
+//   den = |x| + |y|;  s = x >= 0 ? x - |y| : x + |y| = +-(|x| - |y|)                          (:390-400)
+//   `(4096_i64 * s) as i32` keeps s mod 2^20 in [-2^19, 2^19): adding 1.5 * 2^43 (ulp 2^20) rounds s + 0.5 to a
+//     multiple of 2^20 -- never a tie, s is an integer -- and subtracting it again leaves k * 2^20, k = floor(s / 2^20 + 1/2)
+//   q = floor(4096 |sp| / den): the estimate uses 4096 (1 - 2^-21) so that rcp's ulp and two roundings (2^-22 in all)
+//     can only make it too SMALL, by < 0.004: floor() is q or q - 1; the remainder n4 - qf * den is exact in ONE fma
+//     (it is below 2 den < 2^24) and a clamped subtract turns `remainder >= den` into the +1
+//   the sign of the truncating quotient is sp's, the base angle is 8192 - (+-4096) by the sign of x, the result takes
+//     y's sign; (0, 0) -> den = 0 -> the final factor clamp(den + den) is 0 (:388), 1 otherwise.
+// tests/test_disc_f32_model.py replays this sequence in numpy f32 with the reciprocal pushed to both ends of its
+// 1-ulp band against fast_atan2 itself; the GPU parity and fuzz tests run it on the hardware.
+#define FMD_DISC_F32_MAX_D 11
+__device__ __forceinline__ float clamp01(float v) { return __builtin_amdgcn_fmed3f(v, 0.0f, 1.0f); }   // folds into a clamp modifier
+__device__ __forceinline__ float u2f(uint32_t u) { return __builtin_bit_cast(float, u); }
+__device__ __forceinline__ uint32_t f2u(float f) { return __builtin_bit_cast(uint32_t, f); }
+
+__device__ __forceinline__ int disc_f32(uint32_t a, uint32_t b)
+{
+    const uint32_t a_sw = __builtin_amdgcn_alignbit(a, a, 16);          // (im, re)
+    const uint32_t b_cj = (b & 0xFFFFu) | ((0u - (b >> 16)) << 16);      // (re, -im)
+    const float xf = (float)sdot2(a, b), yf = (float)sdot2(a_sw, b_cj);  // c = a * conj(b), exact
+    const float den = __builtin_fabsf(xf) + __builtin_fabsf(yf);
+    const float t = __builtin_fabsf(xf) - __builtin_fabsf(yf);
+    const uint32_t sx = f2u(xf) & 0x80000000u;
+    const float s = u2f(f2u(t) ^ sx);
+    const float big = 13194139533312.0f;                                 // 1.5 * 2^43
+    const float sp = s - (((s + 0.5f) + big) - big);                     // s mod 2^20, signed
+    const float c = __builtin_amdgcn_rcpf(den + 0x1p-30f) * 4095.998046875f;   // + 2^-30: finite for den == 0, no change otherwise
+    const float qf = __builtin_floorf(__builtin_fabsf(sp) * c);
+    const float r = __builtin_fmaf(-qf, den, __builtin_fabsf(sp) * 4096.0f);
+    const float q = qf + clamp01(r - (den - 1.0f));
+    const float qs = u2f(f2u(q) ^ (f2u(sp) & 0x80000000u));
+    const float base = 8192.0f - u2f(0x45800000u ^ sx);                  // 4096 or 12288 (:395,400)
+    const float res = u2f(f2u(base - qs) ^ (f2u(yf) & 0x80000000u));
+    return (int)(res * clamp01(den + den));
 }
 
 // Sum of one audio group: FA samples plus one optional (low_pass_real, :411-415).
@@ -326,7 +370,8 @@ __device__ __forceinline__ void tile_body(const FmdLaunch& L, const TileCtx& X, 
             const uint32_t prev2 = wave_shr1_old(wave_ror1(pk1), pk2);   // lane l <- second of l-1; lane 0 <- first of 63
             int d1, d2;
             if (FMD_ABLATE(0)) { d1 = (int)(pk1 ^ prev1); d2 = (int)(pk2 ^ prev2); }    // ablation: no discriminator
-            else { d1 = disc_fast(pk1, prev1); d2 = disc_fast(pk2, prev2); }            // (:362)
+            else if (FMD_USE_F32) { d1 = disc_f32(pk1, prev1); d2 = disc_f32(pk2, prev2); }   // (:362); whole-dword windows: downsample <= 10
+            else { d1 = disc_fast(pk1, prev1); d2 = disc_fast(pk2, prev2); }
             if (lane > 0 && i1 < cnt) d16[i1] = (int16_t)d1;
             if (i2 < cnt) d16[i2] = (int16_t)d2;
         }
@@ -355,6 +400,7 @@ __device__ __forceinline__ void tile_body(const FmdLaunch& L, const TileCtx& X, 
         // cycles were bank conflicts).  Each lane therefore walks its window from a different even offset and
         // wraps; an even rotation keeps the A, B weight order.
         const bool rotate = (D & 1) == 0 && (p0 & 1u) == 0u && (ndw & 1) == 0 && ndw >= 4;
+        const bool smallD = FMD_USE_F32 && D <= FMD_DISC_F32_MAX_D;
         uint32_t rot0 = 0;
         if (rotate) {
             const uint32_t low = (uint32_t)ndw & (0u - (uint32_t)ndw);                   // lanes 32 / g apart share a bank,
@@ -381,7 +427,7 @@ __device__ __forceinline__ void tile_body(const FmdLaunch& L, const TileCtx& X, 
                 const uint32_t pk1 = pack_lp_perm(re1, im1), pk2 = pack_lp_perm(re2, im2);
                 const uint32_t prev1 = wave_shr1(pk1);
                 const uint32_t prev2 = wave_shr1_old(wave_ror1(pk1), pk2);
-                const int d1 = disc_nosel(pk1, prev1), d2 = disc_nosel(pk2, prev2);
+                const int d1 = disc_nosel(pk1, prev1), d2 = disc_nosel(pk2, prev2);     // rotate: downsample >= 8, mostly > 11
                 if (lane > 0 && i1 < cnt) d16[i1] = (int16_t)d1;
                 if (i2 < cnt) d16[i2] = (int16_t)d2;
                 continue;
@@ -412,7 +458,9 @@ __device__ __forceinline__ void tile_body(const FmdLaunch& L, const TileCtx& X, 
             const uint32_t pk1 = pack_lp_perm(re1, im1), pk2 = pack_lp_perm(re2, im2);
             const uint32_t prev1 = wave_shr1(pk1);
             const uint32_t prev2 = wave_shr1_old(wave_ror1(pk1), pk2);
-            const int d1 = disc_nosel(pk1, prev1), d2 = disc_nosel(pk2, prev2);
+            int d1, d2;
+            if (smallD) { d1 = disc_f32(pk1, prev1); d2 = disc_f32(pk2, prev2); }       // wave-uniform
+            else { d1 = disc_nosel(pk1, prev1); d2 = disc_nosel(pk2, prev2); }
             if (lane > 0 && i1 < cnt) d16[i1] = (int16_t)d1;
             if (i2 < cnt) d16[i2] = (int16_t)d2;
         }

@@ -1,0 +1,116 @@
+"""The f32 form of polar_discriminant_fast / fast_atan2 (simple_fm.rs:377-405) used by the tile kernel for
+downsample <= 11 (disc_f32, rtl-sdr-rs_amd/csrc/fmd_tile_kernel.hip), replayed step by step in numpy float32 --
+same operations, same constants, same order -- with the hardware reciprocal (v_rcp_f32: 1 ulp) pushed to BOTH ends
+of its error band, against the integer definition (vectorised here, itself checked against the C oracle).
+Every input class the kernel can produce: products a * conj(b) of boxcar sums up to |lp| = 128 * 11, the i32 wrap
+ties (s = 2^19 mod 2^20), exact quotients, both axes, (0, 0)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+F = np.float32
+LIM = 128 * 11                      # |lp| <= 128 * D, D <= FMD_DISC_F32_MAX_D
+
+
+def fast_atan2_ref(y, x):
+    """Demod::fast_atan2 on int64 arrays with the `as i32` wrap of the product (simple_fm.rs:383-405)."""
+    y = y.astype(np.int64); x = x.astype(np.int64)
+    yabs = np.abs(y)
+    pos = x >= 0
+    num = np.where(pos, x - yabs, x + yabs) * 4096
+    num = ((num + 2**31) % 2**32) - 2**31                      # (.. as i64 * 4096) as i32
+    den = np.where(pos, x + yabs, yabs - x)
+    safe = np.where(den == 0, 1, den)
+    q = np.sign(num) * (np.abs(num) // safe)                   # Rust `/`: truncation toward zero
+    angle = np.where(pos, 4096, 12288) - q
+    res = np.where(y < 0, -angle, angle)
+    return np.where((x == 0) & (y == 0), 0, res)
+
+
+def disc_f32_model(x, y, rcp_ulps):
+    """disc_f32 after the two dot products, in float32; rcp = correctly rounded 1/d nudged by rcp_ulps ulps."""
+    xf, yf = x.astype(F), y.astype(F)
+    den = np.abs(xf) + np.abs(yf)
+    t = np.abs(xf) - np.abs(yf)
+    sx = xf.view(np.uint32) & np.uint32(0x80000000)
+    s = (t.view(np.uint32) ^ sx).view(F)
+    big = F(13194139533312.0)
+    sp = s - (((s + F(0.5)) + big) - big)
+    d = den + F(2.0 ** -30)
+    rc = (1.0 / d.astype(np.float64)).astype(F)
+    for _ in range(abs(rcp_ulps)):
+        rc = np.nextafter(rc, F(np.inf) if rcp_ulps > 0 else F(0))
+    c = rc * F(4095.998046875)
+    qf = np.floor(np.abs(sp) * c)
+    n4 = np.abs(sp) * F(4096.0)
+    r = (n4.astype(np.float64) - qf.astype(np.float64) * den.astype(np.float64)).astype(F)   # one fma: exact, then rounded
+    assert np.all(r.astype(np.float64) == n4.astype(np.float64) - qf.astype(np.float64) * den.astype(np.float64)), "fma not exact"
+    q = qf + np.clip(r - (den - F(1.0)), F(0), F(1))
+    qs = (q.view(np.uint32) ^ (sp.view(np.uint32) & np.uint32(0x80000000))).view(F)
+    base = F(8192.0) - (np.uint32(0x45800000) ^ sx).view(F)
+    res = ((base - qs).view(np.uint32) ^ (yf.view(np.uint32) & np.uint32(0x80000000))).view(F)
+    out = res * np.clip(den + den, F(0), F(1))
+    assert np.all(out == np.trunc(out))
+    return out.astype(np.int64)
+
+
+def products(ar, ai, br, bi):
+    return ar * br + ai * bi, ai * br - ar * bi                # c = a * conj(b): (re, im)
+
+
+def cases():
+    rng = np.random.default_rng(2026)
+    xs, ys = [], []
+    n = 400000
+    a = rng.integers(-LIM, LIM + 1, (4, n))
+    x, y = products(*a); xs.append(x); ys.append(y)
+    a = rng.choice([-LIM, -LIM + 1, -1, 0, 1, LIM - 1, LIM], (4, 50000))      # corners: largest magnitudes, axes, zero
+    x, y = products(*a); xs.append(x); ys.append(y)
+    a = rng.integers(-60, 61, (4, 100000))                                     # weak signals: small den, no wrap
+    x, y = products(*a); xs.append(x); ys.append(y)
+    # the wrap ties: |x| - |y| = 2^19 (2k + 1) exactly, both signs of x and y
+    k = rng.integers(0, 3, 60000)
+    yy = rng.integers(0, 2**21, 60000)
+    xx = yy + 2**19 * (2 * k + 1)
+    ok = xx + yy < 2**23
+    sgx, sgy = rng.choice([-1, 1], ok.sum()), rng.choice([-1, 1], ok.sum())
+    xs.append(xx[ok] * sgx); ys.append(yy[ok] * sgy)
+    # exact quotients: den divides 4096 * sp
+    den = 2 ** rng.integers(1, 22, 40000)
+    sp = (rng.integers(0, 4097, 40000) * den) // 4096
+    xx = (den + sp) // 2; yy = den - xx
+    xs.append(xx * rng.choice([-1, 1], 40000)); ys.append(yy * rng.choice([-1, 1], 40000))
+    # near-exact quotients around every boundary: 4096 * t = q * den + {-1, 0, +1 ...}
+    den = rng.integers(1, 2**23, 200000)
+    q = rng.integers(0, 4097, 200000)
+    t = (q * den + rng.integers(-3, 4, 200000) + 4095) // 4096
+    t = np.clip(t, 0, den)
+    xx = (den + t) // 2; yy = den - xx                          # |x| + |y| = den, |x| - |y| ~ t
+    xs.append(xx * rng.choice([-1, 1], 200000)); ys.append(yy * rng.choice([-1, 1], 200000))
+    xs.append(np.array([0, 0, 0, 5, -5, 1, -1, 2**22, -2**22, 524288, 524287, -524288, 0, 0]))
+    ys.append(np.array([0, 7, -7, 0, 0, 1, -1, 0, 0, 0, 0, 0, 524288, -524288]))
+    x, y = np.concatenate(xs), np.concatenate(ys)
+    keep = np.abs(x) + np.abs(y) < 2**23
+    return x[keep], y[keep]
+
+
+def test_reference_formula_matches_oracle(oracle):
+    x, y = cases()
+    idx = np.random.default_rng(1).choice(x.size, 20000, replace=False)
+    ref = fast_atan2_ref(y[idx], x[idx])
+    got = np.array([oracle.lib.fmo_fast_atan2(int(b), int(a)) for a, b in zip(x[idx], y[idx])])
+    assert np.array_equal(ref, got)
+    assert oracle.lib.fmo_fast_atan2(0, 524288) == 8192 and oracle.lib.fmo_fast_atan2(0, 524287) == 0
+
+
+@pytest.mark.parametrize("rcp_ulps", [-2, -1, 0, 1, 2])     # v_rcp_f32 is specified to 1 ulp; 2 shows the margin
+def test_f32_discriminator_is_exact(rcp_ulps):
+    x, y = cases()
+    assert x.size > 800000
+    ref = fast_atan2_ref(y, x)
+    got = disc_f32_model(x, y, rcp_ulps)
+    bad = np.nonzero(ref != got)[0]
+    assert bad.size == 0, [(int(x[i]), int(y[i]), int(ref[i]), int(got[i])) for i in bad[:8]]
+    # the wrap is really exercised, and so is the +1 correction
+    assert np.count_nonzero(np.abs(np.abs(x) - np.abs(y)) >= 2**19) > 100000

@@ -66,6 +66,67 @@ KERNEL(k_pk_add_u16, I8S("v_pk_add_u16", ", ", "%8"))
 KERNEL(k_pk_mul_lo_u16, I8S("v_pk_mul_lo_u16", ", ", "%8"))
 KERNEL(k_sad_u32,   I8S("v_sad_u32", ", %8, ", "%9"))
 KERNEL(k_mov_dpp,   I8("v_mov_b32_dpp", "%8 wave_shr:1 row_mask:0xf bank_mask:0xf"))
+// round 2: candidates for a float-domain discriminator
+KERNEL(k_and_b32,   I8S("v_and_b32", ", ", "%8"))
+KERNEL(k_or_b32,    I8S("v_or_b32", ", ", "%8"))
+KERNEL(k_ashr,      I8S("v_ashrrev_i32", ", ", "%8"))
+KERNEL(k_lshr,      I8S("v_lshrrev_b32", ", ", "%8"))
+KERNEL(k_mov,       I8("v_mov_b32", "%8"))
+KERNEL(k_floor_f32, I8("v_floor_f32", "%8"))
+KERNEL(k_trunc_f32, I8("v_trunc_f32", "%8"))
+KERNEL(k_rndne_f32, I8("v_rndne_f32", "%8"))
+KERNEL(k_cvt_f32_i32, I8("v_cvt_f32_i32", "%8"))
+KERNEL(k_cvt_i32_f32, I8("v_cvt_i32_f32", "%8"))
+KERNEL(k_min_f32,   I8S("v_min_f32", ", ", "%8"))
+KERNEL(k_max_f32,   I8S("v_max_f32", ", ", "%8"))
+KERNEL(k_med3_f32,  I8S("v_med3_f32", ", %8, ", "%9"))
+KERNEL(k_bfi_b32,   I8S("v_bfi_b32", ", %8, ", "%9"))
+KERNEL(k_sub_f32,   I8S("v_sub_f32", ", ", "%8"))
+KERNEL(k_add_f32_abs, I8("v_add_f32_e64", "|%8|, |%9|"))
+KERNEL(k_add_f32_clamp, I8("v_add_f32_e64", "%8, %9 clamp"))
+KERNEL(k_fma_f32_neg, I8S("v_fma_f32", ", -%8, ", "|%9|"))
+KERNEL(k_mul_f32_e64, I8("v_mul_f32_e64", "|%8|, %9"))
+KERNEL(k_cmp8_f32,  REP8("v_cmp_ge_f32 s[20:21], %8, %9\n"))
+KERNEL(k_mul_u24,   I8S("v_mul_u32_u24", ", ", "%8"))
+KERNEL(k_mad_i24,   I8S("v_mad_i32_i24", ", %8, ", "%9"))
+KERNEL(k_xad_u32,   I8S("v_xad_u32", ", %8, ", "%9"))
+KERNEL(k_ldexp_f32, I8S("v_ldexp_f32", ", ", "%8"))
+KERNEL(k_max_u32,   I8S("v_max_u32", ", ", "%8"))
+KERNEL(k_min_u32,   I8S("v_min_u32", ", ", "%8"))
+KERNEL(k_mul_hi_u32, I8S("v_mul_hi_u32", ", ", "%8"))
+KERNEL(k_cvt_pk_i16, I8S("v_cvt_pk_i16_i32", ", ", "%8"))
+KERNEL(k_add_lshl,  I8S("v_add_lshl_u32", ", %8, ", "2"))
+KERNEL(k_lshl_or,   I8S("v_lshl_or_b32", ", 16, ", "%9"))
+
+// packed f32 (two floats per 64-bit register pair)
+#define KERNEL64(NAME, OP)                                                                              \
+    __global__ void __launch_bounds__(256) NAME(unsigned* out, int iters, unsigned seed)                \
+    {                                                                                                   \
+        double a0 = threadIdx.x + seed, a1 = a0 * 3, a2 = a0 * 5, a3 = a0 * 7, a4 = a0 + 11, a5 = a0 + 99, a6 = a0 + 5, a7 = a0 * 9; \
+        double b = a0 * 17 + 1, c = a0 * 29 + 3;                                                        \
+        for (int it = 0; it < iters; ++it) {                                                            \
+            asm volatile(OP " %0, %0, %8, %9\n" OP " %1, %1, %8, %9\n" OP " %2, %2, %8, %9\n" OP " %3, %3, %8, %9\n" \
+                         OP " %4, %4, %8, %9\n" OP " %5, %5, %8, %9\n" OP " %6, %6, %8, %9\n" OP " %7, %7, %8, %9\n" \
+                         : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b), "v"(c)); \
+        }                                                                                               \
+        out[blockIdx.x * 256 + threadIdx.x] = (unsigned)(a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7);        \
+    }
+#define KERNEL64B(NAME, OP)                                                                             \
+    __global__ void __launch_bounds__(256) NAME(unsigned* out, int iters, unsigned seed)                \
+    {                                                                                                   \
+        double a0 = threadIdx.x + seed, a1 = a0 * 3, a2 = a0 * 5, a3 = a0 * 7, a4 = a0 + 11, a5 = a0 + 99, a6 = a0 + 5, a7 = a0 * 9; \
+        double b = a0 * 17 + 1;                                                                         \
+        for (int it = 0; it < iters; ++it) {                                                            \
+            asm volatile(OP " %0, %0, %8\n" OP " %1, %1, %8\n" OP " %2, %2, %8\n" OP " %3, %3, %8\n" \
+                         OP " %4, %4, %8\n" OP " %5, %5, %8\n" OP " %6, %6, %8\n" OP " %7, %7, %8\n" \
+                         : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b)); \
+        }                                                                                               \
+        out[blockIdx.x * 256 + threadIdx.x] = (unsigned)(a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7);        \
+    }
+KERNEL64(k_pk_fma_f32x2, "v_pk_fma_f32")
+KERNEL64B(k_pk_add_f32x2, "v_pk_add_f32")
+KERNEL64B(k_pk_mul_f32x2, "v_pk_mul_f32")
+
 template <typename K>
 static void run(const char* name, K kern, int blocks_per_cu, int iters, double base_ns)
 {
@@ -111,5 +172,11 @@ int main()
     R(k_mul_lo); R(k_mul_i24); R(k_mad_u24); R(k_add3); R(k_lshl_add); R(k_and_or); R(k_alignbit); R(k_perm); R(k_bfe_i32);
     R(k_cvt_f32_u32); R(k_cvt_u32_f32); R(k_rcp_f32); R(k_mul_f32); R(k_fma_f32); R(k_add_f32); R(k_pk_add_u16);
     R(k_pk_mul_lo_u16); R(k_sad_u32); R(k_mov_dpp);
+    R(k_and_b32); R(k_or_b32); R(k_ashr); R(k_lshr); R(k_mov); R(k_floor_f32); R(k_trunc_f32); R(k_rndne_f32);
+    R(k_cvt_f32_i32); R(k_cvt_i32_f32); R(k_min_f32); R(k_max_f32); R(k_med3_f32); R(k_bfi_b32); R(k_sub_f32);
+    R(k_cvt_pk_i16); R(k_add_lshl); R(k_lshl_or);
+    R(k_add_f32_abs); R(k_add_f32_clamp); R(k_fma_f32_neg); R(k_mul_f32_e64); R(k_cmp8_f32);
+    R(k_pk_fma_f32x2); R(k_pk_add_f32x2); R(k_pk_mul_f32x2);
+    R(k_mul_u24); R(k_mad_i24); R(k_xad_u32); R(k_ldexp_f32); R(k_max_u32); R(k_min_u32); R(k_mul_hi_u32);
     return 0;
 }
