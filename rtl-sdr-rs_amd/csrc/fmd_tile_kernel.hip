@@ -372,6 +372,9 @@ __device__ __forceinline__ void tile_body(const FmdLaunch& L, const TileCtx& X, 
             if (FMD_ABLATE(0)) { d1 = (int)(pk1 ^ prev1); d2 = (int)(pk2 ^ prev2); }    // ablation: no discriminator
             else if (FMD_USE_F32) { d1 = disc_f32(pk1, prev1); d2 = disc_f32(pk2, prev2); }   // (:362); whole-dword windows: downsample <= 10
             else { d1 = disc_fast(pk1, prev1); d2 = disc_fast(pk2, prev2); }
+            // (Measured and rejected in round 2: storing the full rounds without predication -- lane 0 to a dummy slot --
+            //  so that both discriminators run as one interleaved stream: +2 % at downsample 6 / 10, +7 % at 7.  The
+            //  two separately masked regions the compiler builds here are the faster form.)
             if (lane > 0 && i1 < cnt) d16[i1] = (int16_t)d1;
             if (i2 < cnt) d16[i2] = (int16_t)d2;
         }
