@@ -41,6 +41,9 @@ using namespace fmd_dev;
 #define FMD_ABLATE(bit) false
 #define FMD_F64_SKEW 0
 #endif
+#ifndef FMD_MASKED_UNROLL
+#define FMD_MASKED_UNROLL 1      /* 0: run-time masked-window loop for every dword count (A/B builds) */
+#endif
 #ifndef FMD_USE_F32
 #define FMD_USE_F32 1            /* 0: integer discriminator everywhere (A/B builds) */
 #endif
@@ -301,6 +304,48 @@ __device__ __forceinline__ void tile_exc_flush(const FmdLaunch& L, const TileCtx
     }
 }
 
+// Masked-window rounds with the dword count known at compile time (odd downsample 3 ... 11, or an even one at an
+// odd boxcar phase): a window of D samples covers NDW dwords of which the first and / or the last counts only
+// half.  Which half is fixed per lane (a lane's windows are an even number of samples apart), so the masks fold
+// into 2 * NDW per-lane weight registers and the body is the same 3 VALU instructions per dword as the whole-dword
+// loop -- no run-time trip counts, no per-dword branches.  (Round 1 ran these through the run-time loop below:
+// downsample 7 sat at 57 % of the HBM spec against 70 % for 6 and 8.)
+template <int NDW, int NT>
+__device__ __forceinline__ void masked_rounds(const uint32_t* __restrict__ raw_w, int16_t* __restrict__ d16, int wofs, int s00,
+                                              int D, int cnt, uint32_t lane, uint32_t wave, uint32_t wreA, uint32_t wreB,
+                                              uint32_t wimA, uint32_t wimB, uint32_t mf, uint32_t ml, int cre, int cim, bool smallD)
+{
+    constexpr int NW = NT / 64, RS = NW == 1 ? 124 : 127;
+    uint32_t wr[NDW], wi[NDW];
+#pragma unroll
+    for (int u = 0; u < NDW; ++u) {
+        const uint32_t m = (u == 0 ? mf : 0xFFFFFFFFu) & (u == NDW - 1 ? ml : 0xFFFFFFFFu);
+        wr[u] = ((u & 1) ? wreB : wreA) & m;
+        wi[u] = ((u & 1) ? wimB : wimA) & m;
+    }
+    const int last = cnt - 1;
+    for (int base = (int)wave * RS; base < last; base += NW * RS) {
+        const int i1 = base + (int)lane, i2 = i1 + 64;
+        const uint32_t* __restrict__ pa = raw_w + (uint32_t)(wofs + ((s00 + D * i1) >> 1));
+        const uint32_t* __restrict__ pb = raw_w + (uint32_t)(wofs + ((s00 + D * i2) >> 1));
+        int re1 = cre, im1 = cim, re2 = cre, im2 = cim;
+#pragma unroll
+        for (int u = 0; u < NDW; ++u) {
+            const uint32_t wa = pa[u] ^ 0x80808080u, wb = pb[u] ^ 0x80808080u;           // u8 -> s8 (b - 128)
+            re1 = sdot4(wa, wr[u], re1); im1 = sdot4(wa, wi[u], im1);
+            re2 = sdot4(wb, wr[u], re2); im2 = sdot4(wb, wi[u], im2);
+        }
+        const uint32_t pk1 = pack_lp_perm(re1, im1), pk2 = pack_lp_perm(re2, im2);
+        const uint32_t prev1 = wave_shr1(pk1);
+        const uint32_t prev2 = wave_shr1_old(wave_ror1(pk1), pk2);
+        int d1, d2;
+        if (smallD) { d1 = disc_f32(pk1, prev1); d2 = disc_f32(pk2, prev2); }             // wave-uniform
+        else { d1 = disc_nosel(pk1, prev1); d2 = disc_nosel(pk2, prev2); }
+        if (lane > 0 && i1 < cnt) d16[i1] = (int16_t)d1;
+        if (i2 < cnt) d16[i2] = (int16_t)d2;
+    }
+}
+
 // Everything after the tile's bytes are visible in LDS.  Contains one __syncthreads().
 template <int DH, int NT>
 __device__ __forceinline__ void tile_body(const FmdLaunch& L, const TileCtx& X, unsigned char* smem)
@@ -410,7 +455,18 @@ __device__ __forceinline__ void tile_body(const FmdLaunch& L, const TileCtx& X, 
             const uint32_t g = low < 32u ? low : 32u;                                    // g = gcd(ndw, 32)
             rot0 = 2u * ((((lane & 31u) * g) >> 5) % ((uint32_t)ndw >> 1));
         }
-        for (int base = (int)wave * RS; base < last; base += NW * RS) {
+        // compile-time dword counts (see masked_rounds); anything else runs the general loop below
+#define FMD_MASKED(N) case N: masked_rounds<N, NT>(raw_w, d16, wofs, s00, D, cnt, lane, wave, wreA, wreB, wimA, wimB, mf, ml, cre, cim, smallD); break
+        bool done = false;
+        if (!rotate && FMD_MASKED_UNROLL) {
+            done = true;
+            switch (ndw) {                                   // wave-uniform
+                FMD_MASKED(2); FMD_MASKED(3); FMD_MASKED(4); FMD_MASKED(5); FMD_MASKED(6);
+                default: done = false;
+            }
+        }
+#undef FMD_MASKED
+        for (int base = (int)wave * RS; base < last && !done; base += NW * RS) {
             const int i1 = base + (int)lane, i2 = i1 + 64;
             const uint32_t* __restrict__ pa = raw_w + (uint32_t)(wofs + ((s00 + D * i1) >> 1));
             const uint32_t* __restrict__ pb = raw_w + (uint32_t)(wofs + ((s00 + D * i2) >> 1));
