@@ -106,7 +106,7 @@ def extra_config4(fmd, torch, dev, stream, fused):
         fmd.synth.fill_device(t.data_ptr(), nch, n, sample_offset=b * (n // 2), device_id=dev.index, stream=stream)
         bufs.append(t)
     if fused:
-        taps = rng.integers(-60, 61, T).astype(np.int16)          # |y| <= 128 * sum|h| must fit the packed i16 form
+        taps = rng.integers(-2047, 2048, T).astype(np.int16)         # the same taps as the stand-alone line; auto shift
         fast, slow = 2_500_000, 48_000                               # 20 Msps / 8 -> 2.5 Msps -> 48 kHz audio
         bank = fmd.FirDemodBank(taps, M, fast, slow, nch, device_id=dev.index)
         cap = bank.out_cap(n)

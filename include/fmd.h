@@ -208,6 +208,37 @@ int fmd_fir_filter_batch(fmd_fir *f, const uint8_t *iq, size_t nbytes, int32_t *
 int fmd_fir_filter_device(fmd_fir *f, const void *d_iq, size_t nbytes, void *d_out, size_t out_cap,
                           size_t *out_len_each, void *stream);
 
+/* ---- tapped FIR -> discriminator -> resampler in one kernel (BASELINE north_star: "FIR + demod + resample fused") -- */
+/* NOT a reference interface either.  Definition: Demod::demodulate (simple_fm.rs:256-269) with low_pass_complex
+ * (:337-352) replaced by the tapped decimating FIR above, normalised by a right shift,
+ *     lp[m] = floor( sum_{t < n_taps} taps[t] * x[decim * m + t] / 2^shift ),
+ * followed by the reference's own fm_demod (:355-367, the f64 sample at the first filter output of every call) and
+ * low_pass_real (:408-426, rate_out -> rate_resample).  With taps = 1...1, n_taps == decim == downsample, shift == 0
+ * it returns exactly what fmd_demod_* (and the reference) return -- tested bit for bit; that is its anchor.
+ * Domain: decim even and <= 64, 1 <= n_taps <= 1024, |taps| <= 2047, (128 * sum|taps|) >> shift <= 16384 (so that
+ * |lp| stays in the discriminator's range, the boxcar's bound at downsample 128), shift <= 24.
+ * A call that yields fewer than 2 filter outputs returns FMD_ERR_TOO_SHORT (assert at :356) and changes nothing.
+ * All channels of a bank advance together (equal-sized buffers), so there is no per-channel set_state. */
+typedef struct fmd_firdemod fmd_firdemod;
+int fmd_firdemod_new(const int16_t *taps, uint32_t n_taps, uint32_t decim, uint32_t shift, uint32_t rate_out,
+                     uint32_t rate_resample, const fmd_device_config *dev, fmd_firdemod **out);
+void fmd_firdemod_free(fmd_firdemod *f);
+int fmd_firdemod_reset(fmd_firdemod *f);
+/* Audio samples one call of nbytes can produce per channel (upper bound). */
+size_t fmd_firdemod_out_cap(uint32_t decim, uint32_t rate_out, uint32_t rate_resample, size_t nbytes);
+/* HOST buffers: iq [n_channels][nbytes]; out [n_channels][out_cap] s16; out_len [n_channels]. */
+int fmd_firdemod_demodulate_batch(fmd_firdemod *f, const uint8_t *iq, size_t nbytes, int16_t *out, size_t out_cap,
+                                  size_t *out_len);
+/* DEVICE buffers, enqueued on `stream` without synchronising; the per-channel count (identical for all channels)
+ * is returned in *out_len_each.  fmd_firdemod_check is its completion / verification point (see fmd_demod_check). */
+int fmd_firdemod_demodulate_device(fmd_firdemod *f, const void *d_iq, size_t nbytes, void *d_out, size_t out_cap,
+                                   size_t *out_len_each, void *stream);
+int fmd_firdemod_check(fmd_firdemod *f);
+/* demod_pre, now_lpr, prev_lpr_index of one channel (prev_index / lp_now are 0: the FIR owns the decimation). */
+int fmd_firdemod_get_state(fmd_firdemod *f, uint32_t channel, fmd_demod_state *state);
+int fmd_firdemod_f64_stats(const fmd_firdemod *f, uint64_t *guarded, uint64_t *patched);
+int fmd_firdemod_tiling(const fmd_firdemod *f, uint32_t *audio_per_tile, uint32_t *lds_bytes);
+
 /* ---- diagnostics ---------------------------------------------------------------------- */
 const char *fmd_strerror(int status);
 const char *fmd_last_error(void);          /* thread-local detail of the last failure          */

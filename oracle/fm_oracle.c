@@ -477,3 +477,99 @@ int fmo_fir_filter_batch(fmo_fir **firs, const uint8_t *iq, size_t n_channels, s
     free(th); free(jobs);
     return err;
 }
+
+/* ---- tapped FIR in place of the boxcar: FIR -> fm_demod -> low_pass_real (BASELINE north_star's "FIR + demod +
+ * resample"; see fm_oracle.h).  Composition of the functions above; nothing new is computed here. */
+struct fmo_firdemod {
+    fmo_fir *fir;
+    fmo_demod d;            /* demod_pre, now_lpr, prev_lpr_index (prev_index / lp_now stay 0: the FIR owns the decimation) */
+    uint32_t shift;
+};
+
+fmo_firdemod *fmo_firdemod_new(const int16_t *taps, uint32_t n_taps, uint32_t decim, uint32_t shift,
+                               uint32_t rate_out, uint32_t rate_resample)
+{
+    fmo_firdemod *f = (fmo_firdemod *)calloc(1, sizeof(*f));
+    if (!f) return NULL;
+    f->fir = fmo_fir_new(taps, n_taps, decim);
+    if (!f->fir || shift > 31) { fmo_firdemod_free(f); return NULL; }
+    fmo_demod_config cfg = {rate_out, rate_out, rate_resample, decim, 1};
+    fmo_demod_new(&f->d, &cfg);
+    f->shift = shift;
+    return f;
+}
+
+void fmo_firdemod_free(fmo_firdemod *f)
+{
+    if (!f) return;
+    fmo_fir_free(f->fir);
+    free(f);
+}
+
+long fmo_firdemod_demodulate(fmo_firdemod *f, const uint8_t *buf, size_t len, int16_t *out, size_t out_cap)
+{
+    if (len % 8 != 0) return -1;
+    const size_t cap = len / 2 / f->fir->decim + 2;
+    fmo_cplx *lowpassed = (fmo_cplx *)malloc(cap * sizeof(fmo_cplx));
+    int16_t *demodulated = (int16_t *)malloc(cap * sizeof(int16_t));
+    int16_t *res = (int16_t *)malloc(cap * sizeof(int16_t));
+    long rc = -5;
+    if (!lowpassed || !demodulated || !res) goto done;
+    {
+        const long n = fmo_fir_filter(f->fir, buf, len, lowpassed, cap);       /* in place of low_pass_complex, :261 */
+        if (n < 0) { rc = n; goto done; }
+        for (long i = 0; i < n; i++) {                                         /* fixed-point normalisation: floor(y / 2^shift) */
+            lowpassed[i].re = (int32_t)((int64_t)lowpassed[i].re >> f->shift);
+            lowpassed[i].im = (int32_t)((int64_t)lowpassed[i].im >> f->shift);
+        }
+        if (!(n > 1)) { rc = -2; goto done; }                                  /* assert!(buf.len() > 1), :356 */
+        fmo_fm_demod(&f->d, lowpassed, (size_t)n, demodulated);                /* :264 */
+        const long k = fmo_low_pass_real(&f->d, demodulated, (size_t)n, res);  /* :267 */
+        if (k < 0) rc = -4;
+        else if ((size_t)k > out_cap) rc = -3;
+        else { memcpy(out, res, (size_t)k * sizeof(int16_t)); rc = k; }
+    }
+done:
+    free(lowpassed); free(demodulated); free(res);
+    return rc;
+}
+
+void fmo_firdemod_state(const fmo_firdemod *f, fmo_demod *out) { *out = f->d; }
+
+typedef struct {
+    fmo_firdemod **fs; const uint8_t *iq; size_t c0, c1, len; int16_t *out; size_t out_cap; uint32_t *out_len; int err;
+} firdemod_job;
+
+static void *firdemod_worker(void *arg)
+{
+    firdemod_job *j = (firdemod_job *)arg;
+    for (size_t c = j->c0; c < j->c1; c++) {
+        long n = fmo_firdemod_demodulate(j->fs[c], j->iq + c * j->len, j->len, j->out + c * j->out_cap, j->out_cap);
+        if (n < 0) { if (!j->err) j->err = (int)n; continue; }
+        j->out_len[c] = (uint32_t)n;
+    }
+    return NULL;
+}
+
+int fmo_firdemod_batch(fmo_firdemod **fs, const uint8_t *iq, size_t n_channels, size_t len, int16_t *out,
+                       size_t out_cap, uint32_t *out_len, int n_threads)
+{
+    if (n_threads < 1) n_threads = 1;
+    if ((size_t)n_threads > n_channels) n_threads = (int)(n_channels ? n_channels : 1);
+    pthread_t *th = (pthread_t *)calloc((size_t)n_threads, sizeof(pthread_t));
+    firdemod_job *jobs = (firdemod_job *)calloc((size_t)n_threads, sizeof(firdemod_job));
+    for (int t = 0; t < n_threads; t++) {
+        firdemod_job b = {fs, iq, n_channels * (size_t)t / (size_t)n_threads, n_channels * (size_t)(t + 1) / (size_t)n_threads,
+                          len, out, out_cap, out_len, 0};
+        jobs[t] = b;
+        if (n_threads == 1) firdemod_worker(&jobs[t]);
+        else pthread_create(&th[t], NULL, firdemod_worker, &jobs[t]);
+    }
+    int err = 0;
+    for (int t = 0; t < n_threads; t++) {
+        if (n_threads > 1) pthread_join(th[t], NULL);
+        if (jobs[t].err && !err) err = jobs[t].err;
+    }
+    free(th); free(jobs);
+    return err;
+}

@@ -131,6 +131,23 @@ void fmo_fir_free(fmo_fir *f);
 /* Returns the number of complex outputs written (capacity out_cap), -1 len % 8, -3 capacity. */
 long fmo_fir_filter(fmo_fir *f, const uint8_t *buf, size_t len, fmo_cplx *out, size_t out_cap);
 
+/* ---- the tapped FIR in place of the boxcar inside Demod::demodulate (BASELINE north_star: "the FIR + demod +
+ * resample stages fused").  NOT IN THE REFERENCE; the definition is the composition of the functions above:
+ *     lowpassed = floor(fmo_fir_filter(buf) / 2^shift)   -- instead of low_pass_complex, simple_fm.rs:261
+ *     fmo_fm_demod(lowpassed)  (:264, f64 sample at the first output of every call, demod_pre carried)
+ *     fmo_low_pass_real(...)   (:267, rate_out -> rate_resample)
+ * `shift` is the usual fixed-point normalisation of an integer-tap filter (0 = none).  With taps = 1...1,
+ * n_taps = decim = D and shift = 0 it IS fmo_demodulate -- tested: that reduction is its anchor to the reference.
+ * Return codes as fmo_demodulate (-2: the call yields fewer than 2 filter outputs, assert at :356). */
+typedef struct fmo_firdemod fmo_firdemod;
+fmo_firdemod *fmo_firdemod_new(const int16_t *taps, uint32_t n_taps, uint32_t decim, uint32_t shift,
+                               uint32_t rate_out, uint32_t rate_resample);
+void fmo_firdemod_free(fmo_firdemod *f);
+long fmo_firdemod_demodulate(fmo_firdemod *f, const uint8_t *buf, size_t len, int16_t *out, size_t out_cap);
+void fmo_firdemod_state(const fmo_firdemod *f, fmo_demod *out);
+int fmo_firdemod_batch(fmo_firdemod **fs, const uint8_t *iq, size_t n_channels, size_t len, int16_t *out,
+                       size_t out_cap, uint32_t *out_len, int n_threads);
+
 /* firs[c] fed iq[c] (channel-major iq[n_channels][len], out[n_channels][out_cap]) over n_threads pthreads: the
  * config-4 check at its real size (256 channels x 2 MiB).  Returns 0 or the first negative fmo_fir_filter code. */
 int fmo_fir_filter_batch(fmo_fir **firs, const uint8_t *iq, size_t n_channels, size_t len, fmo_cplx *out,

@@ -91,6 +91,16 @@ PROTOTYPES = {
     "fmd_fir_out_cap": (_sz, [C.c_uint32, C.c_uint32, _sz]),
     "fmd_fir_filter_batch": (C.c_int, [_vp, _vp, _sz, _vp, _sz, _szp]),
     "fmd_fir_filter_device": (C.c_int, [_vp, _vp, _sz, _vp, _sz, _szp, _vp]),
+    "fmd_firdemod_new": (C.c_int, [_i16p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(DeviceConfig), C.POINTER(_vp)]),
+    "fmd_firdemod_free": (None, [_vp]),
+    "fmd_firdemod_reset": (C.c_int, [_vp]),
+    "fmd_firdemod_out_cap": (_sz, [C.c_uint32, C.c_uint32, C.c_uint32, _sz]),
+    "fmd_firdemod_demodulate_batch": (C.c_int, [_vp, _vp, _sz, _vp, _sz, _szp]),
+    "fmd_firdemod_demodulate_device": (C.c_int, [_vp, _vp, _sz, _vp, _sz, _szp, _vp]),
+    "fmd_firdemod_check": (C.c_int, [_vp]),
+    "fmd_firdemod_get_state": (C.c_int, [_vp, C.c_uint32, C.POINTER(DemodState)]),
+    "fmd_firdemod_f64_stats": (C.c_int, [_vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
+    "fmd_firdemod_tiling": (C.c_int, [_vp, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
 }
 
 

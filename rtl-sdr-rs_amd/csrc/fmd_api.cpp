@@ -297,48 +297,57 @@ int host_polar_f64(int cr, int ci)
     return (int)(angle / 3.14159265358979323846264338327950288 * 16384.0);
 }
 
-// After the handle's work has completed: surface the device error word and re-evaluate the guarded f64 samples
+int resolve_device_reports(fmd_demod* d, int16_t* host_out, size_t host_cap);
+
+}  // namespace
+
+// Error text for the other translation units of the library (fmd_fir.hip).
+void fmd_internal_set_err(const char* msg) { set_err("%s", msg); }
+
+// After a handle's work has completed: surface the device error word and re-evaluate the guarded f64 samples
 // (FmdF64Exc) with the host libm.  A sample whose host value differs from the kernel's is patched -- in `host_out`
 // ([C][host_cap], the caller's copy of the most recent launch's output) when given, else in the device buffer the
-// launch wrote -- together with the carried partial sum when it lies in the trailing group.
-int resolve_device_reports(fmd_demod* d, int16_t* host_out, size_t host_cap)
+// launch wrote -- together with the carried partial sum (d_state_cur[channel].now_lpr) when it lies in the trailing
+// group.  Shared by fmd_demod and fmd_firdemod.
+int fmd_internal_resolve_exc(FmdExcBuf* d_exc, int32_t R, uint32_t cur_seq, FmdChanState* d_state_cur, int16_t* host_out,
+                             size_t host_cap, uint64_t* guarded, uint64_t* patched)
 {
     uint32_t head[4] = {0, 0, 0, 0};                        // err, count, guarded_total, pad
-    HIP_TRY(hipMemcpy(head, d->d_exc, sizeof(head), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(head, d_exc, sizeof(head), hipMemcpyDeviceToHost));
     if (head[0] & ~FMD_DEVERR_EXC_CAP) { set_err("device-side sizing assertion failed (bits 0x%x)", head[0]); return FMD_ERR_HIP; }
     if (head[1] == 0) return FMD_OK;
     const uint32_t n = head[1] < FMD_EXC_CAP ? head[1] : FMD_EXC_CAP;
     std::vector<FmdF64Exc> recs(n);
-    HIP_TRY(hipMemcpy(recs.data(), d->d_exc->rec, n * sizeof(FmdF64Exc), hipMemcpyDeviceToHost));
-    HIP_TRY(hipMemset(d->d_exc, 0, 16));
-    d->f64_guarded += head[1];
+    HIP_TRY(hipMemcpy(recs.data(), d_exc->rec, n * sizeof(FmdF64Exc), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemset(d_exc, 0, 16));
+    *guarded += head[1];
     int rc = FMD_OK;
     // several guarded samples may share one audio group (block_len mode): their corrections add up
     std::map<std::pair<uint32_t, uint64_t>, std::pair<int64_t, const FmdF64Exc*>> groups;   // (seq, out_elem) -> (delta, record)
     for (const FmdF64Exc& e : recs) {
         const int16_t want = (int16_t)host_polar_f64(e.cr, e.ci), have = (int16_t)e.d_gpu;
         if (want == have) continue;
-        d->f64_patched += 1;
+        *patched += 1;
         const int delta = (int)want - (int)have;
         if (e.k >= 0) {
             auto& g = groups[{e.seq, e.out_elem}];
             g.first += delta; g.second = &e;
-        } else if (e.seq == d->seq) {
+        } else if (e.seq == cur_seq) {
             int32_t now = 0;
-            int32_t* p = &d->d_state[d->cur][e.channel].now_lpr;
+            int32_t* p = &d_state_cur[e.channel].now_lpr;
             HIP_TRY(hipMemcpy(&now, p, sizeof(now), hipMemcpyDeviceToHost));
             now += delta;
             HIP_TRY(hipMemcpy(p, &now, sizeof(now), hipMemcpyHostToDevice));
         } else {
             set_err("a guarded f64 sample of launch %u (channel %u) lies in the carried partial sum and a later launch "
-                    "has already consumed it: call fmd_demod_check() after every fmd_demod_demodulate_device", e.seq, e.channel);
+                    "has already consumed it: call the handle's check function after every *_device launch", e.seq, e.channel);
             rc = FMD_ERR_HIP;
         }
     }
     for (const auto& kv : groups) {
         const FmdF64Exc& e = *kv.second.second;
-        const int16_t fixed = (int16_t)((e.sum + (int)kv.second.first) / d->r.R);      // low_pass_real, simple_fm.rs:421
-        if (host_out && e.seq == d->seq) host_out[(size_t)e.channel * host_cap + (size_t)e.k] = fixed;
+        const int16_t fixed = (int16_t)((e.sum + (int)kv.second.first) / R);              // low_pass_real, simple_fm.rs:421
+        if (host_out && e.seq == cur_seq) host_out[(size_t)e.channel * host_cap + (size_t)e.k] = fixed;
         else HIP_TRY(hipMemcpy((void*)(uintptr_t)e.out_elem, &fixed, sizeof(fixed), hipMemcpyHostToDevice));
     }
     if (head[0] & FMD_DEVERR_EXC_CAP) {
@@ -348,10 +357,12 @@ int resolve_device_reports(fmd_demod* d, int16_t* host_out, size_t host_cap)
     return rc;
 }
 
+namespace {
+int resolve_device_reports(fmd_demod* d, int16_t* host_out, size_t host_cap)
+{
+    return fmd_internal_resolve_exc(d->d_exc, d->r.R, d->seq, d->d_state[d->cur], host_out, host_cap, &d->f64_guarded, &d->f64_patched);
+}
 }  // namespace
-
-// Error text for the other translation units of the library (fmd_fir.hip).
-void fmd_internal_set_err(const char* msg) { set_err("%s", msg); }
 
 extern "C" {
 

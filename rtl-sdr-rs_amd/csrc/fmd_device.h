@@ -104,6 +104,118 @@ __device__ __forceinline__ FmdExcArgs exc_args(const FmdLaunch& L, uint32_t c, u
     return a;
 }
 
+typedef short fmd_s2 __attribute__((ext_vector_type(2)));
+
+// Two things tried around these helpers and withdrawn (both caught by tests/test_gpu_fuzz.py, downsample 2):
+//  * the dot products as inline-asm VOP3P forms (no v_mov of the addend into a v_dot*c destination, -0.5..1.2 %):
+//    on gfx950 a non-dot VALU instruction must not read a dot result for 3 wait states; hipcc inserts the
+//    s_nops for its own builtins but cannot see through inline asm, so correctness hung on instruction order;
+//  * bound_ctrl on the DPP moves (saves the v_mov 0 of `old`): the DPP-combine pass may then fold the move
+//    into a consumer that runs under the narrower EXEC mask of the predicated stores, where a masked-off
+//    neighbour lane reads as 0.
+__device__ __forceinline__ int sdot2(uint32_t a, uint32_t b)
+{
+    return __builtin_amdgcn_sdot2(__builtin_bit_cast(fmd_s2, a), __builtin_bit_cast(fmd_s2, b), 0, false);
+}
+
+// Demod::polar_discriminant_fast (:377-380) + fast_atan2 (:383-405), branch-free, for packed operands
+// (re | im << 16, components fit i16).  c = a * conj(b) is returned for the f64 sample.
+// Division: |quotient| <= 4097, so an f32 estimate is within 1 and one exact (wrapping) remainder fixes
+// it; valid while |x| + |y| < 2^30, which holds for every downsample <= 128 (|lp| <= 128 * D).  Same results
+// as fmd_fast_atan2 (tested).
+__device__ __forceinline__ int disc_fast(uint32_t a, uint32_t b)
+{
+    const uint32_t a_sw = __builtin_amdgcn_alignbit(a, a, 16);          // (im, re)
+    const uint32_t b_cj = (b & 0xFFFFu) | ((0u - (b >> 16)) << 16);      // (re, -im)
+    const int cr = sdot2(a, b);                                          // ar*br + ai*bi
+    const int ci = sdot2(a_sw, b_cj);                                    // ai*br - ar*bi
+    const uint32_t ux = (uint32_t)cr;
+    const uint32_t my = (uint32_t)(ci >> 31);                            // sign masks: (v ^ m) - m = m ? -v : v
+    const uint32_t yabs = ((uint32_t)ci ^ my) - my;
+    const uint32_t dif = ux - yabs, sum = ux + yabs;
+    const bool xpos = cr >= 0;
+    const int num = (int)((xpos ? dif : sum) << 12);                     // the i64 product truncated to i32 (:397,399)
+    const uint32_t den = xpos ? sum : yabs - ux;
+    const uint32_t mn = (uint32_t)(num >> 31);
+    const uint32_t unum = ((uint32_t)num ^ mn) - mn;
+    uint32_t q = (uint32_t)((float)unum * __builtin_amdgcn_rcpf((float)den));
+    const int rem = (int)(unum - q * den);
+    q = q + (rem >= (int)den ? 1u : 0u) - (rem < 0 ? 1u : 0u);
+    const uint32_t qs = (q ^ mn) - mn;                                   // truncating signed quotient
+    const uint32_t angle = (xpos ? (1u << 12) : (3u << 12)) - qs;
+    const uint32_t res = (angle ^ my) - my;
+    return den == 0u ? 0 : (int)res;                                     // x == 0 && y == 0 (:388)
+}
+
+// The same function without a single select, used by the masked-window loop: there hipcc turns disc_fast's
+// `?:` into VCC-masked v_cndmask_b32_e32, which issues ~4x slower than the SGPR-masked e64 form it picks in
+// the whole-dword loop (tools/valubench.hip).  Measured: this form -1.5 % at D = 7 in the masked loop, but
+// +1.2 ... 2.5 % in the whole-dword loop, which therefore keeps disc_fast.
+// With mx / my the sign masks of x / y:  den = |x| + |y| in both branches of :390-400, the numerator is
+// +-(|x| - |y|) with the sign of x, and the base angle is pi/4 + (x < 0 ? pi/2 : 0).
+__device__ __forceinline__ int disc_nosel(uint32_t a, uint32_t b)
+{
+    const uint32_t a_sw = __builtin_amdgcn_alignbit(a, a, 16);          // (im, re)
+    const uint32_t b_cj = (b & 0xFFFFu) | ((0u - (b >> 16)) << 16);      // (re, -im)
+    const int cr = sdot2(a, b);                                          // ar*br + ai*bi
+    const int ci = sdot2(a_sw, b_cj);                                    // ai*br - ar*bi
+    const uint32_t mx = (uint32_t)(cr >> 31), my = (uint32_t)(ci >> 31);
+    const uint32_t xabs = ((uint32_t)cr ^ mx) - mx, yabs = ((uint32_t)ci ^ my) - my;
+    const uint32_t den = xabs + yabs, t = xabs - yabs;
+    const int num = (int)(((t ^ mx) - mx) << 12);                        // the i64 product truncated to i32 (:397,399)
+    const uint32_t mn = (uint32_t)(num >> 31);
+    const uint32_t unum = ((uint32_t)num ^ mn) - mn;
+    uint32_t q = (uint32_t)((float)unum * __builtin_amdgcn_rcpf((float)den));
+    const int rem = (int)(unum - q * den);
+    q += (uint32_t)(rem >> 31);                                          // estimate one too large
+    q -= (uint32_t)(((int)den - 1 - rem) >> 31);                         // estimate one too small (rem >= den)
+    const uint32_t qs = (q ^ mn) - mn;                                   // truncating signed quotient
+    const uint32_t angle = (1u << 12) + (mx & (2u << 12)) - qs;
+    const uint32_t res = (angle ^ my) - my;
+    return (int)(res & (uint32_t)((int)(0u - den) >> 31));               // x == 0 && y == 0 -> 0 (:388)
+}
+
+// The same function in f32, for downsample <= 11 (FMD_DISC_F32_MAX_D): there |x| + |y| < 2^23, so every quantity
+// below is an integer that f32 holds exactly.  Why: on gfx950 only add / sub / and / or / xor / shift-right and f32
+// add / sub / mul (with their free abs / neg / clamp modifiers) issue in 2 cycles per wave; selects, compares,
+// conversions, integer multiplies, max ... take 4 (tools/valubench.hip).  This form is ~100 cycles against ~124 for
+// the integer one (-10 % on the whole launch at the reference's own rates).
+//   den = |x| + |y|;  s = x >= 0 ? x - |y| : x + |y| = +-(|x| - |y|)                          (:390-400)
+//   `(4096_i64 * s) as i32` keeps s mod 2^20 in [-2^19, 2^19): adding 1.5 * 2^43 (ulp 2^20) rounds s + 0.5 to a
+//     multiple of 2^20 -- never a tie, s is an integer -- and subtracting it again leaves k * 2^20, k = floor(s / 2^20 + 1/2)
+//   q = floor(4096 |sp| / den): the estimate uses 4096 (1 - 2^-21) so that rcp's ulp and two roundings (2^-22 in all)
+//     can only make it too SMALL, by < 0.004: floor() is q or q - 1; the remainder n4 - qf * den is exact in ONE fma
+//     (it is below 2 den < 2^24) and a clamped subtract turns `remainder >= den` into the +1
+//   the sign of the truncating quotient is sp's, the base angle is 8192 - (+-4096) by the sign of x, the result takes
+//     y's sign; (0, 0) -> den = 0 -> the final factor clamp(den + den) is 0 (:388), 1 otherwise.
+// tests/test_disc_f32_model.py replays this sequence in numpy f32 with the reciprocal pushed to both ends of its
+// 1-ulp band against fast_atan2 itself; the GPU parity and fuzz tests run it on the hardware.
+#define FMD_DISC_F32_MAX_D 11
+__device__ __forceinline__ float clamp01(float v) { return __builtin_amdgcn_fmed3f(v, 0.0f, 1.0f); }   // folds into a clamp modifier
+__device__ __forceinline__ float u2f(uint32_t u) { return __builtin_bit_cast(float, u); }
+__device__ __forceinline__ uint32_t f2u(float f) { return __builtin_bit_cast(uint32_t, f); }
+
+__device__ __forceinline__ int disc_f32(uint32_t a, uint32_t b)
+{
+    const uint32_t a_sw = __builtin_amdgcn_alignbit(a, a, 16);          // (im, re)
+    const uint32_t b_cj = (b & 0xFFFFu) | ((0u - (b >> 16)) << 16);      // (re, -im)
+    const float xf = (float)sdot2(a, b), yf = (float)sdot2(a_sw, b_cj);  // c = a * conj(b), exact
+    const float den = __builtin_fabsf(xf) + __builtin_fabsf(yf);
+    const float t = __builtin_fabsf(xf) - __builtin_fabsf(yf);
+    const uint32_t sx = f2u(xf) & 0x80000000u;
+    const float s = u2f(f2u(t) ^ sx);
+    const float big = 13194139533312.0f;                                 // 1.5 * 2^43
+    const float sp = s - (((s + 0.5f) + big) - big);                     // s mod 2^20, signed
+    const float c = __builtin_amdgcn_rcpf(den + 0x1p-30f) * 4095.998046875f;   // + 2^-30: finite for den == 0, no change otherwise
+    const float qf = __builtin_floorf(__builtin_fabsf(sp) * c);
+    const float r = __builtin_fmaf(-qf, den, __builtin_fabsf(sp) * 4096.0f);
+    const float q = qf + clamp01(r - (den - 1.0f));
+    const float qs = u2f(f2u(q) ^ (f2u(sp) & 0x80000000u));
+    const float base = 8192.0f - u2f(0x45800000u ^ sx);                  // 4096 or 12288 (:395,400)
+    const float res = u2f(f2u(base - qs) ^ (f2u(yf) & 0x80000000u));
+    return (int)(res * clamp01(den + den));
+}
+
 // Decimated samples travel packed: re in the low, im in the high 16 bits (|lp| <= 128 * D <= 16384).
 __device__ __forceinline__ uint32_t pack_lp(int re, int im) { return ((uint32_t)re & 0xFFFFu) | ((uint32_t)im << 16); }
 __device__ __forceinline__ int lp_re(uint32_t p) { return (int)(int16_t)(p & 0xFFFFu); }

@@ -32,6 +32,7 @@
 #include <new>
 #include <vector>
 
+#include "fmd_fir_common.h"
 #include "fmd_host.h"
 
 namespace {
@@ -499,42 +500,14 @@ int fmd_fir_new(const int16_t* taps, uint32_t n_taps, uint32_t decim, const fmd_
     // offset v from the window start of output i = 0; fragment order [chunk][lane = row + 16*q][16 bytes].
     std::vector<uint32_t> amat;
     const char* env_mfma = getenv("FMD_FIR_MFMA");
-    const uint32_t nk_tot = (2u * (3u * decim + n_taps) + 63u) / 64u;
-    if (decim <= 64 && nk_tot <= 64 && !(env_mfma && env_mfma[0] == '0')) {
-        f->n_pass = (nk_tot + 7u) / 8u;
-        f->nku = (nk_tot + f->n_pass - 1u) / f->n_pass;
+    FmdFirMfmaPlan plan;
+    if (!(env_mfma && env_mfma[0] == '0') && fmd_fir_build_mfma(taps, n_taps, decim, plan)) {
+        f->n_pass = plan.n_pass; f->nku = plan.nku;
         uint32_t groups = 16384u / (128u * decim);
         f->groups = groups < 1u ? 1u : (groups > 16u ? 16u : groups);
         if (const char* eg = getenv("FMD_FIR_GROUPS")) { const uint32_t g = (uint32_t)atoi(eg); if (g >= 1 && g <= 4u * kFirGroupsPerWave) f->groups = g; }   // tuning
-        const uint32_t chunks = f->n_pass * f->nku;
-        amat.assign((size_t)chunks * 64 * 4, 0u);
-        uint8_t* ab = reinterpret_cast<uint8_t*>(amat.data());
-        for (uint32_t kk = 0; kk < chunks; ++kk)
-            for (uint32_t lane = 0; lane < 64; ++lane)
-                for (uint32_t b = 0; b < 16; ++b) {
-                    const uint32_t r = lane & 15u, i = r >> 2, reg = r & 3u;
-                    const int64_t rel = (int64_t)(64u * kk + 16u * (lane >> 4) + b) - 2ll * decim * i;
-                    if (rel < 0 || rel >= 2ll * n_taps) continue;
-                    const uint32_t t = (uint32_t)rel >> 1, sg = (uint32_t)rel & 1u;
-                    const uint32_t phase = (t + 2u * ((decim / 2u * i) & 1u)) & 3u;
-                    int sign;
-                    if ((reg >> 1) == 0) sign = (phase == 0 && sg == 0) || (phase == 3 && sg == 1) ? 1
-                                              : (phase == 1 && sg == 1) || (phase == 2 && sg == 0) ? -1 : 0;
-                    else sign = (phase == 0 && sg == 1) || (phase == 1 && sg == 0) ? 1
-                              : (phase == 2 && sg == 1) || (phase == 3 && sg == 0) ? -1 : 0;
-                    const int h = taps[t];
-                    const int lo = ((h + 64) & 127) - 64, hi = (h - lo) / 128;      // h = 128*hi + lo, both i8
-                    ab[((size_t)kk * 64 + lane) * 16 + b] = (uint8_t)(int8_t)(sign * ((reg & 1u) ? hi : lo));
-                }
-        for (int par = 0; par < 2; ++par) {
-            int64_t sr = 0, si = 0;
-            for (uint32_t t = 0; t < n_taps; ++t) {
-                const uint32_t phase = (t + 2u * par) & 3u;
-                if (phase == 0 || phase == 3) sr += taps[t];
-                if (phase == 0 || phase == 1) si += taps[t];
-            }
-            f->mre[par] = (int32_t)sr; f->mim[par] = (int32_t)si;
-        }
+        amat.swap(plan.amat);
+        for (int par = 0; par < 2; ++par) { f->mre[par] = plan.mre[par]; f->mim[par] = plan.mim[par]; }
     }
     auto fail = [&](const char* what) { fmd_internal_set_err(what); fmd_fir_free(f); return FMD_ERR_HIP; };
     FmdDeviceGuard guard(device);                         // the caller's current device comes back on return

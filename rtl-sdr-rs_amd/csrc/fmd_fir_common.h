@@ -1,0 +1,58 @@
+// fmd_fir_common.h -- host-side construction of the banded Toeplitz tap matrix the matrix-core FIR kernels use
+// (fmd_fir.hip: stand-alone operator; fmd_firdemod.hip: FIR fused with the discriminator and the resampler).
+// See the header comment of fmd_fir.hip for the data path.
+#ifndef FMD_FIR_COMMON_H
+#define FMD_FIR_COMMON_H
+
+#include <stdint.h>
+
+#include <vector>
+
+struct FmdFirMfmaPlan {
+    std::vector<uint32_t> amat;   // [n_pass * nku][64 lanes][4 dwords]: A fragments, K index = byte offset from the window start of output 0
+    uint32_t n_pass = 0, nku = 0; // K-chunks of 64 bytes = n_pass * nku
+    int32_t mre[2] = {0, 0}, mim[2] = {0, 0};   // additive constants (s8 domain) by window parity
+};
+
+// Rows r = 4*i + reg (i: output within the quad, reg: re_lo, re_hi, im_lo, im_hi), taps split as h = 128*hi + lo with
+// |lo| <= 64, |hi| <= 16 (both i8), rotate_90's signs (simple_fm.rs:276-299) and the re / im byte selection folded in.
+// Returns false when the shape does not fit the matrix-core form (decim > 64 or more than 64 K-chunks).
+inline bool fmd_fir_build_mfma(const int16_t* taps, uint32_t n_taps, uint32_t decim, FmdFirMfmaPlan& P)
+{
+    const uint32_t nk_tot = (2u * (3u * decim + n_taps) + 63u) / 64u;
+    if (decim > 64 || nk_tot > 64) return false;
+    P.n_pass = (nk_tot + 7u) / 8u;
+    P.nku = (nk_tot + P.n_pass - 1u) / P.n_pass;
+    const uint32_t chunks = P.n_pass * P.nku;
+    P.amat.assign((size_t)chunks * 64 * 4, 0u);
+    uint8_t* ab = reinterpret_cast<uint8_t*>(P.amat.data());
+    for (uint32_t kk = 0; kk < chunks; ++kk)
+        for (uint32_t lane = 0; lane < 64; ++lane)
+            for (uint32_t b = 0; b < 16; ++b) {
+                const uint32_t r = lane & 15u, i = r >> 2, reg = r & 3u;
+                const int64_t rel = (int64_t)(64u * kk + 16u * (lane >> 4) + b) - 2ll * decim * i;
+                if (rel < 0 || rel >= 2ll * n_taps) continue;
+                const uint32_t t = (uint32_t)rel >> 1, sg = (uint32_t)rel & 1u;
+                const uint32_t phase = (t + 2u * ((decim / 2u * i) & 1u)) & 3u;
+                int sign;
+                if ((reg >> 1) == 0) sign = (phase == 0 && sg == 0) || (phase == 3 && sg == 1) ? 1
+                                          : (phase == 1 && sg == 1) || (phase == 2 && sg == 0) ? -1 : 0;
+                else sign = (phase == 0 && sg == 1) || (phase == 1 && sg == 0) ? 1
+                          : (phase == 2 && sg == 1) || (phase == 3 && sg == 0) ? -1 : 0;
+                const int h = taps[t];
+                const int lo = ((h + 64) & 127) - 64, hi = (h - lo) / 128;      // h = 128*hi + lo, both i8
+                ab[((size_t)kk * 64 + lane) * 16 + b] = (uint8_t)(int8_t)(sign * ((reg & 1u) ? hi : lo));
+            }
+    for (int par = 0; par < 2; ++par) {
+        int64_t sr = 0, si = 0;
+        for (uint32_t t = 0; t < n_taps; ++t) {
+            const uint32_t phase = (t + 2u * par) & 3u;
+            if (phase == 0 || phase == 3) sr += taps[t];
+            if (phase == 0 || phase == 1) si += taps[t];
+        }
+        P.mre[par] = (int32_t)sr; P.mim[par] = (int32_t)si;
+    }
+    return true;
+}
+
+#endif  // FMD_FIR_COMMON_H

@@ -1,0 +1,623 @@
+// fmd_firdemod.hip -- tapped decimating FIR -> FM discriminator -> audio resampler in ONE gfx950 kernel
+// (BASELINE north_star: "the FIR + demod + resample stages fused into one CDNA4 kernel").
+//
+// Definition (include/fmd.h, oracle/fm_oracle.h): Demod::demodulate (examples/simple_fm.rs:256-269) with
+// low_pass_complex (:337-352) replaced by   lp[m] = floor( sum_t h[t] * x[M*m + t] / 2^shift )   over the rotated
+// (:276-299) and centred (:258) stream; fm_demod (:355-367, f64 sample at the first output of every call) and
+// low_pass_real (:408-426) are the reference's.  With h = 1...1, T = M = downsample, shift = 0 it IS the reference
+// chain -- that reduction is tested bit for bit and is the operator's anchor.
+//
+// One workgroup = one tile of `kt` audio samples of one channel-call, geometry by the same closed-form algebra as
+// the boxcar kernel (fmd_index.h: decimated samples jA-1 .. jB, audio groups by (eq, er)); per tile:
+//   1. stage the raw bytes of the FIR windows of outputs max(jA-1, 0) .. jB (LDS-DMA; through registers when the
+//      tile touches the history or is not 16-byte aligned),
+//   2. FIR on the matrix cores exactly as fmd_fir.hip (v_mfma_i32_16x16x64_i8 over the byte stream against the
+//      banded tap matrix); instead of 8 bytes per output going to HBM the normalised sample is packed to
+//      re | im << 16 and kept in LDS,
+//   3. discriminator per output against its predecessor (disc_nosel: |lp| <= 16384 is enforced at creation; the f64
+//      sample of the call start on one lane, guarded like the boxcar kernel's),
+//   4. low_pass_real: 16 lanes per audio sample sum its group (decimation ratios of a tapped front end are large:
+//      52 discriminator samples per audio sample at 2.5 Msps -> 48 kHz), DPP reduction, one exact small divide.
+// HBM traffic: the u8 input once + 2 bytes per AUDIO sample (the stand-alone FIR writes 8 bytes per output).
+#include "../../include/fmd.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "fmd_device.h"
+#include "fmd_fir_common.h"
+#include "fmd_host.h"
+#include "fmd_kernels.h"
+
+int fmd_internal_resolve_exc(FmdExcBuf* d_exc, int32_t R, uint32_t cur_seq, FmdChanState* d_state_cur, int16_t* host_out,
+                             size_t host_cap, uint64_t* guarded, uint64_t* patched);
+
+namespace {
+
+using namespace fmd_dev;
+
+#if defined(__HIP_DEVICE_COMPILE__)
+#define FMD_AS_GLOBAL __attribute__((address_space(1)))
+#else
+#define FMD_AS_GLOBAL
+#endif
+
+constexpr int kThreads = 256;
+constexpr int kGroupsPerWave = 4;                         // a wave accumulates up to 4 column groups (64 outputs each)
+constexpr uint32_t kMaxOutputs = 64u * 4u * kGroupsPerWave;   // FIR outputs one tile can form
+typedef int fd_i4 __attribute__((ext_vector_type(4)));
+
+struct FirDemodLaunch {
+    // ---- FIR (same meaning as FirLaunch in fmd_fir.hip) ----
+    const uint32_t* iq;        // [C][stride_w] dwords
+    uint64_t stride_w;         // dwords per channel in this call
+    const uint32_t* hist_in;   // [C][Hw]
+    uint32_t* hist_out;
+    uint32_t Hw, NP, half_M;
+    uint32_t wd_first;         // virtual dword (history ++ call) of the window of the call's first output
+    uint32_t par_first;        // stream-dword parity of that window
+    const uint32_t* amat;
+    uint32_t n_pass, col_bytes, shift;
+    int32_t mre[2], mim[2];
+    uint32_t n_channels, tiles, xcd;
+    // ---- demod (fmd_index.h) ----
+    FmdRates r;
+    FmdClassPlan P;            // M = FIR outputs of this call, K = audio samples, nt, eq0, er0 (p0 = 0)
+    FmdTiling tl;
+    uint32_t fa, fb;
+    float inv_sr, inv_R;
+    uint32_t lp_cap, raw_bytes;
+    const FmdChanState* st_in;
+    FmdChanState* st_out;
+    int16_t* out;
+    uint64_t out_stride;
+    FmdExcBuf* exc;
+    double f64_guard;
+    uint32_t seq;
+    int32_t f64_skew;
+};
+
+__device__ __forceinline__ uint32_t virt_dword(const FirDemodLaunch& L, uint32_t c, uint32_t w)
+{
+    typedef const FMD_AS_GLOBAL uint32_t* gw;
+    if (w < L.Hw) return ((gw)(uintptr_t)L.hist_in)[(uint64_t)c * L.Hw + w];
+    uint64_t k = w - L.Hw;
+    if (k >= L.stride_w) k = L.stride_w - 1;              // the zero-weighted pad sample of an odd tap count
+    return ((gw)(uintptr_t)L.iq)[(uint64_t)c * L.stride_w + k];
+}
+
+__device__ __forceinline__ fd_i4 virt_chunk(const FirDemodLaunch& L, uint32_t c, uint32_t w, bool fast)
+{
+    fd_i4 v;
+    if (fast && w >= L.Hw && (uint64_t)(w - L.Hw) + 4 <= L.stride_w) {
+        typedef const FMD_AS_GLOBAL fd_i4* gq;
+        v = *(gq)(uintptr_t)(L.iq + (uint64_t)c * L.stride_w + (w - L.Hw));
+    } else {
+        v.x = (int)virt_dword(L, c, w);     v.y = (int)virt_dword(L, c, w + 1);
+        v.z = (int)virt_dword(L, c, w + 2); v.w = (int)virt_dword(L, c, w + 3);
+    }
+    return v;
+}
+
+__device__ __forceinline__ void dma16(const unsigned char* g, unsigned char* lds_wave_base)
+{
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 2 /* nt */);
+}
+
+// sum over the 16 lanes of a row (lanes 16k .. 16k+15): four DPP row shifts
+__device__ __forceinline__ int row_sum16(int v)
+{
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118 /* row_shr:8 */, 0xf, 0xf, true);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114 /* row_shr:4 */, 0xf, 0xf, true);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112 /* row_shr:2 */, 0xf, 0xf, true);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111 /* row_shr:1 */, 0xf, 0xf, true);
+    return v;                                                // lane 15 of the row holds the total
+}
+
+template <int NKU>
+__global__ void __launch_bounds__(kThreads) fmd_firdemod_kernel(const FirDemodLaunch L)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    __builtin_amdgcn_s_setprio(3);                           // get the loads out first (see fmd_tile_kernel.hip)
+    uint32_t c, t;
+    if (L.xcd == 3u) { c = blockIdx.x * gridDim.z + blockIdx.z; t = blockIdx.y; }   // grid (8, tiles, ceil(C / 8))
+    else { c = blockIdx.y + 65535u * blockIdx.z; t = blockIdx.x; }
+    if (c >= L.n_channels || t >= L.P.nt) return;
+
+    const FmdRates& r = L.r;
+    const FmdClassPlan& P = L.P;
+    const FmdTile T = fmd_tile_fast(r, P, L.tl, 0u, t);      // k0, k1, jA, jB, eq, er (its input range is the boxcar's: unused)
+    const int jfirst = T.jA - 1, cnt = T.jB - jfirst + 1;    // lp[jfirst .. jB]; lp[-1] is demod_pre
+    const uint32_t o0 = jfirst > 0 ? (uint32_t)jfirst : 0u;  // first FIR output (of this call) the tile forms
+    const uint32_t no = (uint32_t)T.jB - o0 + 1u;            // FIR outputs formed
+    const uint32_t w0 = L.wd_first + o0 * L.half_M;          // first virtual dword of the tile
+    const uint32_t nq = ((((no - 1) * L.half_M + L.NP + 3u) >> 2) + 3u) & ~3u;   // 16-byte slots, whole 64-byte chunks
+    if ((uint32_t)cnt > L.lp_cap || nq * 16u > L.raw_bytes || no > kMaxOutputs) {
+        if (tid == 0) atomicOr(&L.exc->err, (uint32_t)cnt > L.lp_cap ? FMD_DEVERR_LP_CAP : FMD_DEVERR_RAW_CAP);
+        return;
+    }
+    uint32_t* const ypk = lds + (L.raw_bytes >> 2);          // packed lp[jfirst + i], i = 0 .. cnt-1
+    int16_t* const d16 = reinterpret_cast<int16_t*>(ypk + L.lp_cap + 1u);
+
+    const uint32_t j = lane & 15u, q = lane >> 4;
+    typedef const FMD_AS_GLOBAL fd_i4* gq;
+    const gq amat = (gq)(uintptr_t)L.amat + lane;
+    fd_i4 A[NKU];                                            // first pass' tap fragments: in flight with the data
+#pragma unroll
+    for (int k = 0; k < NKU; ++k) A[k] = amat[k * 64];
+
+    const bool fast = ((((uintptr_t)L.iq + ((uint64_t)c * L.stride_w + (uint64_t)w0 - L.Hw) * 4u)) & 15u) == 0u;
+    const bool whole = fast && w0 >= L.Hw && (uint64_t)(w0 - L.Hw) + 4ull * nq <= L.stride_w;
+    fd_i4* lq = reinterpret_cast<fd_i4*>(lds);
+    if (whole) {
+        const unsigned char* src = reinterpret_cast<const unsigned char*>(L.iq + (uint64_t)c * L.stride_w + (w0 - L.Hw)) + 16u * tid;
+        unsigned char* dst = reinterpret_cast<unsigned char*>(lds) + 1024u * wave;
+        const uint32_t nfull = nq / kThreads, ntail = nq - nfull * kThreads;
+        for (uint32_t l = 0; l < nfull; ++l) dma16(src + (16u * kThreads) * l, dst + (16u * kThreads) * l);
+        if (tid < ntail) dma16(src + (16u * kThreads) * nfull, dst + (16u * kThreads) * nfull);
+    } else {
+        for (uint32_t i = tid; i < nq; i += kThreads) lq[i] = virt_chunk(L, c, w0 + 4u * i, fast);
+    }
+    FmdChanState st{};
+    if (jfirst < 0 || T.k0 == 0 || T.last) st = L.st_in[c];
+    __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_s_waitcnt(0x0F70);                      // vmcnt(0): the LDS-DMAs (and the A fragments) have landed
+    __syncthreads();
+
+    // ---- FIR on the matrix cores (see fmd_fir.hip) -----------------------------------------------------------
+    const uint8_t* lb = reinterpret_cast<const uint8_t*>(lds);
+    const uint32_t groups = (no + 63u) >> 6;
+    fd_i4 acc[kGroupsPerWave];
+#pragma unroll
+    for (int gi = 0; gi < kGroupsPerWave; ++gi) acc[gi] = fd_i4{0, 0, 0, 0};
+    for (uint32_t pass = 0; pass < L.n_pass; ++pass) {
+        if (pass) {
+#pragma unroll
+            for (int k = 0; k < NKU; ++k) A[k] = amat[(pass * NKU + k) * 64u];
+        }
+#pragma unroll
+        for (int gi = 0; gi < kGroupsPerWave; ++gi) {
+            const uint32_t g = wave + 4u * gi;
+            if (g < groups) {                                // wave-uniform
+                const uint8_t* col = lb + (16u * g + j) * L.col_bytes + 64u * NKU * pass;
+#pragma unroll
+                for (int k = 0; k < NKU; ++k) {
+                    const fd_i4 B = *reinterpret_cast<const fd_i4*>(col + 64 * k + 16u * q) ^ (int)0x80808080;   // u8 -> s8
+                    acc[gi] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A[k], B, acc[gi], 0, 0, 0);
+                }
+            }
+        }
+    }
+    // lane (j, q) holds (re_lo, re_hi, im_lo, im_hi) of the tile's output 64 g + 4 j + q: combine the tap digits, add
+    // the window-parity constant, normalise, pack to re | im << 16 and keep it in LDS
+    const uint32_t par_tile = (L.par_first + o0 * L.half_M) & 1u;
+    const uint32_t par = (par_tile ^ (L.half_M * q)) & 1u;
+    const int cre = L.mre[par], cim = L.mim[par];
+#pragma unroll
+    for (int gi = 0; gi < kGroupsPerWave; ++gi) {
+        const uint32_t g = wave + 4u * gi;
+        const uint32_t o = 64u * g + 4u * j + q;
+        if (g < groups && o < no) {
+            int re = acc[gi].x + (acc[gi].y << 7), im = acc[gi].z + (acc[gi].w << 7);
+            if (par_tile) { re = -re; im = -im; }
+            re = (re + cre) >> L.shift; im = (im + cim) >> L.shift;          // floor(y / 2^shift)
+            ypk[(int)(o0 + o) - jfirst] = pack_lp(re, im);
+        }
+    }
+    if (jfirst < 0 && tid == 0) ypk[0] = pack_lp(st.demod_pre_re, st.demod_pre_im);     // lp[-1]
+    // the channel's last tile also writes the next call's history (the raw bytes are all in global memory)
+    if (T.last) {
+        typedef const FMD_AS_GLOBAL uint32_t* gw;
+        for (uint32_t k = tid; k < L.Hw; k += kThreads) {
+            const uint64_t w = L.stride_w + k;               // virtual dword (history ++ call), < Hw + stride_w
+            L.hist_out[(uint64_t)c * L.Hw + k] = w < L.Hw ? ((gw)(uintptr_t)L.hist_in)[(uint64_t)c * L.Hw + w]
+                                                         : ((gw)(uintptr_t)L.iq)[(uint64_t)c * L.stride_w + (w - L.Hw)];
+        }
+    }
+    __syncthreads();
+
+    // ---- fm_demod (:355-367): every sample against its predecessor ---------------------------------------------
+    bool any_guard = false;
+    for (int i = (int)tid + 1; i < cnt; i += kThreads) {
+        const uint32_t a = ypk[i], b = ypk[i - 1];
+        int d;
+        if (jfirst + i == 0) {                               // the first sample of the call: f64 path (:359), tid 0
+            int cr, ci;
+            fmd_mul_conj(lp_re(a), lp_im(a), lp_re(b), lp_im(b), cr, ci);
+            bool g;
+            d = polar_f64(cr, ci, L.f64_guard, &g);
+#ifdef FMD_EXPERIMENT
+            if (g) d += L.f64_skew;
+#endif
+            any_guard = g;
+        } else d = disc_nosel(a, b);                         // (:362)
+        d16[i] = (int16_t)d;
+    }
+    __syncthreads();
+
+    // ---- low_pass_real (:408-426): 16 lanes per audio sample ---------------------------------------------------
+    const uint32_t nk = T.k1 - T.k0, sub = tid & 15u;
+    int16_t* const outc = L.out + (uint64_t)c * L.out_stride;
+    for (uint32_t q0 = 0; q0 < nk; q0 += kThreads / 16) {    // uniform trip count: the DPP reduction needs whole rows
+        const uint32_t qa = q0 + (tid >> 4);
+        int sum = 0;
+        if (qa < nk) {
+            const uint32_t x = T.er + qa * L.fb;
+            const uint32_t u = fmd_udiv_small(x, r.sr, L.inv_sr);
+            const bool extra = x - u * r.sr < L.fb;
+            const int e = (int)(T.eq + qa * L.fa + u);
+            int s = e - (int)L.fa + (extra ? 0 : 1);
+            s = s > 0 ? s : 0;                               // the call's first group starts at 0
+            for (int jj = s + (int)sub; jj <= e; jj += 16) sum += d16[jj - jfirst];
+        }
+        sum = row_sum16(sum);
+        if (qa < nk && sub == 15u) {
+            if (T.k0 + qa == 0u) sum += st.now_lpr;          // continues the previous call's partial sum (:410-417)
+            outc[T.k0 + qa] = (int16_t)fmd_sdiv_small(sum, r.R, L.inv_R);
+        }
+    }
+    if (jfirst < 0 && tid == 0 && any_guard) {               // guarded f64 sample (FmdF64Exc, fmd_kernels.h)
+        int cr, ci;
+        fmd_mul_conj(lp_re(ypk[1]), lp_im(ypk[1]), lp_re(ypk[0]), lp_im(ypk[0]), cr, ci);
+        FmdExcArgs a;
+        a.sr = r.sr; a.fr = r.fr; a.i0r = P.i0r; a.K = P.K; a.c = c; a.seq = L.seq;
+        a.now_lpr_in = st.now_lpr; a.jfirst = jfirst; a.d16 = d16; a.out_c = outc; a.exc = L.exc;
+        exc_emit(a, 0, cr, ci);
+    }
+
+    // ---- state after the call (last tile; simple_fm.rs:232-239) --------------------------------------------------
+    if (T.last && tid == 0) {
+        FmdChanState ns_{};
+        const int s = P.K == 0 ? 0 : (int)fmd_audio_end(r, P.i0r, P.K - 1) + 1;
+        int sum = P.K == 0 ? st.now_lpr : 0;
+        for (int jj = s; jj <= T.jB; ++jj) sum += d16[jj - jfirst];
+        ns_.now_lpr = sum;
+        ns_.lpr_index_r = fmd_next_lpr_index_r(r, P.i0r, P.M, P.K);
+        const uint32_t l = ypk[cnt - 1];                     // demod_pre = the last filter output (M >= 2 guaranteed by the host)
+        ns_.demod_pre_re = lp_re(l); ns_.demod_pre_im = lp_im(l);
+        L.st_out[c] = ns_;
+    }
+}
+
+template <int NKU>
+void launch(const FirDemodLaunch& L, dim3 g, size_t lds, hipStream_t s)
+{
+    hipLaunchKernelGGL(fmd_firdemod_kernel<NKU>, g, dim3(kThreads), lds, s, L);
+}
+
+#define FD_TRY(expr)                                                                        \
+    do {                                                                                    \
+        hipError_t e_ = (expr);                                                             \
+        if (e_ != hipSuccess) {                                                             \
+            char m_[256];                                                                   \
+            snprintf(m_, sizeof m_, "%s failed: %s", #expr, hipGetErrorString(e_));         \
+            fmd_internal_set_err(m_);                                                       \
+            return e_ == hipErrorOutOfMemory ? FMD_ERR_NOMEM : FMD_ERR_HIP;                 \
+        }                                                                                   \
+    } while (0)
+
+#define FD_ON_DEVICE(dev)                                                                   \
+    FmdDeviceGuard dev_guard_(dev);                                                         \
+    if (dev_guard_.error() != hipSuccess) { fmd_internal_set_err("hipSetDevice failed"); return FMD_ERR_HIP; }
+
+}  // namespace
+
+struct fmd_firdemod {
+    uint32_t T = 0, M = 0, C = 0, NP = 0, Hw = 0, shift = 0;
+    int device = 0;
+    uint64_t pos = 0;                                     // samples consumed per channel
+    FmdFirMfmaPlan plan;
+    uint32_t* d_amat = nullptr;
+    uint32_t* d_hist[2] = {nullptr, nullptr};
+    FmdChanState* d_state[2] = {nullptr, nullptr};
+    int cur = 0;
+    FmdRates r{};
+    uint32_t i0r = 0;                                     // resampler phase of every channel (host mirror)
+    uint32_t last_K = 0;
+    uint32_t lp_cap = 0, raw_bytes = 0;
+    FmdExcBuf* d_exc = nullptr;
+    double f64_guard = 0x1p-20;
+    int32_t f64_skew = 0;
+    uint32_t seq = 0;
+    uint64_t f64_guarded = 0, f64_patched = 0;
+    FmdStreamOrder order;
+    hipStream_t stream = nullptr;
+    uint8_t* d_iq = nullptr; size_t d_iq_cap = 0;
+    int16_t* d_out = nullptr; size_t d_out_cap = 0;
+};
+
+namespace {
+
+void fd_counts(const fmd_firdemod* f, uint64_t ns, uint64_t* m0, uint64_t* m1)
+{
+    const uint64_t S = f->pos, T = f->T, M = f->M;
+    *m0 = S >= T ? (S - T) / M + 1 : 0;
+    *m1 = S + ns >= T ? (S + ns - T) / M + 1 : 0;
+}
+
+// LDS per tile for `kt` audio samples: raw bytes of the windows + packed samples + discriminator samples
+bool fd_sizes(const fmd_firdemod* f, uint32_t kt, uint32_t* lp_cap, uint32_t* raw_bytes, size_t* lds)
+{
+    FmdRates r = f->r; r.kt = kt;
+    const uint32_t cap = fmd_tile_lp_cap(r);
+    if (cap > kMaxOutputs) return false;
+    const uint32_t half_M = f->M / 2;
+    const uint64_t staged = (((((uint64_t)(cap - 1) * half_M + f->NP + 3) / 4) + 3) & ~(uint64_t)3) * 16;
+    const uint64_t touched = (uint64_t)16 * ((cap + 63) / 64) * (8u * f->M) + (uint64_t)64 * f->plan.n_pass * f->plan.nku;
+    const uint64_t raw = ((staged > touched ? staged : touched) + 15) & ~(uint64_t)15;
+    const uint64_t total = raw + 4ull * (cap + 1) + 2ull * (cap + 8) + 16;
+    if (total > 60 * 1024) return false;
+    *lp_cap = cap; *raw_bytes = (uint32_t)raw; *lds = (size_t)total;
+    return true;
+}
+
+int fd_enqueue(fmd_firdemod* f, const void* d_iq, size_t nbytes, void* d_out, size_t out_cap, size_t* n_each, hipStream_t stream)
+{
+    if (nbytes % 8 != 0) { fmd_internal_set_err("nbytes % 8 != 0 (simple_fm.rs:286 would panic)"); return FMD_ERR_BAD_LENGTH; }
+    if (nbytes == 0 || nbytes > (1ull << 31)) { fmd_internal_set_err("nbytes out of range"); return FMD_ERR_UNSUPPORTED; }
+    if (((uintptr_t)d_iq & 3u) != 0 || ((uintptr_t)d_out & 1u) != 0) { fmd_internal_set_err("misaligned device buffer"); return FMD_ERR_INVALID_ARG; }
+    const uint64_t ns = nbytes / 2;
+    uint64_t m0, m1;
+    fd_counts(f, ns, &m0, &m1);
+    const uint64_t Mdec = m1 - m0;
+    if (Mdec < 2) { fmd_internal_set_err("the call yields fewer than 2 filter outputs (simple_fm.rs:356 asserts > 1)"); return FMD_ERR_TOO_SHORT; }
+    FmdRates r = f->r;
+    if (!fmd_ranges_fit32(r, Mdec * r.D)) { fmd_internal_set_err("call exceeds the 32-bit index range for these rates"); return FMD_ERR_UNSUPPORTED; }
+    FirDemodLaunch L{};
+    L.P = fmd_make_plan(r, 0u, f->i0r, 0u);
+    L.P.M = (uint32_t)Mdec;
+    L.P.K = fmd_num_audio(r, f->i0r, L.P.M);
+    L.P.nt = fmd_num_tiles(r, L.P.K);
+    if (L.P.K > out_cap) { fmd_internal_set_err("out_cap too small"); return FMD_ERR_CAPACITY; }
+    L.iq = static_cast<const uint32_t*>(d_iq);
+    L.stride_w = nbytes / 4;
+    L.hist_in = f->d_hist[f->cur]; L.hist_out = f->d_hist[f->cur ^ 1];
+    L.Hw = f->Hw; L.NP = f->NP; L.half_M = f->M / 2;
+    const uint64_t vs0 = f->M * m0 + 2ull * f->Hw - f->pos;      // virtual sample index of the first window (even)
+    L.wd_first = (uint32_t)(vs0 / 2);
+    L.par_first = (uint32_t)((f->M * m0 / 2) & 1u);
+    L.amat = f->d_amat; L.n_pass = f->plan.n_pass; L.col_bytes = 8u * f->M; L.shift = f->shift;
+    for (int p = 0; p < 2; ++p) { L.mre[p] = f->plan.mre[p]; L.mim[p] = f->plan.mim[p]; }
+    L.n_channels = f->C; L.tiles = L.P.nt;
+    L.r = r; L.tl = fmd_make_tiling(r);
+    L.fa = r.fr / r.sr; L.fb = r.fr % r.sr;
+    L.inv_sr = 1.0f / (float)r.sr; L.inv_R = 1.0f / (float)r.R;
+    L.lp_cap = f->lp_cap; L.raw_bytes = f->raw_bytes;
+    L.st_in = f->d_state[f->cur]; L.st_out = f->d_state[f->cur ^ 1];
+    L.out = static_cast<int16_t*>(d_out); L.out_stride = out_cap;
+    L.exc = f->d_exc; L.f64_guard = f->f64_guard; L.seq = f->seq + 1; L.f64_skew = f->f64_skew;
+    uint32_t lc, rb; size_t lds;
+    if (!fd_sizes(f, r.kt, &lc, &rb, &lds)) { fmd_internal_set_err("tile sizing failed"); return FMD_ERR_UNSUPPORTED; }
+    FD_TRY(f->order.before(stream));
+    const uint32_t per = (f->C + 7u) / 8u;
+    dim3 g(L.tiles, f->C < 65535u ? f->C : 65535u, (f->C + 65534u) / 65535u);
+    if (f->C >= 8u && L.tiles <= 65535u && per <= 65535u) { g = dim3(8u, L.tiles, per); L.xcd = 3u; }
+    switch (f->plan.nku) {
+        case 1: launch<1>(L, g, lds, stream); break;
+        case 2: launch<2>(L, g, lds, stream); break;
+        case 3: launch<3>(L, g, lds, stream); break;
+        case 4: launch<4>(L, g, lds, stream); break;
+        case 5: launch<5>(L, g, lds, stream); break;
+        case 6: launch<6>(L, g, lds, stream); break;
+        case 7: launch<7>(L, g, lds, stream); break;
+        default: launch<8>(L, g, lds, stream); break;
+    }
+    FD_TRY(hipGetLastError());
+    f->order.after(stream);
+    f->seq += 1;
+    f->cur ^= 1;
+    f->i0r = fmd_next_lpr_index_r(r, f->i0r, L.P.M, L.P.K);
+    f->pos += ns;
+    f->last_K = L.P.K;
+    if (n_each) *n_each = L.P.K;
+    return FMD_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t fmd_firdemod_out_cap(uint32_t decim, uint32_t rate_out, uint32_t rate_resample, size_t nbytes)
+{
+    if (!decim || !rate_out) return 0;
+    const uint64_t M = nbytes / 2 / decim + 2;
+    return (size_t)((M * rate_resample + rate_out - 1) / rate_out + 1);
+}
+
+int fmd_firdemod_new(const int16_t* taps, uint32_t n_taps, uint32_t decim, uint32_t shift, uint32_t rate_out,
+                     uint32_t rate_resample, const fmd_device_config* dev, fmd_firdemod** out)
+{
+    if (!taps || !dev || !out || dev->n_channels == 0) { fmd_internal_set_err("null / empty argument"); return FMD_ERR_INVALID_ARG; }
+    *out = nullptr;
+    if (n_taps == 0 || n_taps > 1024 || decim == 0 || decim % 2 != 0 || decim > 64 || shift > 24) {
+        fmd_internal_set_err("need 1 <= n_taps <= 1024, an even 2 <= decim <= 64 and shift <= 24");
+        return FMD_ERR_UNSUPPORTED;
+    }
+    if (rate_resample == 0 || rate_out < rate_resample) {
+        fmd_internal_set_err("need rate_out >= rate_resample >= 1 (simple_fm.rs:421 divides by rate_out / rate_resample)");
+        return FMD_ERR_BAD_RATES;
+    }
+    uint64_t sum_abs = 0;
+    for (uint32_t t = 0; t < n_taps; ++t) {
+        if (taps[t] > 2047 || taps[t] < -2047) { fmd_internal_set_err("|tap| > 2047"); return FMD_ERR_UNSUPPORTED; }
+        sum_abs += (uint64_t)(taps[t] < 0 ? -taps[t] : taps[t]);
+    }
+    // |lp| <= 128 * sum|h| / 2^shift must stay within the discriminator's range (the boxcar's bound at downsample 128)
+    if (((128ull * sum_abs) >> shift) > 16384ull) {
+        fmd_internal_set_err("filter gain too large for the discriminator: need (128 * sum|taps|) >> shift <= 16384");
+        return FMD_ERR_UNSUPPORTED;
+    }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) { fmd_internal_set_err("no HIP device (this library has no CPU path)"); return FMD_ERR_NO_DEVICE; }
+    int device = dev->device_id;
+    if (device < 0) { if (hipGetDevice(&device) != hipSuccess) device = 0; }
+    hipDeviceProp_t prop;
+    if (device >= ndev || hipGetDeviceProperties(&prop, device) != hipSuccess || strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+        fmd_internal_set_err("device is not a gfx950");
+        return FMD_ERR_NO_DEVICE;
+    }
+    fmd_firdemod* f = new (std::nothrow) fmd_firdemod();
+    if (!f) return FMD_ERR_NOMEM;
+    f->T = n_taps; f->M = decim; f->C = dev->n_channels; f->device = device; f->shift = shift;
+    f->NP = ((n_taps + 1) / 2 + 3u) & ~3u;
+    const uint32_t H = n_taps - 1, Hp = H + (H & 1u);
+    f->Hw = Hp / 2;
+    if (!fmd_fir_build_mfma(taps, n_taps, decim, f->plan)) { delete f; fmd_internal_set_err("shape does not fit the matrix-core form"); return FMD_ERR_UNSUPPORTED; }
+    FmdRates& r = f->r;
+    r.D = decim; r.fast = rate_out; r.slow = rate_resample;
+    r.g = fmd_gcd(r.fast, r.slow); r.fr = r.fast / r.g; r.sr = r.slow / r.g;
+    r.R = (int32_t)(r.fast / r.slow);
+    const uint64_t fa = r.fr / r.sr;
+    if (r.fr > FMD_MAX_RATE_REDUCED || (fa + 2) * 32768ull >= (1u << 24) || (uint32_t)r.R >= (1u << 24)) {
+        delete f; fmd_internal_set_err("rate ratio outside the exact-small-divide range"); return FMD_ERR_UNSUPPORTED;
+    }
+    // tiling: the most audio samples per tile that fit (<= 1024 filter outputs, ~20 KB of LDS -> 8 tiles per CU)
+    uint32_t best = 0; size_t lds = 0;
+    uint32_t kt_env = 0;
+    if (const char* e = getenv("FMD_FD_KT")) kt_env = (uint32_t)atoi(e);
+    for (uint32_t kt = 1; kt <= 1024; ++kt) {
+        if ((uint64_t)r.sr * (kt + 2) >= (1u << 24)) break;
+        uint32_t lc, rb; size_t l;
+        if (!fd_sizes(f, kt, &lc, &rb, &l)) break;
+        if (l > 20480 && best) break;
+        best = kt;
+        if (kt_env && kt == kt_env) break;
+    }
+    if (!best) { delete f; fmd_internal_set_err("one audio sample does not fit a tile: rate_out / rate_resample x decim too large"); return FMD_ERR_UNSUPPORTED; }
+    r.kt = best;
+    if (!fd_sizes(f, r.kt, &f->lp_cap, &f->raw_bytes, &lds)) { delete f; return FMD_ERR_UNSUPPORTED; }
+    if (const char* g = getenv("FMD_F64_GUARD_LOG2")) { if (*g) f->f64_guard = ldexp(1.0, atoi(g)); }
+    if (const char* g = getenv("FMD_F64_SKEW")) f->f64_skew = atoi(g);
+
+    auto fail = [&](const char* what) { fmd_internal_set_err(what); fmd_firdemod_free(f); return FMD_ERR_HIP; };
+    FmdDeviceGuard guard(device);
+    if (guard.error() != hipSuccess) return fail("hipSetDevice");
+    if (hipMalloc(&f->d_amat, f->plan.amat.size() * 4) != hipSuccess) return fail("hipMalloc(tap matrix)");
+    if (hipMemcpy(f->d_amat, f->plan.amat.data(), f->plan.amat.size() * 4, hipMemcpyHostToDevice) != hipSuccess) return fail("hipMemcpy(tap matrix)");
+    const size_t hb = (size_t)f->C * (f->Hw ? f->Hw : 1) * 4, sb = (size_t)f->C * sizeof(FmdChanState);
+    for (int i = 0; i < 2; ++i) {
+        if (hipMalloc(&f->d_hist[i], hb) != hipSuccess || hipMemset(f->d_hist[i], 0, hb) != hipSuccess) return fail("hipMalloc(history)");
+        if (hipMalloc(&f->d_state[i], sb) != hipSuccess || hipMemset(f->d_state[i], 0, sb) != hipSuccess) return fail("hipMalloc(state)");
+    }
+    if (hipMalloc(&f->d_exc, sizeof(FmdExcBuf)) != hipSuccess || hipMemset(f->d_exc, 0, sizeof(FmdExcBuf)) != hipSuccess) return fail("hipMalloc(reports)");
+    if (hipStreamCreateWithFlags(&f->stream, hipStreamNonBlocking) != hipSuccess) return fail("hipStreamCreate");
+    if (hipDeviceSynchronize() != hipSuccess) return fail("hipDeviceSynchronize");
+    *out = f;
+    return FMD_OK;
+}
+
+void fmd_firdemod_free(fmd_firdemod* f)
+{
+    if (!f) return;
+    FmdDeviceGuard guard(f->device);
+    (void)hipDeviceSynchronize();
+    f->order.destroy();
+    if (f->d_amat) (void)hipFree(f->d_amat);
+    for (int i = 0; i < 2; ++i) { if (f->d_hist[i]) (void)hipFree(f->d_hist[i]); if (f->d_state[i]) (void)hipFree(f->d_state[i]); }
+    if (f->d_exc) (void)hipFree(f->d_exc);
+    if (f->d_iq) (void)hipFree(f->d_iq);
+    if (f->d_out) (void)hipFree(f->d_out);
+    if (f->stream) (void)hipStreamDestroy(f->stream);
+    delete f;
+}
+
+int fmd_firdemod_reset(fmd_firdemod* f)
+{
+    if (!f) return FMD_ERR_INVALID_ARG;
+    FD_ON_DEVICE(f->device);
+    FD_TRY(hipDeviceSynchronize());
+    const size_t hb = (size_t)f->C * (f->Hw ? f->Hw : 1) * 4, sb = (size_t)f->C * sizeof(FmdChanState);
+    for (int i = 0; i < 2; ++i) { FD_TRY(hipMemset(f->d_hist[i], 0, hb)); FD_TRY(hipMemset(f->d_state[i], 0, sb)); }
+    FD_TRY(hipMemset(f->d_exc, 0, 16));
+    FD_TRY(hipDeviceSynchronize());
+    f->pos = 0; f->cur = 0; f->i0r = 0; f->last_K = 0;
+    f->order.reset();
+    return FMD_OK;
+}
+
+int fmd_firdemod_demodulate_device(fmd_firdemod* f, const void* d_iq, size_t nbytes, void* d_out, size_t out_cap,
+                                   size_t* out_len_each, void* stream)
+{
+    if (!f || !d_iq || !d_out) { fmd_internal_set_err("null argument"); return FMD_ERR_INVALID_ARG; }
+    FD_ON_DEVICE(f->device);
+    return fd_enqueue(f, d_iq, nbytes, d_out, out_cap, out_len_each, static_cast<hipStream_t>(stream));
+}
+
+int fmd_firdemod_check(fmd_firdemod* f)
+{
+    if (!f) { fmd_internal_set_err("null argument"); return FMD_ERR_INVALID_ARG; }
+    FD_ON_DEVICE(f->device);
+    FD_TRY(hipDeviceSynchronize());
+    return fmd_internal_resolve_exc(f->d_exc, f->r.R, f->seq, f->d_state[f->cur], nullptr, 0, &f->f64_guarded, &f->f64_patched);
+}
+
+int fmd_firdemod_demodulate_batch(fmd_firdemod* f, const uint8_t* iq, size_t nbytes, int16_t* out, size_t out_cap,
+                                  size_t* out_len)
+{
+    if (!f || !iq || !out || !out_len) { fmd_internal_set_err("null argument"); return FMD_ERR_INVALID_ARG; }
+    FD_ON_DEVICE(f->device);
+    if (nbytes % 8 != 0) { fmd_internal_set_err("nbytes % 8 != 0"); return FMD_ERR_BAD_LENGTH; }
+    const size_t in_bytes = nbytes * (size_t)f->C, out_elems = out_cap * (size_t)f->C;
+    if (in_bytes > f->d_iq_cap) {
+        if (f->d_iq) { FD_TRY(hipFree(f->d_iq)); f->d_iq = nullptr; f->d_iq_cap = 0; }
+        FD_TRY(hipMalloc(&f->d_iq, in_bytes ? in_bytes : 1));
+        f->d_iq_cap = in_bytes;
+    }
+    if (out_elems > f->d_out_cap) {
+        if (f->d_out) { FD_TRY(hipFree(f->d_out)); f->d_out = nullptr; f->d_out_cap = 0; }
+        FD_TRY(hipMalloc(&f->d_out, (out_elems ? out_elems : 1) * sizeof(int16_t)));
+        f->d_out_cap = out_elems;
+    }
+    FD_TRY(hipMemcpyAsync(f->d_iq, iq, in_bytes, hipMemcpyHostToDevice, f->stream));
+    size_t n = 0;
+    int rc = fd_enqueue(f, f->d_iq, nbytes, f->d_out, out_cap, &n, f->stream);
+    if (rc) return rc;
+    if (n) FD_TRY(hipMemcpyAsync(out, f->d_out, out_elems * sizeof(int16_t), hipMemcpyDeviceToHost, f->stream));
+    FD_TRY(hipStreamSynchronize(f->stream));
+    for (uint32_t c = 0; c < f->C; ++c) out_len[c] = n;
+    return fmd_internal_resolve_exc(f->d_exc, f->r.R, f->seq, f->d_state[f->cur], out, out_cap, &f->f64_guarded, &f->f64_patched);
+}
+
+int fmd_firdemod_get_state(fmd_firdemod* f, uint32_t channel, fmd_demod_state* state)
+{
+    if (!f || !state || channel >= f->C) { fmd_internal_set_err("bad argument"); return FMD_ERR_INVALID_ARG; }
+    FD_ON_DEVICE(f->device);
+    FD_TRY(hipDeviceSynchronize());
+    int rc = fmd_internal_resolve_exc(f->d_exc, f->r.R, f->seq, f->d_state[f->cur], nullptr, 0, &f->f64_guarded, &f->f64_patched);
+    if (rc) return rc;
+    FmdChanState s;
+    FD_TRY(hipMemcpy(&s, f->d_state[f->cur] + channel, sizeof(s), hipMemcpyDeviceToHost));
+    memset(state, 0, sizeof(*state));
+    state->now_lpr = s.now_lpr;
+    state->prev_lpr_index = (int32_t)(s.lpr_index_r * f->r.g);
+    state->demod_pre_re = s.demod_pre_re; state->demod_pre_im = s.demod_pre_im;
+    return FMD_OK;
+}
+
+int fmd_firdemod_f64_stats(const fmd_firdemod* f, uint64_t* guarded, uint64_t* patched)
+{
+    if (!f) return FMD_ERR_INVALID_ARG;
+    if (guarded) *guarded = f->f64_guarded;
+    if (patched) *patched = f->f64_patched;
+    return FMD_OK;
+}
+
+int fmd_firdemod_tiling(const fmd_firdemod* f, uint32_t* audio_per_tile, uint32_t* lds_bytes)
+{
+    if (!f) return FMD_ERR_INVALID_ARG;
+    uint32_t lc, rb; size_t lds = 0;
+    (void)fd_sizes(f, f->r.kt, &lc, &rb, &lds);
+    if (audio_per_tile) *audio_per_tile = f->r.kt;
+    if (lds_bytes) *lds_bytes = (uint32_t)lds;
+    return FMD_OK;
+}
+
+}  // extern "C"

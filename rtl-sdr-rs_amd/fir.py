@@ -7,7 +7,7 @@ import ctypes as C
 
 import numpy as np
 
-from ._ffi import DeviceConfig, check, lib
+from ._ffi import DemodState, DeviceConfig, check, lib
 
 
 class FirBank:
@@ -47,3 +47,74 @@ class FirBank:
         n = C.c_size_t(0)
         check(lib().fmd_fir_filter_device(self._h, d_iq, nbytes, d_out, out_cap, C.byref(n), stream))
         return n.value
+
+
+def auto_shift(taps):
+    """Smallest normalisation shift that keeps |lp| in the discriminator's range: (128 * sum|taps|) >> shift <= 16384."""
+    g = 128 * int(np.abs(np.asarray(taps, dtype=np.int64)).sum())
+    s = 0
+    while (g >> s) > 16384:
+        s += 1
+    return s
+
+
+class FirDemodBank:
+    """Tapped FIR -> discriminator -> resampler in one kernel (include/fmd.h, fmd_firdemod_*): Demod::demodulate
+    (simple_fm.rs:256-269) with the boxcar replaced by `taps` (decimate by `decim`, normalise by >> shift)."""
+
+    def __init__(self, taps, decim, rate_out, rate_resample, n_channels=1, shift=None, device_id=-1):
+        self.taps = np.ascontiguousarray(taps, dtype=np.int16)
+        self.decim, self.n_channels = int(decim), int(n_channels)
+        self.rate_out, self.rate_resample = int(rate_out), int(rate_resample)
+        self.shift = auto_shift(self.taps) if shift is None else int(shift)
+        self._h = C.c_void_p()
+        dev = DeviceConfig(self.n_channels, device_id, 0)
+        check(lib().fmd_firdemod_new(self.taps.ctypes.data_as(C.POINTER(C.c_int16)), self.taps.size, self.decim, self.shift,
+                                     self.rate_out, self.rate_resample, C.byref(dev), C.byref(self._h)))
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h:
+            lib().fmd_firdemod_free(self._h)
+            self._h = C.c_void_p()
+
+    __del__ = close
+
+    def reset(self):
+        check(lib().fmd_firdemod_reset(self._h))
+
+    def out_cap(self, nbytes):
+        return int(lib().fmd_firdemod_out_cap(self.decim, self.rate_out, self.rate_resample, nbytes))
+
+    def demodulate_batch(self, iq):
+        """iq uint8 [n_channels, nbytes] -> int16 array [n_channels, n_audio]."""
+        iq = np.ascontiguousarray(iq, dtype=np.uint8)
+        if iq.ndim != 2 or iq.shape[0] != self.n_channels:
+            raise ValueError("iq must be [n_channels, nbytes]")
+        cap = max(1, self.out_cap(iq.shape[1]))
+        out = np.empty((self.n_channels, cap), dtype=np.int16)
+        lens = (C.c_size_t * self.n_channels)()
+        check(lib().fmd_firdemod_demodulate_batch(self._h, iq.ctypes.data, iq.shape[1], out.ctypes.data, cap, lens))
+        return out[:, :lens[0]].copy()
+
+    def demodulate_device(self, d_iq, nbytes, d_out, out_cap, stream=None):
+        n = C.c_size_t(0)
+        check(lib().fmd_firdemod_demodulate_device(self._h, d_iq, nbytes, d_out, out_cap, C.byref(n), stream))
+        return n.value
+
+    def check(self):
+        check(lib().fmd_firdemod_check(self._h))
+
+    def get_state(self, channel=0):
+        s = DemodState()
+        check(lib().fmd_firdemod_get_state(self._h, channel, C.byref(s)))
+        return s
+
+    def f64_stats(self):
+        g, p = C.c_uint64(), C.c_uint64()
+        check(lib().fmd_firdemod_f64_stats(self._h, C.byref(g), C.byref(p)))
+        return {"guarded": g.value, "patched": p.value}
+
+    def tiling(self):
+        a, b = C.c_uint32(), C.c_uint32()
+        check(lib().fmd_firdemod_tiling(self._h, C.byref(a), C.byref(b)))
+        return {"audio_per_tile": a.value, "lds_bytes": b.value}

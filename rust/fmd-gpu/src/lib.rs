@@ -70,6 +70,11 @@ pub struct fmd_fir {
     _private: [u8; 0],
 }
 
+#[repr(C)]
+pub struct fmd_firdemod {
+    _private: [u8; 0],
+}
+
 extern "C" {
     pub fn fmd_optimal_settings(freq: u32, rate: u32, rate_resample: u32, radio: *mut RadioConfig, demod: *mut DemodConfig) -> c_int;
     pub fn fmd_demod_new(config: *const DemodConfig, dev: *const DeviceConfig, out: *mut *mut fmd_demod) -> c_int;
@@ -100,6 +105,16 @@ extern "C" {
     pub fn fmd_fir_out_cap(n_taps: u32, decim: u32, nbytes: usize) -> usize;
     pub fn fmd_fir_filter_batch(f: *mut fmd_fir, iq: *const u8, nbytes: usize, out: *mut i32, out_cap: usize, out_len: *mut usize) -> c_int;
     pub fn fmd_fir_filter_device(f: *mut fmd_fir, d_iq: *const c_void, nbytes: usize, d_out: *mut c_void, out_cap: usize, out_len_each: *mut usize, stream: *mut c_void) -> c_int;
+    pub fn fmd_firdemod_new(taps: *const i16, n_taps: u32, decim: u32, shift: u32, rate_out: u32, rate_resample: u32, dev: *const DeviceConfig, out: *mut *mut fmd_firdemod) -> c_int;
+    pub fn fmd_firdemod_free(f: *mut fmd_firdemod);
+    pub fn fmd_firdemod_reset(f: *mut fmd_firdemod) -> c_int;
+    pub fn fmd_firdemod_out_cap(decim: u32, rate_out: u32, rate_resample: u32, nbytes: usize) -> usize;
+    pub fn fmd_firdemod_demodulate_batch(f: *mut fmd_firdemod, iq: *const u8, nbytes: usize, out: *mut i16, out_cap: usize, out_len: *mut usize) -> c_int;
+    pub fn fmd_firdemod_demodulate_device(f: *mut fmd_firdemod, d_iq: *const c_void, nbytes: usize, d_out: *mut c_void, out_cap: usize, out_len_each: *mut usize, stream: *mut c_void) -> c_int;
+    pub fn fmd_firdemod_check(f: *mut fmd_firdemod) -> c_int;
+    pub fn fmd_firdemod_get_state(f: *mut fmd_firdemod, channel: u32, state: *mut DemodState) -> c_int;
+    pub fn fmd_firdemod_f64_stats(f: *const fmd_firdemod, guarded: *mut u64, patched: *mut u64) -> c_int;
+    pub fn fmd_firdemod_tiling(f: *const fmd_firdemod, audio_per_tile: *mut u32, lds_bytes: *mut u32) -> c_int;
 }
 
 /// Error in the crate's convention (`src/error.rs:8,40-44`: a Result, never a panic).

@@ -90,6 +90,17 @@ class Oracle:
         lib.fmo_fir_filter_batch.argtypes = [C.POINTER(C.c_void_p), u8p, C.c_size_t, C.c_size_t, C.POINTER(Cplx), C.c_size_t,
                                              C.POINTER(C.c_uint32), C.c_int]
         lib.fmo_fir_filter_batch.restype = C.c_int
+        lib.fmo_firdemod_new.argtypes = [i16p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32]
+        lib.fmo_firdemod_new.restype = C.c_void_p
+        lib.fmo_firdemod_free.argtypes = [C.c_void_p]
+        lib.fmo_firdemod_free.restype = None
+        lib.fmo_firdemod_demodulate.argtypes = [C.c_void_p, u8p, C.c_size_t, i16p, C.c_size_t]
+        lib.fmo_firdemod_demodulate.restype = C.c_long
+        lib.fmo_firdemod_state.argtypes = [C.c_void_p, C.POINTER(Demod)]
+        lib.fmo_firdemod_state.restype = None
+        lib.fmo_firdemod_batch.argtypes = [C.POINTER(C.c_void_p), u8p, C.c_size_t, C.c_size_t, i16p, C.c_size_t,
+                                           C.POINTER(C.c_uint32), C.c_int]
+        lib.fmo_firdemod_batch.restype = C.c_int
         lib.fmcf_demodulate.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(ChanState),
                                         u8p, C.c_size_t, i16p, C.c_size_t]
         lib.fmcf_demodulate.restype = C.c_long
@@ -163,6 +174,40 @@ class Oracle:
             raise ValueError("fmo_fir_filter_batch -> %d" % rc)
         assert len(set(lens.tolist())) == 1
         return out[:, :int(lens[0]), :]
+
+    def firdemod_new(self, taps, decim, shift, rate_out, rate_resample):
+        taps = np.ascontiguousarray(taps, dtype=np.int16)
+        h = self.lib.fmo_firdemod_new(taps.ctypes.data_as(C.POINTER(C.c_int16)), taps.size, decim, shift, rate_out, rate_resample)
+        assert h
+        return h
+
+    def firdemod(self, h, buf):
+        buf = np.ascontiguousarray(buf, dtype=np.uint8)
+        out = np.empty(buf.size // 2 + 16, dtype=np.int16)
+        n = self.lib.fmo_firdemod_demodulate(h, buf.ctypes.data_as(C.POINTER(C.c_uint8)), buf.size,
+                                             out.ctypes.data_as(C.POINTER(C.c_int16)), out.size)
+        if n < 0:
+            raise ValueError("fmo_firdemod_demodulate -> %d" % n)
+        return out[:n].copy()
+
+    def firdemod_batch(self, hs, iq, cap, threads=0):
+        import os
+        iq = np.ascontiguousarray(iq, dtype=np.uint8)
+        nch, n = iq.shape
+        out = np.empty((nch, cap), dtype=np.int16)
+        lens = np.zeros(nch, dtype=np.uint32)
+        arr = (C.c_void_p * nch)(*hs)
+        rc = self.lib.fmo_firdemod_batch(arr, iq.ctypes.data_as(C.POINTER(C.c_uint8)), nch, n,
+                                         out.ctypes.data_as(C.POINTER(C.c_int16)), cap,
+                                         lens.ctypes.data_as(C.POINTER(C.c_uint32)), threads or (os.cpu_count() or 1))
+        if rc:
+            raise ValueError("fmo_firdemod_batch -> %d" % rc)
+        return out, lens
+
+    def firdemod_state(self, h):
+        d = Demod()
+        self.lib.fmo_firdemod_state(h, C.byref(d))
+        return self.state_of(d)
 
     def new_bank(self, cfg, n):
         bank = (Demod * n)()

@@ -1,0 +1,129 @@
+"""Tapped FIR -> discriminator -> resampler fused in one kernel (fmd_firdemod_*, BASELINE north_star's "FIR + demod +
+resample fused").  No reference counterpart exists for a tapped FIR, so the anchors are:
+  * CPU: the oracle's composition fmo_firdemod_* (fmo_fir_filter -> fmo_fm_demod -> fmo_low_pass_real) with all-ones taps,
+    n_taps == decim == downsample, shift 0 IS fmo_demodulate -- the reference chain (simple_fm.rs:256-269), audio and state;
+  * GPU: the fused kernel == that composition for arbitrary taps / shifts / rates / ragged streaming calls, and therefore
+    == the boxcar kernel == the reference for all-ones taps (checked directly too), incl. BASELINE configs[3] at its full
+    size (127 taps, decimate 8, 256 channels x 2 MiB) with every channel compared."""
+import numpy as np
+import pytest
+
+
+@pytest.mark.parametrize("D,fast,slow", [(6, 170000, 32000), (10, 240000, 32000), (2, 48000, 48000), (16, 150000, 32000)])
+def test_oracle_composition_reduces_to_reference_chain(oracle, D, fast, slow):
+    rng = np.random.default_rng(D)
+    h = oracle.firdemod_new(np.ones(D, np.int16), D, 0, fast, slow)
+    d = oracle.new(oracle.config(D, fast, slow))
+    for i in range(6):
+        n = 8 * int(rng.integers(4 * D, 600))
+        b = rng.integers(0, 256, n, dtype=np.uint8) if i % 2 else np.where(rng.integers(0, 2, n) > 0, 255, 0).astype(np.uint8)
+        assert np.array_equal(oracle.firdemod(h, b), oracle.demodulate(d, b))
+    s1, s2 = oracle.firdemod_state(h), oracle.state_of(d)
+    assert (s1["now_lpr"], s1["prev_lpr_index"], s1["demod_pre"]) == (s2["now_lpr"], s2["prev_lpr_index"], s2["demod_pre"])
+    oracle.lib.fmo_firdemod_free(h)
+
+
+def state_tuple(s):
+    return (s["now_lpr"], s["prev_lpr_index"], s["demod_pre"])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("D,fast,slow", [(6, 170000, 32000), (10, 240000, 32000), (2, 48000, 48000), (16, 150000, 32000),
+                                         (64, 37500, 8000)])
+def test_gpu_all_ones_is_the_boxcar_kernel_and_the_reference(fmd, oracle, D, fast, slow):
+    """taps = 1...1, n_taps = decim = downsample, shift 0: fused FIR kernel == boxcar kernel == oracle of the reference."""
+    rng = np.random.default_rng(D + 100)
+    nch = 6
+    fd = fmd.FirDemodBank(np.ones(D, np.int16), D, fast, slow, nch, shift=0)
+    cfg = fmd.DemodConfig(fast, fast, slow, D, max(1, (1 << 15) // (128 * D)))
+    bank = fmd.DemodBank(cfg, nch)
+    ods = [oracle.new(oracle.config(D, fast, slow)) for _ in range(nch)]
+    for call in range(5):
+        n = 8 * int(rng.integers(4 * D, 4000)) if call != 2 else fmd.DEFAULT_BUF_LENGTH
+        iq = rng.integers(0, 256, (nch, n), dtype=np.uint8)
+        if call == 3:
+            iq[:] = np.where(rng.integers(0, 2, (nch, n)) > 0, 255, 0)           # full scale: the fast_atan2 wrap
+        got = fd.demodulate_batch(iq)
+        box = bank.demodulate_batch(iq)
+        for c in range(nch):
+            exp = oracle.demodulate(ods[c], iq[c])
+            assert np.array_equal(got[c], exp), (call, c)
+            assert np.array_equal(box[c], exp), (call, c)
+    for c in (0, nch - 1):
+        assert state_tuple(fd.get_state(c).as_dict()) == state_tuple(oracle.state_of(ods[c]))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("T,M,fast,slow", [(127, 8, 2500000, 48000), (33, 4, 250000, 48000), (5, 2, 96000, 48000),
+                                           (64, 6, 170000, 32000), (255, 32, 625000, 8000), (300, 8, 100000, 44100),
+                                           (16, 16, 48000, 48000), (129, 64, 37500, 8000), (1, 2, 500000, 32000)])
+def test_gpu_fused_matches_composition(fmd, oracle, T, M, fast, slow):
+    rng = np.random.default_rng(T * 11 + M)
+    taps = rng.integers(-2047, 2048, T).astype(np.int16)
+    shift = fmd.auto_shift(taps) + int(rng.integers(0, 3))
+    nch = 5
+    fd = fmd.FirDemodBank(taps, M, fast, slow, nch, shift=shift)
+    hs = [oracle.firdemod_new(taps, M, shift, fast, slow) for _ in range(nch)]
+    first = 8 * ((T + 2 * M) // 4 + 2)                                            # >= 2 filter outputs
+    for call in range(6):
+        n = first if call == 0 else 8 * int(rng.integers(2 * M, 700))
+        if call == 3:
+            n = 8 * int(rng.integers(6000, 9000))                                  # several tiles per channel
+        iq = rng.integers(0, 256, (nch, n), dtype=np.uint8)
+        if call == 4:
+            iq[:] = np.where(rng.integers(0, 2, (nch, n)) > 0, 255, 0)
+        got = fd.demodulate_batch(iq)
+        for c in range(nch):
+            exp = oracle.firdemod(hs[c], iq[c])
+            assert got[c].shape == exp.shape, (call, c, got[c].shape, exp.shape)
+            assert np.array_equal(got[c], exp), (call, c)
+    for c in range(nch):
+        assert state_tuple(fd.get_state(c).as_dict()) == state_tuple(oracle.firdemod_state(hs[c]))
+        oracle.lib.fmo_firdemod_free(hs[c])
+    fd.reset()
+    assert fd.get_state(0).as_dict()["demod_pre"] == [0, 0]
+
+
+@pytest.mark.gpu
+def test_gpu_fused_config4_full_size(fmd, oracle):
+    """BASELINE configs[3] shape with the demodulator behind it: 127 taps, decimate 8, 256 channels x 2 MiB per call,
+    2.5 Msps -> 48 kHz; two consecutive calls, EVERY channel compared (the launch bench.py's extra line times)."""
+    import torch
+    rng = np.random.default_rng(1)
+    taps = rng.integers(-2047, 2048, 127).astype(np.int16)
+    nch, n, fast, slow = 256, 2 << 20, 2500000, 48000
+    fd = fmd.FirDemodBank(taps, 8, fast, slow, nch)
+    hs = [oracle.firdemod_new(taps, 8, fd.shift, fast, slow) for _ in range(nch)]
+    cap = fd.out_cap(n)
+    d_out = torch.zeros((nch, cap), dtype=torch.int16, device="cuda")
+    for call in range(2):
+        iq = fmd.synth.synth_iq(nch, n, sample_offset=call * (n // 2), amplitude=110)
+        d_iq = torch.from_numpy(iq).cuda()
+        k = fd.demodulate_device(d_iq.data_ptr(), n, d_out.data_ptr(), cap)
+        fd.check()
+        exp, lens = oracle.firdemod_batch(hs, iq, cap)
+        assert int(lens.min()) == int(lens.max()) == k and k > 2500
+        got = d_out.cpu().numpy()
+        bad = [c for c in range(nch) if not np.array_equal(got[c, :k], exp[c, :k])]
+        assert not bad, (call, bad[:8])
+    for h in hs:
+        oracle.lib.fmo_firdemod_free(h)
+
+
+@pytest.mark.gpu
+def test_gpu_fused_errors(fmd):
+    with pytest.raises(fmd.FmdError) as ei:
+        fmd.FirDemodBank(np.full(127, 2047, np.int16), 8, 2500000, 48000, shift=0)     # gain beyond the discriminator's range
+    assert ei.value.status == -6
+    with pytest.raises(fmd.FmdError):
+        fmd.FirDemodBank(np.ones(4, np.int16), 3, 48000, 48000)                        # odd decimation
+    with pytest.raises(fmd.FmdError) as ei:
+        fmd.FirDemodBank(np.ones(4, np.int16), 4, 32000, 48000)                        # rate_out < rate_resample
+    assert ei.value.status == -4
+    b = fmd.FirDemodBank(np.ones(4, np.int16), 4, 48000, 48000)
+    with pytest.raises(fmd.FmdError) as ei:
+        b.demodulate_batch(np.zeros((1, 12), np.uint8))
+    assert ei.value.status == -2
+    with pytest.raises(fmd.FmdError) as ei:
+        b.demodulate_batch(np.zeros((1, 8), np.uint8))                                 # one filter output: assert at :356
+    assert ei.value.status == -3
