@@ -4,7 +4,7 @@ TAG=${1:-pmc}; shift
 OUT=gpurun_out/$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
-ARGS="--steps 10 --warmup 2 --settle 20 --no-cpu $@"
+ARGS="--steps 10 --warmup 2 --settle 20 --no-cpu --no-extra $@"
 run() { # name counters...
   n=$1; shift
   timeout 300 rocprofv3 --kernel-trace --pmc "$@" -d $OUT/$n -o pmc -f csv --kernel-include-regex "fmd_demod" -- python3 bench.py $ARGS > $OUT/$n.json 2> $OUT/$n.err || tail -5 $OUT/$n.err

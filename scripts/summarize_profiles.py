@@ -4,10 +4,12 @@ committed summaries under profiles/.  Usage: summarize_profiles.py <tag> [round-
 import collections, csv, glob, json, os, shutil, sys
 
 tag = sys.argv[1]
-rnd = sys.argv[2] if len(sys.argv) > 2 else "r01"
+rnd = sys.argv[2] if len(sys.argv) > 2 else "r02"
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src, pmc, out = os.path.join(root, "gpurun_out", tag), os.path.join(root, "gpurun_out", tag + "_pmc"), os.path.join(root, "profiles")
-KERNEL = "fmd_demod_tile_kernel<5, 256>"
+KERNEL = "fmd_demod_tile_kernel<5, 256, true>"
+sys.path.insert(0, root)
+import bench as _bench   # kernel_source_hash(): ties the PMC summary to the sources it was measured on
 
 def bench_line(path):
     return json.loads([l for l in open(path).read().splitlines() if l.startswith('{"metric"')][0])
@@ -21,11 +23,12 @@ rows = [r for r in csv.DictReader(open(os.path.join(src, "prof", "trace_kernel_t
 dur = [int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in rows]
 prof_bench = bench_line(os.path.join(src, "prof_bench.json"))
 settle, warm, steps = prof_bench["config"]["settle_steps_untimed"], prof_bench["warmup"], prof_bench["steps"]
-timed = dur[settle + warm: settle + warm + steps]
+regions = prof_bench.get("timing", {}).get("regions", 1)
+timed = dur[settle + warm: settle + warm + steps * regions]
 summary = {
-    "command": "rocprofv3 --kernel-trace --stats -S -u usec -- python3 bench.py --no-cpu   (settle %d + warmup %d + steps %d + 20 paired launches)" % (settle, warm, steps),
+    "command": "rocprofv3 --kernel-trace --stats -S -u usec -- python3 bench.py --no-cpu --no-extra   (settle %d + warmup %d + %d regions x %d steps + 40 paired launches)" % (settle, warm, regions, steps),
     "kernel": KERNEL, "launches": len(dur), "avg_ns_all_launches": sum(dur) / len(dur),
-    "avg_ns_timed_region_%d_launches" % steps: sum(timed) / len(timed),
+    "avg_ns_timed_regions_%d_launches" % len(timed): sum(timed) / len(timed),
     "avg_ns_first_50_launches_clock_ramp": sum(dur[:50]) / 50, "min_ns": min(dur), "max_ns": max(dur),
     "bench_py_kernel_ms_events_region_same_run": prof_bench["roofline"]["kernel_ms_events_region"],
     "note": "trace_kernel_stats average covers every launch incl. the untimed settle phase; the timed region's average is "
@@ -43,9 +46,9 @@ waves = counters["SQ_WAVES"]["mean_per_launch"]
 alg = bench["roofline"]["algorithmic_bytes_per_launch"]
 fetch_kb, write_kb = counters["FETCH_SIZE"]["mean_per_launch"], counters["WRITE_SIZE"]["mean_per_launch"]
 traffic = fetch_kb * 1024 * 2 + write_kb * 1024
-pm = {"command": "rocprofv3 --kernel-trace --pmc <set> -- python3 bench.py --steps 10 --warmup 2 --settle 20 --no-cpu  (scripts/gpu_pmc.sh; "
+pm = {"command": "rocprofv3 --kernel-trace --pmc <set> -- python3 bench.py --steps 10 --warmup 2 --settle 20 --no-cpu --no-extra  (scripts/gpu_pmc.sh; "
                  "one pass per counter set; never combined with --sys-trace)",
-      "kernel": KERNEL, "counters": counters,
+      "kernel": KERNEL, "kernel_source_sha16": _bench.kernel_source_hash(), "counters": counters,
       "per_wave": {"valu": counters["SQ_INSTS_VALU"]["mean_per_launch"] / waves, "salu": counters["SQ_INSTS_SALU"]["mean_per_launch"] / waves,
                    "lds": counters["SQ_INSTS_LDS"]["mean_per_launch"] / waves, "vmem_rd": counters["SQ_INSTS_VMEM_RD"]["mean_per_launch"] / waves},
       "hbm_traffic": {"fetch_size_kb": fetch_kb, "write_size_kb": write_kb,
@@ -53,7 +56,7 @@ pm = {"command": "rocprofv3 --kernel-trace --pmc <set> -- python3 bench.py --ste
                       "bytes_per_launch": traffic, "algorithmic_bytes_per_launch": alg, "ratio_to_algorithmic": traffic / alg}}
 json.dump(pm, open(os.path.join(out, rnd + "_pmc_summary.json"), "w"), indent=1)
 print("bench ms/step %.4f frac %.4f | trace timed avg %.1f us (events %.1f us) | traffic x%.4f | VALU/wave %.1f SALU/wave %.1f" % (
-    bench["ms_per_step"], bench["roofline"]["frac"], summary["avg_ns_timed_region_%d_launches" % steps] / 1e3,
+    bench["ms_per_step"], bench["roofline"]["frac"], summary["avg_ns_timed_regions_%d_launches" % len(timed)] / 1e3,
     prof_bench["roofline"]["kernel_ms_events_region"] * 1e3, traffic / alg, pm["per_wave"]["valu"], pm["per_wave"]["salu"]))
 
 # ---- config 4 (FIR): <tag>_fir_mfma.json, <tag>_fir_valu.json, <tag>_fir/prof, <tag>_pmc_fir/summary.json ----------
