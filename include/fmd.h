@@ -239,6 +239,32 @@ int fmd_firdemod_get_state(fmd_firdemod *f, uint32_t channel, fmd_demod_state *s
 int fmd_firdemod_f64_stats(const fmd_firdemod *f, uint64_t *guarded, uint64_t *patched);
 int fmd_firdemod_tiling(const fmd_firdemod *f, uint32_t *audio_per_tile, uint32_t *lds_bytes);
 
+/* ---- pipelined, multi-GPU sink for read_sync buffers ------------------------------------------------------- */
+/* NEW SURFACE (the reference has no asynchronous reader).  It mirrors the hand-off the example
+ * does have: receive() fills a buffer with RtlSdr::read_sync (src/lib.rs:153) and sends it down an mpsc channel,
+ * process() demodulates it and calls output() (examples/simple_fm.rs:55-60,114-127,150-156).  Here the channel
+ * is a ring of `depth` page-locked slots and the consumer is one Demod bank per GPU: channels are split into
+ * contiguous ranges over `device_ids` (one Demod per stream, :137 -- no communication between devices); host ->
+ * device copy of buffer n+1, the kernel of buffer n and the device -> host copy of buffer n-1 overlap.
+ *   fmd_sink_acquire: the next slot to fill, [n_channels][nbytes] channel-major (blocks only when all `depth`
+ *                     slots are in flight: then the oldest is completed first);
+ *   fmd_sink_submit : enqueue it on every device and return without waiting;
+ *   completion, in submission order, from inside acquire / poll / drain on the caller's thread:
+ *       callback(user, seq, audio [n_channels][out_cap], out_len [n_channels], out_cap, status)
+ *     -- `audio` is valid during the callback only; status FMD_OK or the first error of that buffer.
+ * Results are exactly those of feeding the same buffers to fmd_demod_demodulate_batch one by one. */
+typedef struct fmd_sink fmd_sink;
+typedef void (*fmd_sink_callback)(void *user, uint64_t seq, const int16_t *audio, const size_t *out_len,
+                                  size_t out_cap, int status);
+int fmd_sink_new(const fmd_demod_config *config, uint32_t n_channels, const int32_t *device_ids, uint32_t n_devices,
+                 size_t nbytes, uint32_t depth, fmd_sink_callback callback, void *user, fmd_sink **out);
+void fmd_sink_free(fmd_sink *s);
+int fmd_sink_acquire(fmd_sink *s, uint8_t **iq);
+int fmd_sink_submit(fmd_sink *s);
+int fmd_sink_poll(fmd_sink *s);     /* deliver what has finished; returns the number of buffers delivered or < 0 */
+int fmd_sink_drain(fmd_sink *s);    /* wait for and deliver everything in flight */
+int fmd_sink_info(const fmd_sink *s, size_t *out_cap, uint32_t *n_devices, uint32_t *in_flight);
+
 /* ---- diagnostics ---------------------------------------------------------------------- */
 const char *fmd_strerror(int status);
 const char *fmd_last_error(void);          /* thread-local detail of the last failure          */

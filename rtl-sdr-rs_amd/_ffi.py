@@ -101,7 +101,16 @@ PROTOTYPES = {
     "fmd_firdemod_get_state": (C.c_int, [_vp, C.c_uint32, C.POINTER(DemodState)]),
     "fmd_firdemod_f64_stats": (C.c_int, [_vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "fmd_firdemod_tiling": (C.c_int, [_vp, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
+    "fmd_sink_new": (C.c_int, [C.POINTER(DemodConfig), C.c_uint32, C.POINTER(C.c_int32), C.c_uint32, _sz, C.c_uint32, _vp, _vp, C.POINTER(_vp)]),
+    "fmd_sink_free": (None, [_vp]),
+    "fmd_sink_acquire": (C.c_int, [_vp, C.POINTER(_vp)]),
+    "fmd_sink_submit": (C.c_int, [_vp]),
+    "fmd_sink_poll": (C.c_int, [_vp]),
+    "fmd_sink_drain": (C.c_int, [_vp]),
+    "fmd_sink_info": (C.c_int, [_vp, _szp, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
 }
+
+SINK_CALLBACK = C.CFUNCTYPE(None, C.c_void_p, C.c_uint64, C.POINTER(C.c_int16), C.POINTER(C.c_size_t), C.c_size_t, C.c_int)
 
 
 def build(force=False):

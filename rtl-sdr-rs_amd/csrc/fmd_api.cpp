@@ -20,6 +20,7 @@
 
 #include "fmd_host.h"
 #include "fmd_index.h"
+#include "fmd_internal.h"
 #include "fmd_kernels.h"
 
 namespace {
@@ -82,6 +83,7 @@ struct fmd_demod {
     FmdChanState* d_state[2] = {nullptr, nullptr};
     int cur = 0;
     FmdExcBuf* d_exc = nullptr;           // device error word + guarded f64 samples (fmd_kernels.h)
+    FmdExcBuf* exc_override = nullptr;    // fmd_internal_set_report_buffer (pipelined sink: one buffer per in-flight launch)
     double f64_guard = 0x1p-20;           // FMD_F64_GUARD_LOG2 (tests lower the bar to exercise the patch path)
     int32_t f64_skew = 0;                 // FMD_F64_SKEW, honoured by -DFMD_EXPERIMENT builds only
     uint32_t seq = 0;                     // launches enqueued
@@ -246,8 +248,8 @@ int enqueue(fmd_demod* d, const void* d_iq, size_t nbytes, void* d_out, size_t o
     L.out = static_cast<int16_t*>(d_out);
     L.out_stride = out_cap;
     L.out_len = static_cast<uint32_t*>(d_out_len);
-    L.err = &d->d_exc->err;
-    L.exc = d->d_exc;
+    L.exc = d->exc_override ? d->exc_override : d->d_exc;
+    L.err = &L.exc->err;
     L.f64_guard = d->f64_guard;
     L.seq = d->seq + 1;
 #ifdef FMD_EXPERIMENT
@@ -304,13 +306,24 @@ int resolve_device_reports(fmd_demod* d, int16_t* host_out, size_t host_cap);
 // Error text for the other translation units of the library (fmd_fir.hip).
 void fmd_internal_set_err(const char* msg) { set_err("%s", msg); }
 
+void fmd_internal_set_report_buffer(fmd_demod* d, FmdExcBuf* buf) { d->exc_override = buf; }
+
+FmdHandleView fmd_internal_view(fmd_demod* d)
+{
+    FmdHandleView v;
+    v.R = d->r.R; v.seq = d->seq; v.state_cur = d->d_state[d->cur];
+    v.guarded = &d->f64_guarded; v.patched = &d->f64_patched; v.device = d->device;
+    return v;
+}
+
 // After a handle's work has completed: surface the device error word and re-evaluate the guarded f64 samples
 // (FmdF64Exc) with the host libm.  A sample whose host value differs from the kernel's is patched -- in `host_out`
 // ([C][host_cap], the caller's copy of the most recent launch's output) when given, else in the device buffer the
 // launch wrote -- together with the carried partial sum (d_state_cur[channel].now_lpr) when it lies in the trailing
-// group.  Shared by fmd_demod and fmd_firdemod.
-int fmd_internal_resolve_exc(FmdExcBuf* d_exc, int32_t R, uint32_t cur_seq, FmdChanState* d_state_cur, int16_t* host_out,
-                             size_t host_cap, uint64_t* guarded, uint64_t* patched)
+// group.  host_seq: the launch `host_out` is a copy of; state_seq: the launch whose state d_state_cur holds (the most
+// recent one).  Shared by fmd_demod, fmd_firdemod and the pipelined sink.
+int fmd_internal_resolve_exc(FmdExcBuf* d_exc, int32_t R, uint32_t host_seq, uint32_t state_seq, FmdChanState* d_state_cur,
+                             int16_t* host_out, size_t host_cap, uint64_t* guarded, uint64_t* patched)
 {
     uint32_t head[4] = {0, 0, 0, 0};                        // err, count, guarded_total, pad
     HIP_TRY(hipMemcpy(head, d_exc, sizeof(head), hipMemcpyDeviceToHost));
@@ -332,7 +345,7 @@ int fmd_internal_resolve_exc(FmdExcBuf* d_exc, int32_t R, uint32_t cur_seq, FmdC
         if (e.k >= 0) {
             auto& g = groups[{e.seq, e.out_elem}];
             g.first += delta; g.second = &e;
-        } else if (e.seq == cur_seq) {
+        } else if (e.seq == state_seq) {
             int32_t now = 0;
             int32_t* p = &d_state_cur[e.channel].now_lpr;
             HIP_TRY(hipMemcpy(&now, p, sizeof(now), hipMemcpyDeviceToHost));
@@ -347,7 +360,7 @@ int fmd_internal_resolve_exc(FmdExcBuf* d_exc, int32_t R, uint32_t cur_seq, FmdC
     for (const auto& kv : groups) {
         const FmdF64Exc& e = *kv.second.second;
         const int16_t fixed = (int16_t)((e.sum + (int)kv.second.first) / R);              // low_pass_real, simple_fm.rs:421
-        if (host_out && e.seq == cur_seq) host_out[(size_t)e.channel * host_cap + (size_t)e.k] = fixed;
+        if (host_out && e.seq == host_seq) host_out[(size_t)e.channel * host_cap + (size_t)e.k] = fixed;
         else HIP_TRY(hipMemcpy((void*)(uintptr_t)e.out_elem, &fixed, sizeof(fixed), hipMemcpyHostToDevice));
     }
     if (head[0] & FMD_DEVERR_EXC_CAP) {
@@ -360,7 +373,7 @@ int fmd_internal_resolve_exc(FmdExcBuf* d_exc, int32_t R, uint32_t cur_seq, FmdC
 namespace {
 int resolve_device_reports(fmd_demod* d, int16_t* host_out, size_t host_cap)
 {
-    return fmd_internal_resolve_exc(d->d_exc, d->r.R, d->seq, d->d_state[d->cur], host_out, host_cap, &d->f64_guarded, &d->f64_patched);
+    return fmd_internal_resolve_exc(d->d_exc, d->r.R, d->seq, d->seq, d->d_state[d->cur], host_out, host_cap, &d->f64_guarded, &d->f64_patched);
 }
 }  // namespace
 

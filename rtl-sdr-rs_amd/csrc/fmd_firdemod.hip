@@ -33,10 +33,8 @@
 #include "fmd_device.h"
 #include "fmd_fir_common.h"
 #include "fmd_host.h"
+#include "fmd_internal.h"
 #include "fmd_kernels.h"
-
-int fmd_internal_resolve_exc(FmdExcBuf* d_exc, int32_t R, uint32_t cur_seq, FmdChanState* d_state_cur, int16_t* host_out,
-                             size_t host_cap, uint64_t* guarded, uint64_t* patched);
 
 namespace {
 
@@ -556,7 +554,7 @@ int fmd_firdemod_check(fmd_firdemod* f)
     if (!f) { fmd_internal_set_err("null argument"); return FMD_ERR_INVALID_ARG; }
     FD_ON_DEVICE(f->device);
     FD_TRY(hipDeviceSynchronize());
-    return fmd_internal_resolve_exc(f->d_exc, f->r.R, f->seq, f->d_state[f->cur], nullptr, 0, &f->f64_guarded, &f->f64_patched);
+    return fmd_internal_resolve_exc(f->d_exc, f->r.R, f->seq, f->seq, f->d_state[f->cur], nullptr, 0, &f->f64_guarded, &f->f64_patched);
 }
 
 int fmd_firdemod_demodulate_batch(fmd_firdemod* f, const uint8_t* iq, size_t nbytes, int16_t* out, size_t out_cap,
@@ -583,7 +581,7 @@ int fmd_firdemod_demodulate_batch(fmd_firdemod* f, const uint8_t* iq, size_t nby
     if (n) FD_TRY(hipMemcpyAsync(out, f->d_out, out_elems * sizeof(int16_t), hipMemcpyDeviceToHost, f->stream));
     FD_TRY(hipStreamSynchronize(f->stream));
     for (uint32_t c = 0; c < f->C; ++c) out_len[c] = n;
-    return fmd_internal_resolve_exc(f->d_exc, f->r.R, f->seq, f->d_state[f->cur], out, out_cap, &f->f64_guarded, &f->f64_patched);
+    return fmd_internal_resolve_exc(f->d_exc, f->r.R, f->seq, f->seq, f->d_state[f->cur], out, out_cap, &f->f64_guarded, &f->f64_patched);
 }
 
 int fmd_firdemod_get_state(fmd_firdemod* f, uint32_t channel, fmd_demod_state* state)
@@ -591,7 +589,7 @@ int fmd_firdemod_get_state(fmd_firdemod* f, uint32_t channel, fmd_demod_state* s
     if (!f || !state || channel >= f->C) { fmd_internal_set_err("bad argument"); return FMD_ERR_INVALID_ARG; }
     FD_ON_DEVICE(f->device);
     FD_TRY(hipDeviceSynchronize());
-    int rc = fmd_internal_resolve_exc(f->d_exc, f->r.R, f->seq, f->d_state[f->cur], nullptr, 0, &f->f64_guarded, &f->f64_patched);
+    int rc = fmd_internal_resolve_exc(f->d_exc, f->r.R, f->seq, f->seq, f->d_state[f->cur], nullptr, 0, &f->f64_guarded, &f->f64_patched);
     if (rc) return rc;
     FmdChanState s;
     FD_TRY(hipMemcpy(&s, f->d_state[f->cur] + channel, sizeof(s), hipMemcpyDeviceToHost));

@@ -1,0 +1,67 @@
+"""Pipelined multi-GPU sink for read_sync buffers (include/fmd.h, fmd_sink_*): new surface over the reference's
+receive -> mpsc -> process -> output hand-off (examples/simple_fm.rs:55-60,114-127,150-156)."""
+import ctypes as C
+
+import numpy as np
+
+from ._ffi import SINK_CALLBACK, check, lib
+
+
+class Sink:
+    """on_audio(seq, audio_list, status): audio_list[c] is channel c's int16 array of that buffer (copied)."""
+
+    def __init__(self, config, n_channels, nbytes, device_ids=(0,), depth=3, on_audio=None):
+        self.n_channels, self.nbytes = int(n_channels), int(nbytes)
+        self.on_audio = on_audio
+        self.results = []                                   # (seq, [arrays], status) when no callback is given
+
+        def _cb(user, seq, audio, out_len, out_cap, status):
+            lens = [out_len[c] for c in range(self.n_channels)]
+            flat = np.ctypeslib.as_array(audio, shape=(self.n_channels, out_cap))
+            rows = [flat[c, :lens[c]].copy() for c in range(self.n_channels)]
+            if self.on_audio:
+                self.on_audio(seq, rows, status)
+            else:
+                self.results.append((seq, rows, status))
+
+        self._cb = SINK_CALLBACK(_cb)                       # keep alive
+        ids = (C.c_int32 * len(device_ids))(*device_ids)
+        self._h = C.c_void_p()
+        check(lib().fmd_sink_new(C.byref(config), self.n_channels, ids, len(device_ids), self.nbytes, depth,
+                                 C.cast(self._cb, C.c_void_p), None, C.byref(self._h)))
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h:
+            lib().fmd_sink_free(self._h)
+            self._h = C.c_void_p()
+
+    __del__ = close
+
+    def acquire(self):
+        """The next slot as a writable uint8 array [n_channels, nbytes] (page-locked memory owned by the sink)."""
+        p = C.c_void_p()
+        check(lib().fmd_sink_acquire(self._h, C.byref(p)))
+        raw = (C.c_uint8 * (self.n_channels * self.nbytes)).from_address(p.value)
+        return np.frombuffer(raw, dtype=np.uint8).reshape(self.n_channels, self.nbytes)
+
+    def submit(self):
+        check(lib().fmd_sink_submit(self._h))
+
+    def push(self, iq):
+        """acquire + copy + submit: what receive() does with a freshly read buffer (simple_fm.rs:114-127)."""
+        self.acquire()[:] = iq
+        self.submit()
+
+    def poll(self):
+        n = lib().fmd_sink_poll(self._h)
+        if n < 0:
+            check(n)
+        return n
+
+    def drain(self):
+        check(lib().fmd_sink_drain(self._h))
+
+    def info(self):
+        cap, nd, fl = C.c_size_t(), C.c_uint32(), C.c_uint32()
+        check(lib().fmd_sink_info(self._h, C.byref(cap), C.byref(nd), C.byref(fl)))
+        return {"out_cap": cap.value, "n_devices": nd.value, "in_flight": fl.value}

@@ -75,6 +75,14 @@ pub struct fmd_firdemod {
     _private: [u8; 0],
 }
 
+#[repr(C)]
+pub struct fmd_sink {
+    _private: [u8; 0],
+}
+
+/// `fmd_sink_callback`: (user, seq, audio [n_channels][out_cap], out_len [n_channels], out_cap, status).
+pub type fmd_sink_callback = Option<unsafe extern "C" fn(*mut c_void, u64, *const i16, *const usize, usize, c_int)>;
+
 extern "C" {
     pub fn fmd_optimal_settings(freq: u32, rate: u32, rate_resample: u32, radio: *mut RadioConfig, demod: *mut DemodConfig) -> c_int;
     pub fn fmd_demod_new(config: *const DemodConfig, dev: *const DeviceConfig, out: *mut *mut fmd_demod) -> c_int;
@@ -115,6 +123,13 @@ extern "C" {
     pub fn fmd_firdemod_get_state(f: *mut fmd_firdemod, channel: u32, state: *mut DemodState) -> c_int;
     pub fn fmd_firdemod_f64_stats(f: *const fmd_firdemod, guarded: *mut u64, patched: *mut u64) -> c_int;
     pub fn fmd_firdemod_tiling(f: *const fmd_firdemod, audio_per_tile: *mut u32, lds_bytes: *mut u32) -> c_int;
+    pub fn fmd_sink_new(config: *const DemodConfig, n_channels: u32, device_ids: *const i32, n_devices: u32, nbytes: usize, depth: u32, callback: fmd_sink_callback, user: *mut c_void, out: *mut *mut fmd_sink) -> c_int;
+    pub fn fmd_sink_free(s: *mut fmd_sink);
+    pub fn fmd_sink_acquire(s: *mut fmd_sink, iq: *mut *mut u8) -> c_int;
+    pub fn fmd_sink_submit(s: *mut fmd_sink) -> c_int;
+    pub fn fmd_sink_poll(s: *mut fmd_sink) -> c_int;
+    pub fn fmd_sink_drain(s: *mut fmd_sink) -> c_int;
+    pub fn fmd_sink_info(s: *const fmd_sink, out_cap: *mut usize, n_devices: *mut u32, in_flight: *mut u32) -> c_int;
 }
 
 /// Error in the crate's convention (`src/error.rs:8,40-44`: a Result, never a panic).
