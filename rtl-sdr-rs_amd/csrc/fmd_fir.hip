@@ -184,7 +184,7 @@ __device__ __forceinline__ void fir_dma16(const unsigned char* g, unsigned char*
 __device__ __forceinline__ uint32_t fir_swz_slot(uint32_t slot) { return slot ^ (((slot >> 4) & 1u) << 1); }
 
 template <int NKU, bool SWZ>
-__global__ void __launch_bounds__(kFirThreads) fmd_fir_mfma_kernel(const FirLaunch L)
+__global__ void __launch_bounds__(kFirThreads, 8) fmd_fir_mfma_kernel(const FirLaunch L)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     const uint32_t tid = threadIdx.x;

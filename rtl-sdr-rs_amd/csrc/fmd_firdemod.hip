@@ -120,7 +120,7 @@ __device__ __forceinline__ int row_sum16(int v)
 }
 
 template <int NKU>
-__global__ void __launch_bounds__(kThreads) fmd_firdemod_kernel(const FirDemodLaunch L)
+__global__ void __launch_bounds__(kThreads, 8) fmd_firdemod_kernel(const FirDemodLaunch L)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
@@ -143,7 +143,8 @@ __global__ void __launch_bounds__(kThreads) fmd_firdemod_kernel(const FirDemodLa
         return;
     }
     uint32_t* const ypk = lds + (L.raw_bytes >> 2);          // packed lp[jfirst + i], i = 0 .. cnt-1
-    int16_t* const d16 = reinterpret_cast<int16_t*>(ypk + L.lp_cap + 1u);
+    // the discriminator samples reuse the raw bytes' space: those are dead once the matrix-core phase is over (barrier B2)
+    int16_t* const d16 = reinterpret_cast<int16_t*>(lds);
 
     const uint32_t j = lane & 15u, q = lane >> 4;
     typedef const FMD_AS_GLOBAL fd_i4* gq;
@@ -351,7 +352,8 @@ bool fd_sizes(const fmd_firdemod* f, uint32_t kt, uint32_t* lp_cap, uint32_t* ra
     const uint64_t staged = (((((uint64_t)(cap - 1) * half_M + f->NP + 3) / 4) + 3) & ~(uint64_t)3) * 16;
     const uint64_t touched = (uint64_t)16 * ((cap + 63) / 64) * (8u * f->M) + (uint64_t)64 * f->plan.n_pass * f->plan.nku;
     const uint64_t raw = ((staged > touched ? staged : touched) + 15) & ~(uint64_t)15;
-    const uint64_t total = raw + 4ull * (cap + 1) + 2ull * (cap + 8) + 16;
+    if (raw < 2ull * (cap + 8)) return false;              // d16 aliases the raw region
+    const uint64_t total = raw + 4ull * (cap + 1) + 16;
     if (total > 60 * 1024) return false;
     *lp_cap = cap; *raw_bytes = (uint32_t)raw; *lds = (size_t)total;
     return true;
