@@ -64,6 +64,7 @@ struct FirDemodLaunch {
     uint32_t n_pass, col_bytes, shift;
     int32_t mre[2], mim[2];
     uint32_t n_channels, tiles, xcd;
+    uint32_t lpa_log;          // log2 of the lanes that share one audio sample in the resampler
     // ---- demod (fmd_index.h) ----
     FmdRates r;
     FmdClassPlan P;            // M = FIR outputs of this call, K = audio samples, nt, eq0, er0 (p0 = 0)
@@ -79,7 +80,17 @@ struct FirDemodLaunch {
     double f64_guard;
     uint32_t seq;
     int32_t f64_skew;
+    uint32_t dbg;              // ablation bits, honoured by -DFMD_EXPERIMENT builds only
 };
+
+#ifndef FD_PREXOR
+#define FD_PREXOR 0   /* measured: equal to slightly slower (0.1505 vs 0.1477 ms); the extra barrier costs what the 57 v_xor per wave save */
+#endif
+#ifdef FMD_EXPERIMENT
+#define FD_ABLATE(bit) ((L.dbg >> (bit)) & 1u)
+#else
+#define FD_ABLATE(bit) false
+#endif
 
 __device__ __forceinline__ uint32_t virt_dword(const FirDemodLaunch& L, uint32_t c, uint32_t w)
 {
@@ -109,14 +120,46 @@ __device__ __forceinline__ void dma16(const unsigned char* g, unsigned char* lds
                                      (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 2 /* nt */);
 }
 
-// sum over the 16 lanes of a row (lanes 16k .. 16k+15): four DPP row shifts
-__device__ __forceinline__ int row_sum16(int v)
+// Sum over groups of 2^LOG lanes (LOG <= 4, groups inside a 16-lane DPP row): log2 row shifts; the group's last lane
+// ends up with the total.
+template <int LOG>
+__device__ __forceinline__ int group_sum_dpp(int v)
 {
-    v += __builtin_amdgcn_update_dpp(0, v, 0x118 /* row_shr:8 */, 0xf, 0xf, true);
-    v += __builtin_amdgcn_update_dpp(0, v, 0x114 /* row_shr:4 */, 0xf, 0xf, true);
-    v += __builtin_amdgcn_update_dpp(0, v, 0x112 /* row_shr:2 */, 0xf, 0xf, true);
-    v += __builtin_amdgcn_update_dpp(0, v, 0x111 /* row_shr:1 */, 0xf, 0xf, true);
-    return v;                                                // lane 15 of the row holds the total
+    if (LOG >= 4) v += __builtin_amdgcn_update_dpp(0, v, 0x118 /* row_shr:8 */, 0xf, 0xf, true);
+    if (LOG >= 3) v += __builtin_amdgcn_update_dpp(0, v, 0x114 /* row_shr:4 */, 0xf, 0xf, true);
+    if (LOG >= 2) v += __builtin_amdgcn_update_dpp(0, v, 0x112 /* row_shr:2 */, 0xf, 0xf, true);
+    if (LOG >= 1) v += __builtin_amdgcn_update_dpp(0, v, 0x111 /* row_shr:1 */, 0xf, 0xf, true);
+    return v;
+}
+
+// low_pass_real (:408-426) for the tile's nk audio samples: 2^LOG lanes per audio sample sum its group of
+// discriminator samples, DPP reduction, one exact small divide.  LOG is chosen by the host so that a tile's audio
+// samples fit ONE pass of the 256 threads (a second pass for a seventeenth sample costs as much as the first).
+template <int LOG>
+__device__ __forceinline__ void resample_tile(const FirDemodLaunch& L, const FmdTile& T, const int16_t* d16, int jfirst,
+                                              int now_lpr_in, int16_t* outc, uint32_t tid)
+{
+    constexpr uint32_t LPA = 1u << LOG;
+    const FmdRates& r = L.r;
+    const uint32_t nk = T.k1 - T.k0, sub = tid & (LPA - 1u);
+    for (uint32_t q0 = 0; q0 < nk; q0 += kThreads / LPA) {   // uniform trip count: the DPP reduction needs whole groups
+        const uint32_t qa = q0 + (tid >> LOG);
+        int sum = 0;
+        if (qa < nk) {
+            const uint32_t x = T.er + qa * L.fb;
+            const uint32_t u = fmd_udiv_small(x, r.sr, L.inv_sr);
+            const bool extra = x - u * r.sr < L.fb;
+            const int e = (int)(T.eq + qa * L.fa + u);
+            int s = e - (int)L.fa + (extra ? 0 : 1);
+            s = s > 0 ? s : 0;                               // the call's first group starts at 0
+            for (int jj = s + (int)sub; jj <= e; jj += (int)LPA) sum += d16[jj - jfirst];
+        }
+        sum = group_sum_dpp<LOG>(sum);
+        if (qa < nk && sub == LPA - 1u) {
+            if (T.k0 + qa == 0u) sum += now_lpr_in;          // continues the previous call's partial sum (:410-417)
+            outc[T.k0 + qa] = (int16_t)fmd_sdiv_small(sum, r.R, L.inv_R);
+        }
+    }
 }
 
 template <int NKU>
@@ -171,13 +214,21 @@ __global__ void __launch_bounds__(kThreads, 8) fmd_firdemod_kernel(const FirDemo
     __builtin_amdgcn_s_waitcnt(0x0F70);                      // vmcnt(0): the LDS-DMAs (and the A fragments) have landed
     __syncthreads();
 
+    // u8 -> s8 (b - 128) once per staged byte: every byte is the B operand of ~5 MFMAs (columns 64 bytes apart, 320-byte
+    // windows), so flipping the sign bits here costs a fifth of the v_xor the fragment reads would need (70 -> 13 per
+    // wave), for one more barrier
+    if (FD_PREXOR) {
+        for (uint32_t i = tid; i < nq; i += kThreads) lq[i] = lq[i] ^ (int)0x80808080;
+        __syncthreads();
+    }
+
     // ---- FIR on the matrix cores (see fmd_fir.hip) -----------------------------------------------------------
     const uint8_t* lb = reinterpret_cast<const uint8_t*>(lds);
     const uint32_t groups = (no + 63u) >> 6;
     fd_i4 acc[kGroupsPerWave];
 #pragma unroll
     for (int gi = 0; gi < kGroupsPerWave; ++gi) acc[gi] = fd_i4{0, 0, 0, 0};
-    for (uint32_t pass = 0; pass < L.n_pass; ++pass) {
+    for (uint32_t pass = 0; pass < L.n_pass && !FD_ABLATE(0); ++pass) {
         if (pass) {
 #pragma unroll
             for (int k = 0; k < NKU; ++k) A[k] = amat[(pass * NKU + k) * 64u];
@@ -189,7 +240,8 @@ __global__ void __launch_bounds__(kThreads, 8) fmd_firdemod_kernel(const FirDemo
                 const uint8_t* col = lb + (16u * g + j) * L.col_bytes + 64u * NKU * pass;
 #pragma unroll
                 for (int k = 0; k < NKU; ++k) {
-                    const fd_i4 B = *reinterpret_cast<const fd_i4*>(col + 64 * k + 16u * q) ^ (int)0x80808080;   // u8 -> s8
+                    fd_i4 B = *reinterpret_cast<const fd_i4*>(col + 64 * k + 16u * q);
+                    if (!FD_PREXOR) B = B ^ (int)0x80808080;                                   // u8 -> s8
                     acc[gi] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A[k], B, acc[gi], 0, 0, 0);
                 }
             }
@@ -225,7 +277,7 @@ __global__ void __launch_bounds__(kThreads, 8) fmd_firdemod_kernel(const FirDemo
 
     // ---- fm_demod (:355-367): every sample against its predecessor ---------------------------------------------
     bool any_guard = false;
-    for (int i = (int)tid + 1; i < cnt; i += kThreads) {
+    for (int i = (int)tid + 1; i < cnt && !FD_ABLATE(1); i += kThreads) {
         const uint32_t a = ypk[i], b = ypk[i - 1];
         int d;
         if (jfirst + i == 0) {                               // the first sample of the call: f64 path (:359), tid 0
@@ -242,25 +294,15 @@ __global__ void __launch_bounds__(kThreads, 8) fmd_firdemod_kernel(const FirDemo
     }
     __syncthreads();
 
-    // ---- low_pass_real (:408-426): 16 lanes per audio sample ---------------------------------------------------
-    const uint32_t nk = T.k1 - T.k0, sub = tid & 15u;
+    // ---- low_pass_real (:408-426): 2^lpa_log lanes per audio sample ---------------------------------------------
     int16_t* const outc = L.out + (uint64_t)c * L.out_stride;
-    for (uint32_t q0 = 0; q0 < nk; q0 += kThreads / 16) {    // uniform trip count: the DPP reduction needs whole rows
-        const uint32_t qa = q0 + (tid >> 4);
-        int sum = 0;
-        if (qa < nk) {
-            const uint32_t x = T.er + qa * L.fb;
-            const uint32_t u = fmd_udiv_small(x, r.sr, L.inv_sr);
-            const bool extra = x - u * r.sr < L.fb;
-            const int e = (int)(T.eq + qa * L.fa + u);
-            int s = e - (int)L.fa + (extra ? 0 : 1);
-            s = s > 0 ? s : 0;                               // the call's first group starts at 0
-            for (int jj = s + (int)sub; jj <= e; jj += 16) sum += d16[jj - jfirst];
-        }
-        sum = row_sum16(sum);
-        if (qa < nk && sub == 15u) {
-            if (T.k0 + qa == 0u) sum += st.now_lpr;          // continues the previous call's partial sum (:410-417)
-            outc[T.k0 + qa] = (int16_t)fmd_sdiv_small(sum, r.R, L.inv_R);
+    if (!FD_ABLATE(2)) {
+        switch (L.lpa_log) {                                 // wave-uniform
+            case 4: resample_tile<4>(L, T, d16, jfirst, st.now_lpr, outc, tid); break;
+            case 3: resample_tile<3>(L, T, d16, jfirst, st.now_lpr, outc, tid); break;
+            case 2: resample_tile<2>(L, T, d16, jfirst, st.now_lpr, outc, tid); break;
+            case 1: resample_tile<1>(L, T, d16, jfirst, st.now_lpr, outc, tid); break;
+            default: resample_tile<0>(L, T, d16, jfirst, st.now_lpr, outc, tid); break;
         }
     }
     if (jfirst < 0 && tid == 0 && any_guard) {               // guarded f64 sample (FmdF64Exc, fmd_kernels.h)
@@ -328,6 +370,7 @@ struct fmd_firdemod {
     uint32_t seq = 0;
     uint64_t f64_guarded = 0, f64_patched = 0;
     FmdStreamOrder order;
+    size_t lds_budget = 20480;                            // LDS per tile (8 tiles per CU); FMD_FD_LDS (tuning)
     hipStream_t stream = nullptr;
     uint8_t* d_iq = nullptr; size_t d_iq_cap = 0;
     int16_t* d_out = nullptr; size_t d_out_cap = 0;
@@ -394,6 +437,13 @@ int fd_enqueue(fmd_firdemod* f, const void* d_iq, size_t nbytes, void* d_out, si
     L.st_in = f->d_state[f->cur]; L.st_out = f->d_state[f->cur ^ 1];
     L.out = static_cast<int16_t*>(d_out); L.out_stride = out_cap;
     L.exc = f->d_exc; L.f64_guard = f->f64_guard; L.seq = f->seq + 1; L.f64_skew = f->f64_skew;
+#ifdef FMD_EXPERIMENT
+    { const char* e = getenv("FMD_DBG"); L.dbg = e ? (uint32_t)atoi(e) : 0u; }
+#endif
+    // lanes per audio sample: as many as leave room for the tile's audio samples in one pass, at most one per group element
+    L.lpa_log = 4u;
+    while (L.lpa_log > 0u && ((uint32_t)kThreads >> L.lpa_log) < r.kt) L.lpa_log -= 1u;
+    while (L.lpa_log > 0u && (1u << L.lpa_log) > 2u * (L.fa + 1u)) L.lpa_log -= 1u;
     uint32_t lc, rb; size_t lds;
     if (!fd_sizes(f, r.kt, &lc, &rb, &lds)) { fmd_internal_set_err("tile sizing failed"); return FMD_ERR_UNSUPPORTED; }
     FD_TRY(f->order.before(stream));
@@ -483,11 +533,12 @@ int fmd_firdemod_new(const int16_t* taps, uint32_t n_taps, uint32_t decim, uint3
     uint32_t best = 0; size_t lds = 0;
     uint32_t kt_env = 0;
     if (const char* e = getenv("FMD_FD_KT")) kt_env = (uint32_t)atoi(e);
+    if (const char* e = getenv("FMD_FD_LDS")) f->lds_budget = (size_t)atoi(e);
     for (uint32_t kt = 1; kt <= 1024; ++kt) {
         if ((uint64_t)r.sr * (kt + 2) >= (1u << 24)) break;
         uint32_t lc, rb; size_t l;
         if (!fd_sizes(f, kt, &lc, &rb, &l)) break;
-        if (l > 20480 && best) break;
+        if (l > f->lds_budget && best) break;
         best = kt;
         if (kt_env && kt == kt_env) break;
     }
