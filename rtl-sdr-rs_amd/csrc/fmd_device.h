@@ -73,7 +73,7 @@ struct FmdExcArgs {
     FmdExcBuf* exc;
 };
 
-static __device__ __noinline__ void exc_emit(FmdExcArgs a, int j, int cr, int ci)
+[[maybe_unused]] static __device__ __noinline__ void exc_emit(FmdExcArgs a, int j, int cr, int ci)
 {
     FmdF64Exc e{};
     e.channel = a.c; e.cr = cr; e.ci = ci;

@@ -64,7 +64,8 @@ struct FirDemodLaunch {
     uint32_t n_pass, col_bytes, shift;
     int32_t mre[2], mim[2];
     uint32_t n_channels, tiles, xcd;
-    uint32_t lpa_log;          // log2 of the lanes that share one audio sample in the resampler
+    uint32_t small;            // 1: the group lookups fit the exact f32-reciprocal divide (fmd_udiv_small)
+    float inv_fr;
     // ---- demod (fmd_index.h) ----
     FmdRates r;
     FmdClassPlan P;            // M = FIR outputs of this call, K = audio samples, nt, eq0, er0 (p0 = 0)
@@ -120,46 +121,16 @@ __device__ __forceinline__ void dma16(const unsigned char* g, unsigned char* lds
                                      (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 2 /* nt */);
 }
 
-// Sum over groups of 2^LOG lanes (LOG <= 4, groups inside a 16-lane DPP row): log2 row shifts; the group's last lane
-// ends up with the total.
-template <int LOG>
-__device__ __forceinline__ int group_sum_dpp(int v)
+// Record of a guarded f64 sample (FmdF64Exc, fmd_kernels.h) for a caller that already holds the group's sum: k < 0 = the carried partial group.
+static __device__ __noinline__ void exc_emit_direct(FmdExcBuf* exc, uint32_t c, uint32_t seq, int k, int sum, int d_gpu,
+                                                    int cr, int ci, int16_t* out_elem)
 {
-    if (LOG >= 4) v += __builtin_amdgcn_update_dpp(0, v, 0x118 /* row_shr:8 */, 0xf, 0xf, true);
-    if (LOG >= 3) v += __builtin_amdgcn_update_dpp(0, v, 0x114 /* row_shr:4 */, 0xf, 0xf, true);
-    if (LOG >= 2) v += __builtin_amdgcn_update_dpp(0, v, 0x112 /* row_shr:2 */, 0xf, 0xf, true);
-    if (LOG >= 1) v += __builtin_amdgcn_update_dpp(0, v, 0x111 /* row_shr:1 */, 0xf, 0xf, true);
-    return v;
-}
-
-// low_pass_real (:408-426) for the tile's nk audio samples: 2^LOG lanes per audio sample sum its group of
-// discriminator samples, DPP reduction, one exact small divide.  LOG is chosen by the host so that a tile's audio
-// samples fit ONE pass of the 256 threads (a second pass for a seventeenth sample costs as much as the first).
-template <int LOG>
-__device__ __forceinline__ void resample_tile(const FirDemodLaunch& L, const FmdTile& T, const int16_t* d16, int jfirst,
-                                              int now_lpr_in, int16_t* outc, uint32_t tid)
-{
-    constexpr uint32_t LPA = 1u << LOG;
-    const FmdRates& r = L.r;
-    const uint32_t nk = T.k1 - T.k0, sub = tid & (LPA - 1u);
-    for (uint32_t q0 = 0; q0 < nk; q0 += kThreads / LPA) {   // uniform trip count: the DPP reduction needs whole groups
-        const uint32_t qa = q0 + (tid >> LOG);
-        int sum = 0;
-        if (qa < nk) {
-            const uint32_t x = T.er + qa * L.fb;
-            const uint32_t u = fmd_udiv_small(x, r.sr, L.inv_sr);
-            const bool extra = x - u * r.sr < L.fb;
-            const int e = (int)(T.eq + qa * L.fa + u);
-            int s = e - (int)L.fa + (extra ? 0 : 1);
-            s = s > 0 ? s : 0;                               // the call's first group starts at 0
-            for (int jj = s + (int)sub; jj <= e; jj += (int)LPA) sum += d16[jj - jfirst];
-        }
-        sum = group_sum_dpp<LOG>(sum);
-        if (qa < nk && sub == LPA - 1u) {
-            if (T.k0 + qa == 0u) sum += now_lpr_in;          // continues the previous call's partial sum (:410-417)
-            outc[T.k0 + qa] = (int16_t)fmd_sdiv_small(sum, r.R, L.inv_R);
-        }
-    }
+    FmdF64Exc e{};
+    e.channel = c; e.cr = cr; e.ci = ci; e.d_gpu = d_gpu; e.seq = seq; e.k = k; e.sum = sum;
+    e.out_elem = (uint64_t)(uintptr_t)out_elem;
+    atomicAdd(&exc->guarded_total, 1u);
+    const uint32_t slot = atomicAdd(&exc->count, 1u);
+    if (slot < FMD_EXC_CAP) exc->rec[slot] = e; else atomicOr(&exc->err, FMD_DEVERR_EXC_CAP);
 }
 
 template <int NKU>
@@ -186,8 +157,7 @@ __global__ void __launch_bounds__(kThreads, 8) fmd_firdemod_kernel(const FirDemo
         return;
     }
     uint32_t* const ypk = lds + (L.raw_bytes >> 2);          // packed lp[jfirst + i], i = 0 .. cnt-1
-    // the discriminator samples reuse the raw bytes' space: those are dead once the matrix-core phase is over (barrier B2)
-    int16_t* const d16 = reinterpret_cast<int16_t*>(lds);
+    int* const gsum = reinterpret_cast<int*>(ypk + L.lp_cap + 1u);   // audio group sums of the tile: [nk] + the carried tail
 
     const uint32_t j = lane & 15u, q = lane >> 4;
     typedef const FMD_AS_GLOBAL fd_i4* gq;
@@ -264,6 +234,7 @@ __global__ void __launch_bounds__(kThreads, 8) fmd_firdemod_kernel(const FirDemo
         }
     }
     if (jfirst < 0 && tid == 0) ypk[0] = pack_lp(st.demod_pre_re, st.demod_pre_im);     // lp[-1]
+    for (uint32_t k = tid; k <= r.kt; k += kThreads) gsum[k] = 0;
     // the channel's last tile also writes the next call's history (the raw bytes are all in global memory)
     if (T.last) {
         typedef const FMD_AS_GLOBAL uint32_t* gw;
@@ -275,52 +246,72 @@ __global__ void __launch_bounds__(kThreads, 8) fmd_firdemod_kernel(const FirDemo
     }
     __syncthreads();
 
-    // ---- fm_demod (:355-367): every sample against its predecessor ---------------------------------------------
+    // ---- fm_demod (:355-367) + the sums of low_pass_real (:408-417) ----------------------------------------------
+    // A thread takes `ch` CONSECUTIVE discriminator samples and adds them up per audio group as it goes (a group is
+    // fa or fa + 1 samples long: with 52 per group a thread's run touches one group, rarely two), then adds its
+    // partial sums to the tile's group accumulators in LDS.  The resampler that is left is one divide per audio
+    // sample.  (Summing groups in a separate pass over an array of discriminator samples cost 115 VALU instructions
+    // per wave -- every lane of a group redoing the index arithmetic -- against 171 for the discriminator itself.)
+    const uint32_t nk = T.k1 - T.k0;
+    const uint32_t ch = ((uint32_t)cnt - 1u + kThreads - 1u) / kThreads;
+    int d_first = 0, cr0 = 0, ci0 = 0;
     bool any_guard = false;
-    for (int i = (int)tid + 1; i < cnt && !FD_ABLATE(1); i += kThreads) {
-        const uint32_t a = ypk[i], b = ypk[i - 1];
-        int d;
-        if (jfirst + i == 0) {                               // the first sample of the call: f64 path (:359), tid 0
-            int cr, ci;
-            fmd_mul_conj(lp_re(a), lp_im(a), lp_re(b), lp_im(b), cr, ci);
-            bool g;
-            d = polar_f64(cr, ci, L.f64_guard, &g);
+    {
+        const int i_lo = 1 + (int)(tid * ch), i_hi = i_lo + (int)ch <= cnt ? i_lo + (int)ch : cnt;   // samples [i_lo, i_hi)
+        if (i_lo < i_hi && !FD_ABLATE(1)) {
+            const int j_lo = jfirst + i_lo;
+            // audio sample k whose group holds j_lo, and where that group ends: e(k) = ((k + 1) fr - i0r - 1) / sr
+            const uint32_t k = L.small ? fmd_udiv_small((uint32_t)j_lo * r.sr + P.i0r, r.fr, L.inv_fr) : ((uint32_t)j_lo * r.sr + P.i0r) / r.fr;
+            const uint32_t xk = (k + 1u) * r.fr - P.i0r - 1u;
+            uint32_t e = L.small ? fmd_udiv_small(xk, r.sr, L.inv_sr) : xk / r.sr;
+            uint32_t rem = xk - e * r.sr;
+            uint32_t q = k - T.k0;                           // the tile's local audio index (>= nk: the carried tail)
+            int part = 0;
+            uint32_t prev = ypk[i_lo - 1];
+            for (int i = i_lo; i < i_hi; ++i) {
+                const int j = jfirst + i;
+                while ((uint32_t)j > e) {                    // next group: e(k + 1) from e(k) by the remainder
+                    atomicAdd(&gsum[q < nk ? q : nk], part);
+                    part = 0; ++q;
+                    rem += L.fb; e += L.fa;
+                    if (rem >= r.sr) { rem -= r.sr; ++e; }
+                }
+                const uint32_t a = ypk[i];
+                int d;
+                if (j == 0) {                                // the first sample of the call: f64 path (:359), tid 0
+                    fmd_mul_conj(lp_re(a), lp_im(a), lp_re(prev), lp_im(prev), cr0, ci0);
+                    bool g;
+                    d = polar_f64(cr0, ci0, L.f64_guard, &g);
 #ifdef FMD_EXPERIMENT
-            if (g) d += L.f64_skew;
+                    if (g) d += L.f64_skew;
 #endif
-            any_guard = g;
-        } else d = disc_nosel(a, b);                         // (:362)
-        d16[i] = (int16_t)d;
+                    any_guard = g;
+                    d_first = (int)(int16_t)d;
+                } else d = disc_nosel(a, prev);              // (:362)
+                part += (int)(int16_t)d;                     // `as i16` (:362), summed as i32 (:414)
+                prev = a;
+            }
+            atomicAdd(&gsum[q < nk ? q : nk], part);
+        }
     }
     __syncthreads();
 
-    // ---- low_pass_real (:408-426): 2^lpa_log lanes per audio sample ---------------------------------------------
+    // ---- low_pass_real (:418-422): one divide per audio sample ---------------------------------------------------
     int16_t* const outc = L.out + (uint64_t)c * L.out_stride;
-    if (!FD_ABLATE(2)) {
-        switch (L.lpa_log) {                                 // wave-uniform
-            case 4: resample_tile<4>(L, T, d16, jfirst, st.now_lpr, outc, tid); break;
-            case 3: resample_tile<3>(L, T, d16, jfirst, st.now_lpr, outc, tid); break;
-            case 2: resample_tile<2>(L, T, d16, jfirst, st.now_lpr, outc, tid); break;
-            case 1: resample_tile<1>(L, T, d16, jfirst, st.now_lpr, outc, tid); break;
-            default: resample_tile<0>(L, T, d16, jfirst, st.now_lpr, outc, tid); break;
-        }
+    for (uint32_t k = tid; k < nk && !FD_ABLATE(2); k += kThreads) {
+        int sum = gsum[k];
+        if (T.k0 + k == 0u) sum += st.now_lpr;               // continues the previous call's partial sum (:410-417)
+        outc[T.k0 + k] = (int16_t)fmd_sdiv_small(sum, r.R, L.inv_R);
     }
     if (jfirst < 0 && tid == 0 && any_guard) {               // guarded f64 sample (FmdF64Exc, fmd_kernels.h)
-        int cr, ci;
-        fmd_mul_conj(lp_re(ypk[1]), lp_im(ypk[1]), lp_re(ypk[0]), lp_im(ypk[0]), cr, ci);
-        FmdExcArgs a;
-        a.sr = r.sr; a.fr = r.fr; a.i0r = P.i0r; a.K = P.K; a.c = c; a.seq = L.seq;
-        a.now_lpr_in = st.now_lpr; a.jfirst = jfirst; a.d16 = d16; a.out_c = outc; a.exc = L.exc;
-        exc_emit(a, 0, cr, ci);
+        const bool in_audio = P.K > 0u;                      // sample 0 lies in audio group 0, or in the carried tail
+        exc_emit_direct(L.exc, c, L.seq, in_audio ? 0 : -1, gsum[0] + st.now_lpr, d_first, cr0, ci0, outc);
     }
 
     // ---- state after the call (last tile; simple_fm.rs:232-239) --------------------------------------------------
     if (T.last && tid == 0) {
         FmdChanState ns_{};
-        const int s = P.K == 0 ? 0 : (int)fmd_audio_end(r, P.i0r, P.K - 1) + 1;
-        int sum = P.K == 0 ? st.now_lpr : 0;
-        for (int jj = s; jj <= T.jB; ++jj) sum += d16[jj - jfirst];
-        ns_.now_lpr = sum;
+        ns_.now_lpr = gsum[nk] + (P.K == 0 ? st.now_lpr : 0);       // the trailing partial group
         ns_.lpr_index_r = fmd_next_lpr_index_r(r, P.i0r, P.M, P.K);
         const uint32_t l = ypk[cnt - 1];                     // demod_pre = the last filter output (M >= 2 guaranteed by the host)
         ns_.demod_pre_re = lp_re(l); ns_.demod_pre_im = lp_im(l);
@@ -395,8 +386,7 @@ bool fd_sizes(const fmd_firdemod* f, uint32_t kt, uint32_t* lp_cap, uint32_t* ra
     const uint64_t staged = (((((uint64_t)(cap - 1) * half_M + f->NP + 3) / 4) + 3) & ~(uint64_t)3) * 16;
     const uint64_t touched = (uint64_t)16 * ((cap + 63) / 64) * (8u * f->M) + (uint64_t)64 * f->plan.n_pass * f->plan.nku;
     const uint64_t raw = ((staged > touched ? staged : touched) + 15) & ~(uint64_t)15;
-    if (raw < 2ull * (cap + 8)) return false;              // d16 aliases the raw region
-    const uint64_t total = raw + 4ull * (cap + 1) + 16;
+    const uint64_t total = raw + 4ull * (cap + 1) + 4ull * (kt + 2) + 16;
     if (total > 60 * 1024) return false;
     *lp_cap = cap; *raw_bytes = (uint32_t)raw; *lds = (size_t)total;
     return true;
@@ -440,10 +430,8 @@ int fd_enqueue(fmd_firdemod* f, const void* d_iq, size_t nbytes, void* d_out, si
 #ifdef FMD_EXPERIMENT
     { const char* e = getenv("FMD_DBG"); L.dbg = e ? (uint32_t)atoi(e) : 0u; }
 #endif
-    // lanes per audio sample: as many as leave room for the tile's audio samples in one pass, at most one per group element
-    L.lpa_log = 4u;
-    while (L.lpa_log > 0u && ((uint32_t)kThreads >> L.lpa_log) < r.kt) L.lpa_log -= 1u;
-    while (L.lpa_log > 0u && (1u << L.lpa_log) > 2u * (L.fa + 1u)) L.lpa_log -= 1u;
+    L.small = ((uint64_t)L.P.M * r.sr + 2ull * r.fr < (1u << 24) && (uint64_t)r.fr < (1u << 24)) ? 1u : 0u;
+    L.inv_fr = 1.0f / (float)r.fr;
     uint32_t lc, rb; size_t lds;
     if (!fd_sizes(f, r.kt, &lc, &rb, &lds)) { fmd_internal_set_err("tile sizing failed"); return FMD_ERR_UNSUPPORTED; }
     FD_TRY(f->order.before(stream));

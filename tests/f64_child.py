@@ -96,12 +96,39 @@ def scenario_stream(D, fast, slow, block_len):
     return {"bad": bad, "state_bad": st_bad, "stats": bank.f64_stats()}
 
 
+def scenario_firdemod():
+    """The fused FIR kernel's f64 sample (first filter output of every call): group sums of 52 / 5 samples, and a
+    ratio at which the sample mostly lies in the carried tail."""
+    o = oracle_lib.load()
+    rng = np.random.default_rng(8)
+    bad = st_bad = 0
+    stats = {"guarded": 0, "patched": 0}
+    for (T, M, fast, slow) in [(33, 4, 250000, 48000), (6, 6, 170000, 32000), (16, 8, 1000000, 8000)]:
+        taps = np.ones(T, np.int16) if T == M else rng.integers(-2047, 2048, T).astype(np.int16)
+        n = 7
+        fd = fmd.FirDemodBank(taps, M, fast, slow, n)
+        hs = [o.firdemod_new(taps, M, fd.shift, fast, slow) for _ in range(n)]
+        for call in range(5):
+            iq = rng.integers(0, 256, (n, 8 * int(rng.integers(60, 900))), dtype=np.uint8)
+            got = fd.demodulate_batch(iq)
+            for c in range(n):
+                bad += 0 if np.array_equal(got[c], o.firdemod(hs[c], iq[c])) else 1
+        for c in range(n):
+            a, b = fd.get_state(c).as_dict(), o.firdemod_state(hs[c])
+            st_bad += 0 if (a["now_lpr"], a["demod_pre"]) == (b["now_lpr"], b["demod_pre"]) else 1
+        s = fd.f64_stats()
+        stats["guarded"] += s["guarded"]; stats["patched"] += s["patched"]
+    return {"bad": bad, "state_bad": st_bad, "stats": stats}
+
+
 if __name__ == "__main__":
     kind = sys.argv[1]
     if kind == "direct":
         res = scenario_direct(False)
     elif kind == "direct_device":
         res = scenario_direct(True)
+    elif kind == "firdemod":
+        res = scenario_firdemod()
     else:
         D, fast, slow, bl = (int(x) for x in sys.argv[2:6])
         res = scenario_stream(D, fast, slow, bl)

@@ -60,3 +60,12 @@ def test_patch_inside_group_sums_and_carried_tail(D, fast, slow, block_len):
     r = run_child(["stream", D, fast, slow, block_len], guard_log2=-1, skew=5)
     assert r["bad"] == 0 and r["state_bad"] == 0
     assert r["stats"]["guarded"] > 0 and r["stats"]["patched"] == r["stats"]["guarded"]
+
+
+def test_fused_fir_kernel_guard_and_patch():
+    """fmd_firdemod_*: the same guard on its one f64 sample per call, patched in the audio sample or the carried sum."""
+    r = run_child(["firdemod"], guard_log2=-1)
+    assert r["bad"] == 0 and r["state_bad"] == 0 and r["stats"]["guarded"] > 50 and r["stats"]["patched"] == 0
+    r = run_child(["firdemod"], guard_log2=-1, skew=7)
+    assert r["bad"] == 0 and r["state_bad"] == 0
+    assert r["stats"]["guarded"] > 50 and r["stats"]["patched"] == r["stats"]["guarded"]
