@@ -266,6 +266,9 @@ int enqueue(fmd_demod* d, const void* d_iq, size_t nbytes, void* d_out, size_t o
         L.Qt = L.tl.Qt;
         L.fa = r.fr / r.sr; L.fb = r.fr % r.sr;
         L.inv_sr = 1.0f / (float)r.sr; L.inv_R = 1.0f / (float)r.R;
+        L.magic_R = fmd_make_magic((uint32_t)r.R);
+        L.sr_shift = 32u;
+        if ((r.sr & (r.sr - 1u)) == 0u) { L.sr_shift = 0u; while ((1u << L.sr_shift) < r.sr) ++L.sr_shift; }
         for (size_t k = 0; k < plans.size(); ++k) L.cls[k] = plans[k];
         L.chan_class = nullptr;
         if (d->classes.size() > 1) {

@@ -227,6 +227,32 @@ FMD_HD int32_t fmd_sdiv_small(int32_t s, int32_t d, float inv_d)
     return (int32_t)((q ^ m) - m);
 }
 
+// Truncating s / d by a host-made reciprocal (round-up method): with sh = ceil(log2 d) and m = ceil(2^(31+sh) / d) < 2^32,
+// floor(n / d) = mulhi(n, m) >> (sh - 1) for every 0 <= n < 2^24 (the error term n * (m d - 2^(31+sh)) / (d 2^(31+sh)) is
+// below 2^-7 / d).  d == 1 is flagged by m == 0.  One v_mul_hi_u32 instead of two conversions and a v_mul_lo.
+struct FmdMagic { uint32_t m, sh; };
+inline FmdMagic fmd_make_magic(uint32_t d)
+{
+    FmdMagic g{0u, 0u};
+    if (d <= 1u) return g;
+    uint32_t s = 0; while ((1ull << s) < d) ++s;
+    g.m = (uint32_t)(((1ull << (31 + s)) + d - 1) / d);
+    g.sh = s - 1u;
+    return g;
+}
+FMD_HD int32_t fmd_sdiv_magic(int32_t s, FmdMagic g)
+{
+    const uint32_t mk = (uint32_t)(s >> 31);
+    const uint32_t n = ((uint32_t)s ^ mk) - mk;
+#if defined(__HIP_DEVICE_COMPILE__)
+    const uint32_t hi = __umulhi(n, g.m);
+#else
+    const uint32_t hi = (uint32_t)(((uint64_t)n * g.m) >> 32);
+#endif
+    const uint32_t q = g.m ? hi >> g.sh : n;
+    return (int32_t)((q ^ mk) - mk);
+}
+
 // Truncating num / den for den > 0, |num / den| <= 4097 (the fast_atan2 quotient): f32 estimate
 // within 1, exact wrapping-remainder fix-up.  Needs den < 2^30.
 FMD_HD float fmd_rcp(float x)

@@ -101,6 +101,8 @@ struct FmdLaunch {
     FmdTiling tl;             // tiling constants of fmd_tile_fast
     uint32_t fa, fb;          // fr = fa * sr + fb
     float    inv_sr, inv_R;
+    uint32_t sr_shift;        // log2(sr) when sr is a power of two, else 32
+    FmdMagic magic_R;         // fmd_sdiv_magic(sum, magic_R) == sum / R for |sum| < 2^24
     const uint8_t* chan_class;// [n_channels] class id, or nullptr when every channel is class 0
     FmdClassPlan cls[FMD_MAX_CLASSES];
 };

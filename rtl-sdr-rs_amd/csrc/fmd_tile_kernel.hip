@@ -469,8 +469,12 @@ __device__ __forceinline__ void tile_body(const FmdLaunch& L, const TileCtx& X, 
     for (uint32_t q = tid; q < nk; q += NT) {
         if (FMD_ABLATE(2)) { outc[T.k0 + q] = d16[q + 1]; continue; }           // ablation: no resampler
         const uint32_t x = T.er + q * L.fb;
-        const uint32_t u = fmd_udiv_small(x, r.sr, L.inv_sr);
-        const bool extra = x - u * r.sr < L.fb;
+        // sr (the reduced resample rate) is a power of two at the reference's rates (170 k -> 32 k: 16) and at the
+        // bench configuration (240 k -> 32 k: 2): shift and mask instead of the exact small divide (wave-uniform)
+        uint32_t u, xrem;
+        if (L.sr_shift < 32u) { u = x >> L.sr_shift; xrem = x & (r.sr - 1u); }
+        else { u = fmd_udiv_small(x, r.sr, L.inv_sr); xrem = x - u * r.sr; }
+        const bool extra = xrem < L.fb;
         const int e = (int)(T.eq + q * L.fa + u);
         int s = e - (int)L.fa + (extra ? 0 : 1);
         s = s > 0 ? s : 0;                                   // the call's first group starts at 0
@@ -493,13 +497,13 @@ __device__ __forceinline__ void tile_body(const FmdLaunch& L, const TileCtx& X, 
                 sum += extra ? v : 0;
             }
         }
-        outc[T.k0 + q] = (int16_t)fmd_sdiv_small(sum, r.R, L.inv_R);
+        outc[T.k0 + q] = (int16_t)fmd_sdiv_magic(sum, L.magic_R);
     }
     if (T.k0 == 0 && tid == 0 && nk > 0) {                   // same lane as the loop's store to outc[0]: this one wins
         const int e = (int)(T.eq + fmd_udiv_small(T.er, r.sr, L.inv_sr));
         int sum = st.now_lpr;
         for (int jj = 0; jj <= e; ++jj) sum += d16[jj - jfirst];
-        outc[0] = (int16_t)fmd_sdiv_small(sum, r.R, L.inv_R);
+        outc[0] = (int16_t)fmd_sdiv_magic(sum, L.magic_R);
     }
 
     // Guarded f64 samples (rare: within 2^-20 of an integer): their records need the finished group sums.

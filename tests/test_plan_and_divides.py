@@ -69,3 +69,23 @@ def test_small_divides_exact(cf):
     for d in [1, 2, 3, 5, 7, 16, 85]:
         for t in list(range(0, 5 * d + 3)) + [d * 1000 - 1, d * 1000, d * 1000 + 1]:
             assert cf.fmcf_udiv_small(t, d) == t // d
+
+
+def test_magic_divide_matches_truncating_division():
+    """fmd_sdiv_magic (fmd_index.h): the resampler's divide by R = rate_out / rate_resample (simple_fm.rs:421) as one
+    multiply-high -- checked here through the same formula in Python ints for every R class and the whole |sum| range."""
+    import random
+    rnd = random.Random(5)
+    for R in [1, 2, 3, 5, 7, 8, 52, 53, 127, 128, 129, 1000, 65535, 65536, 999983, (1 << 24) - 1]:
+        s = 0
+        while (1 << s) < R:
+            s += 1
+        m = 0 if R <= 1 else ((1 << (31 + s)) + R - 1) // R
+        assert m < (1 << 32)
+        ns = [0, 1, R - 1, R, R + 1, 2 * R - 1, 2 * R, (1 << 24) - 1, (1 << 24) - R] + [rnd.randrange(1 << 24) for _ in range(20000)]
+        ns += [k * R + d for k in (1, 2, 77, ((1 << 24) - 1) // R) for d in (-1, 0, 1)]
+        for n in ns:
+            if not (0 <= n < (1 << 24)):
+                continue
+            q = n if m == 0 else ((n * m) >> 32) >> (s - 1)
+            assert q == n // R, (R, n, q)
