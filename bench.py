@@ -33,7 +33,7 @@ CHANNELS = 4096
 BLOCK = 16 * 16384
 D, FAST, SLOW = 10, 240000, 32000
 HBM_PEAK_GBS = 8000.0            # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-KERNEL = "fmd_demod_tile_kernel<5, 256, true>"   # the dominant kernel of this workload (rocprofv3 --kernel-trace name)
+KERNEL = "fmd_demod_tile_kernel<5, 256, 2>"   # the dominant kernel of this workload (rocprofv3 --kernel-trace name)
 MIN_TIMED_S = 0.050              # repeat the K-step region until this much has been timed
 PMC_SUMMARY = os.path.join("profiles", "r02_pmc_summary.json")
 

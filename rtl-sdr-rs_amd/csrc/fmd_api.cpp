@@ -79,7 +79,7 @@ struct fmd_demod {
     bool force_generic = false;
     int n_cus = 0;                        // compute units of the device
     uint32_t block_threads = 256;         // FMD_NT: workgroup size of the one-block-per-tile kernel
-    bool allow_fast = true;               // FMD_FAST=0: always the general prologue (A/B)
+    uint32_t allow_fast = 2;              // FMD_FAST: 0 general prologue only, 1 closed form only, 2 (default) table, else closed form (A/B)
     FmdChanState* d_state[2] = {nullptr, nullptr};
     int cur = 0;
     FmdExcBuf* d_exc = nullptr;           // device error word + guarded f64 samples (fmd_kernels.h)
@@ -283,7 +283,7 @@ int enqueue(fmd_demod* d, const void* d_iq, size_t nbytes, void* d_out, size_t o
             L.chan_class = d->d_chan_class;
         }
         L.block_threads = d->block_threads;
-        L.fast = d->allow_fast ? 1u : 0u;     // fmd_launch_tile decides (fmd_fast_geometry)
+        L.fast = d->allow_fast;               // fmd_launch_tile decides (fmd_fast_geometry)
         HIP_TRY(fmd_launch_tile(L, stream));
     } else {
         HIP_TRY(fmd_launch_generic(L, stream));
@@ -474,7 +474,7 @@ int fmd_demod_new(const fmd_demod_config* config, const fmd_device_config* dev, 
     // two waves per block step 2*127 windows per round: an odd downsample would flip a lane's rotation phase
     if (d->block_threads == 128 && (config->downsample & 1u)) d->block_threads = 256;
     const uint32_t kt_env = env_u32("FMD_KT", 0);
-    d->allow_fast = env_u32("FMD_FAST", 1) != 0;
+    d->allow_fast = env_u32("FMD_FAST", 2);
     int rc = choose_tiling(d, kt_env);
     if (rc) { delete d; return rc; }
 

@@ -68,10 +68,21 @@ struct FmdFastGeo {
 };
 static_assert(sizeof(FmdFastGeo) == 64, "one s_load_dwordx16");
 
+// The same per tile as a table, for rates whose tile length is NOT a multiple of the reduced resample rate (44.1 kHz
+// audio, 166 666 Hz ...: tile t then needs a division) when a channel-call has at most FMD_FAST_ROWS tiles -- which a
+// read_sync buffer always does.  The row sits in the kernel arguments right behind FmdFastGeo: one more scalar load.
+struct FmdTileRow {
+    uint32_t lo2, hi2;        // byte range of the channel-call the tile reads
+    int32_t  jA, jB;          // decimated samples the tile owns
+    uint32_t eq, er;          // (k0 + 1) fr - i0r - 1 = eq sr + er
+};
+#define FMD_FAST_ROWS 32
+
 struct FmdLaunch {
     FmdFastGeo fg;            // valid when `fast` (must stay the first member)
-    uint32_t fast;            // 1: fmd_demod_tile_kernel<.., true> with the geometry above
+    uint32_t fast;            // 0: general prologue; 1: closed-form geometry (fg alone); 2: fg + rows[tile]
     uint32_t pad0;
+    FmdTileRow rows[FMD_FAST_ROWS];
     const uint8_t* iq;        // [n_channels][chan_stride] interleaved u8 IQ, 16-byte aligned base
     uint64_t chan_stride;     // bytes per channel (= nbytes of the call)
     uint64_t total_bytes;     // n_channels * chan_stride

@@ -549,15 +549,21 @@ struct FastAddr {
     bool whole;
 };
 
-__device__ __forceinline__ FastAddr fast_addr(const FmdFastGeo& g)
+template <int FAST>
+__device__ __forceinline__ FastAddr fast_addr(const FmdLaunch& L)
 {
+    const FmdFastGeo& g = L.fg;
     FastAddr A;
     A.c = blockIdx.x * g.per + blockIdx.z;                   // grid (8, tiles, per): blockIdx.x is the XCD
     A.t = blockIdx.y;
-    const int32_t base = (int32_t)(A.t * g.step2);
-    const int32_t lo = base + g.lo_off2, hi = base + g.hi_off2;
-    A.lo2 = (uint32_t)(lo > 0 ? lo : 0);
-    A.hi2 = A.t + 1u == g.nt ? g.ns2 : (uint32_t)hi;
+    if (FAST == 2) {                                         // the tile's row of the table
+        A.lo2 = L.rows[A.t].lo2; A.hi2 = L.rows[A.t].hi2;
+    } else {
+        const int32_t base = (int32_t)(A.t * g.step2);
+        const int32_t lo = base + g.lo_off2, hi = base + g.hi_off2;
+        A.lo2 = (uint32_t)(lo > 0 ? lo : 0);
+        A.hi2 = A.t + 1u == g.nt ? g.ns2 : (uint32_t)hi;
+    }
     A.gbase = g.iq + (uint64_t)A.c * g.chan_stride;
     A.a0 = (A.gbase + A.lo2) & ~15ull;
     A.nchunks = (uint32_t)((A.gbase + A.hi2 - A.a0 + 15) >> 4);
@@ -566,6 +572,7 @@ __device__ __forceinline__ FastAddr fast_addr(const FmdFastGeo& g)
 }
 
 // The rest of the tile context, computed while the DMAs are in flight.
+template <int FAST>
 __device__ __forceinline__ TileCtx fast_ctx(const FmdLaunch& L, const FastAddr& A)
 {
     const FmdFastGeo& g = L.fg;
@@ -579,11 +586,15 @@ __device__ __forceinline__ TileCtx fast_ctx(const FmdLaunch& L, const FastAddr& 
     T.last = t + 1u == g.nt;
     T.k0 = t * L.r.kt;
     T.k1 = T.k0 + L.r.kt < P.K ? T.k0 + L.r.kt : P.K;
-    T.eq = t * g.Qt + P.eq0;
-    T.er = P.er0;
-    const int32_t ja = (int32_t)(t * g.Qt) + g.jA_off;
-    T.jA = ja > 0 ? ja : 0;
-    T.jB = T.last ? (int32_t)P.M - 1 : (int32_t)(t * g.Qt) + g.jB_off;
+    if (FAST == 2) {
+        T.eq = L.rows[t].eq; T.er = L.rows[t].er; T.jA = L.rows[t].jA; T.jB = L.rows[t].jB;
+    } else {
+        T.eq = t * g.Qt + P.eq0;
+        T.er = P.er0;
+        const int32_t ja = (int32_t)(t * g.Qt) + g.jA_off;
+        T.jA = ja > 0 ? ja : 0;
+        T.jB = T.last ? (int32_t)P.M - 1 : (int32_t)(t * g.Qt) + g.jB_off;
+    }
     T.nLo = (int32_t)(A.lo2 >> 1); T.nHi = (int32_t)(A.hi2 >> 1);
     X.jfirst = T.jA - 1;
     X.cnt = T.jB - X.jfirst + 1;
@@ -603,7 +614,7 @@ __device__ __forceinline__ void issue_dma(uint64_t a0, uint32_t nchunks, unsigne
 }
 
 // ---- one block per tile, LDS-DMA staging ------------------------------------------------------------
-template <int DH, int NT, bool FAST>
+template <int DH, int NT, int FAST>
 __global__ void __launch_bounds__(NT) fmd_demod_tile_kernel(const FmdLaunch L)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -615,13 +626,13 @@ __global__ void __launch_bounds__(NT) fmd_demod_tile_kernel(const FmdLaunch L)
         // One phase class, tiles that repeat exactly (kt * fr % sr == 0), XCD-aware grid (8, tiles, ceil(C / 8)):
         // the byte range of the tile is a multiply-add of the first 64 bytes of the kernel arguments.  The host has
         // checked the LDS sizing of every tile of this launch (fmd_fast_geometry), so there is nothing to assert.
-        const FastAddr A = fast_addr(L.fg);
+        const FastAddr A = fast_addr<FAST>(L);
         if (A.c >= L.fg.n_channels) return;
         if (FMD_ABLATE(4)) {
         } else if (A.whole) {
             issue_dma<NT>(A.a0, A.nchunks, smem, tid);
         }
-        const TileCtx X = fast_ctx(L, A);                    // scalar work under the load latency
+        const TileCtx X = fast_ctx<FAST>(L, A);              // scalar work under the load latency
         if (!A.whole && !FMD_ABLATE(4)) stage_slow<NT>(L, X, smem, tid);
         if (FMD_ABLATE(3)) {                                 // ablation: staging skeleton only
             __syncthreads();
@@ -676,11 +687,12 @@ template <int DH>
 void launch_one(const FmdLaunch& L, dim3 g, size_t lds, hipStream_t stream)
 {
     switch (L.block_threads) {
-        case 128: hipLaunchKernelGGL((fmd_demod_tile_kernel<DH, 128, false>), g, dim3(128), lds, stream, L); break;
-        case 64: hipLaunchKernelGGL((fmd_demod_tile_kernel<DH, 64, false>), g, dim3(64), lds, stream, L); break;
+        case 128: hipLaunchKernelGGL((fmd_demod_tile_kernel<DH, 128, 0>), g, dim3(128), lds, stream, L); break;
+        case 64: hipLaunchKernelGGL((fmd_demod_tile_kernel<DH, 64, 0>), g, dim3(64), lds, stream, L); break;
         default:
-            if (L.fast) hipLaunchKernelGGL((fmd_demod_tile_kernel<DH, 256, true>), g, dim3(256), lds, stream, L);
-            else hipLaunchKernelGGL((fmd_demod_tile_kernel<DH, 256, false>), g, dim3(256), lds, stream, L);
+            if (L.fast == 1u) hipLaunchKernelGGL((fmd_demod_tile_kernel<DH, 256, 1>), g, dim3(256), lds, stream, L);
+            else if (L.fast == 2u) hipLaunchKernelGGL((fmd_demod_tile_kernel<DH, 256, 2>), g, dim3(256), lds, stream, L);
+            else hipLaunchKernelGGL((fmd_demod_tile_kernel<DH, 256, 0>), g, dim3(256), lds, stream, L);
             break;
     }
 }
@@ -704,35 +716,49 @@ bool fmd_tile_kernel_supports(const FmdRates& r, uint32_t raw_cap)
     return true;
 }
 
-// Fills L.fg when the launch qualifies for the fast prologue: one phase class, tiles that repeat exactly, 256-thread
-// blocks, and every tile of the launch within the LDS sizing (checked here, once, instead of by every block).
-static bool fmd_fast_geometry(FmdLaunch& L, uint32_t per)
+// Fills L.fg (and L.rows) when the launch qualifies for a fast prologue: one phase class, 256-thread blocks, every tile
+// of the launch within the LDS sizing (checked here, once, instead of by every block).  Returns the mode: 1 = closed
+// form (tiles repeat exactly: kt * fr % sr == 0), 2 = per-tile table (any rates, at most FMD_FAST_ROWS tiles), 0 = none.
+static uint32_t fmd_fast_geometry(FmdLaunch& L, uint32_t per)
 {
-    if (!L.fast || L.chan_class || L.tl.Rt != 0u || L.block_threads != 256u) return false;   // L.fast: allowed (FMD_FAST != 0)
+    if (!L.fast || L.chan_class || L.block_threads != 256u) return 0u;   // L.fast on entry: allowed (FMD_FAST != 0)
     const FmdRates& r = L.r;
     const FmdClassPlan& P = L.cls[0];
-    if (P.nt != L.tiles || P.nt == 0u) return false;
+    if (P.nt != L.tiles || P.nt == 0u) return 0u;
     const FmdTiling& tl = L.tl;
+    const uint64_t ns2 = 2ull * L.ns;
+    if (ns2 >= (1ull << 31)) return 0u;
+    FmdFastGeo& g = L.fg;
+    g.iq = (uint64_t)(uintptr_t)L.iq; g.iq_end = g.iq + L.total_bytes; g.chan_stride = L.chan_stride;
+    g.n_channels = L.n_channels; g.per = per; g.nt = P.nt; g.ns2 = (uint32_t)ns2; g.Qt = tl.Qt;
+    // the table whenever it fits (measured ~1 % faster than the closed form even where both apply: two scalar loads and
+    // no multiply-adds); FMD_FAST=1 keeps the closed form for A/B
+    if (P.nt <= FMD_FAST_ROWS && (tl.Rt != 0u || L.fast != 1u) ) {
+        for (uint32_t t = 0; t < P.nt; ++t) {
+            const FmdTile T = fmd_tile_fast(r, P, tl, L.ns, t);
+            if ((uint64_t)(T.jB - T.jA + 2) > L.lp_cap || 2ull * (uint64_t)(T.nHi - T.nLo) + 30u > L.raw_cap) return 0u;
+            L.rows[t] = FmdTileRow{2u * (uint32_t)T.nLo, 2u * (uint32_t)T.nHi, T.jA, T.jB, T.eq, T.er};
+        }
+        return 2u;
+    }
+    if (tl.Rt != 0u) return 0u;
     const int64_t jA_off = (int64_t)P.eq0 - tl.fq + (P.er0 >= tl.frr ? 1 : 0);
     const int64_t jB_off = (int64_t)P.eq0 + tl.Bq + (P.er0 + tl.Br >= r.sr ? 1 : 0);
     const int64_t lo_off2 = 2 * ((int64_t)r.D * (jA_off - 1) - P.p0), hi_off2 = 2 * ((int64_t)r.D * (jB_off + 1) - P.p0);
-    const uint64_t step2 = 2ull * r.D * tl.Qt, ns2 = 2ull * L.ns;
-    if (jA_off > 0 || step2 * P.nt + (uint64_t)(hi_off2 > 0 ? hi_off2 : 0) >= (1ull << 31) || ns2 >= (1ull << 31)) return false;
+    const uint64_t step2 = 2ull * r.D * tl.Qt;
+    if (jA_off > 0 || step2 * P.nt + (uint64_t)(hi_off2 > 0 ? hi_off2 : 0) >= (1ull << 31)) return 0u;
     // every tile: the same expressions as fmd_tile_fast (tests/test_plan_and_divides.py proves that one), plus the LDS sizing
     for (uint32_t t = 0; t < P.nt; ++t) {
         const FmdTile T = fmd_tile_fast(r, P, tl, L.ns, t);
         const int64_t ja = (int64_t)t * tl.Qt + jA_off, lo = (int64_t)t * step2 + lo_off2;
         const int64_t jA = ja > 0 ? ja : 0, jB = T.last ? (int64_t)P.M - 1 : (int64_t)t * tl.Qt + jB_off;
         const int64_t nLo2 = lo > 0 ? lo : 0, nHi2 = T.last ? (int64_t)ns2 : (int64_t)t * step2 + hi_off2;
-        if (jA != T.jA || jB != T.jB || nLo2 != 2ll * T.nLo || nHi2 != 2ll * T.nHi) return false;
-        if ((uint64_t)(jB - jA + 2) > L.lp_cap || (uint64_t)(nHi2 - nLo2) + 30u > L.raw_cap) return false;
+        if (jA != T.jA || jB != T.jB || nLo2 != 2ll * T.nLo || nHi2 != 2ll * T.nHi) return 0u;
+        if ((uint64_t)(jB - jA + 2) > L.lp_cap || (uint64_t)(nHi2 - nLo2) + 30u > L.raw_cap) return 0u;
     }
-    FmdFastGeo& g = L.fg;
-    g.iq = (uint64_t)(uintptr_t)L.iq; g.iq_end = g.iq + L.total_bytes; g.chan_stride = L.chan_stride;
-    g.n_channels = L.n_channels; g.per = per; g.nt = P.nt;
-    g.step2 = (uint32_t)step2; g.lo_off2 = (int32_t)lo_off2; g.hi_off2 = (int32_t)hi_off2; g.ns2 = (uint32_t)ns2;
-    g.Qt = tl.Qt; g.jA_off = (int32_t)jA_off; g.jB_off = (int32_t)jB_off;
-    return true;
+    g.step2 = (uint32_t)step2; g.lo_off2 = (int32_t)lo_off2; g.hi_off2 = (int32_t)hi_off2;
+    g.jA_off = (int32_t)jA_off; g.jB_off = (int32_t)jB_off;
+    return 1u;
 }
 
 hipError_t fmd_launch_tile(const FmdLaunch& L, hipStream_t stream)
@@ -750,7 +776,7 @@ hipError_t fmd_launch_tile(const FmdLaunch& L, hipStream_t stream)
     if (L.xcd_swizzle && L.n_channels >= 8u && L.tiles <= 65535u && per <= 65535u) {
         g = dim3(8u, L.tiles, per);
         K.xcd_swizzle = 3u;
-        K.fast = fmd_fast_geometry(K, per) ? 1u : 0u;
+        K.fast = fmd_fast_geometry(K, per);
     } else K.fast = 0u;
     switch (dh) {
         case 1: launch_one<1>(K, g, lds, stream); break;

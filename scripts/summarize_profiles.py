@@ -7,7 +7,7 @@ tag = sys.argv[1]
 rnd = sys.argv[2] if len(sys.argv) > 2 else "r02"
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src, pmc, out = os.path.join(root, "gpurun_out", tag), os.path.join(root, "gpurun_out", tag + "_pmc"), os.path.join(root, "profiles")
-KERNEL = "fmd_demod_tile_kernel<5, 256, true>"
+KERNEL = "fmd_demod_tile_kernel<5, 256, 2>"
 sys.path.insert(0, root)
 import bench as _bench   # kernel_source_hash(): ties the PMC summary to the sources it was measured on
 

@@ -1,5 +1,6 @@
 """GPU parity of the non-default kernel variants (same results by construction, selected by environment at
-Demod creation): 64/128-thread tile blocks (FMD_NT), the plain and index-arithmetic block mappings (FMD_XCD),
+Demod creation): 64/128-thread tile blocks (FMD_NT), the plain and index-arithmetic block mappings (FMD_XCD), the general and
+the table-driven prologue (FMD_FAST=0: general prologue, 1: closed-form geometry; the default prefers the per-tile table),
 the generic fallback kernel (FMD_FORCE_GENERIC).  The register-streaming and persistent kernels of round 1
 (measured slower) were removed in round 2."""
 import numpy as np
@@ -22,7 +23,7 @@ def blocks_for(fmd, nch, ncalls, seed, n=None):
     return out
 
 
-@pytest.mark.parametrize("env", [{"FMD_NT": "128"}, {"FMD_NT": "64"}, {"FMD_XCD": "0"}, {"FMD_XCD": "1"},
+@pytest.mark.parametrize("env", [{"FMD_NT": "128"}, {"FMD_NT": "64"}, {"FMD_XCD": "0"}, {"FMD_XCD": "1"}, {"FMD_FAST": "0"}, {"FMD_FAST": "1"},
                                  {"FMD_FORCE_GENERIC": "1"}])
 @pytest.mark.parametrize("cfg", [CFG_24, CFG_REF, (4, 300000, 50000), (16, 62500, 31250)])
 def test_kernel_variants_bit_exact(fmd, oracle, monkeypatch, env, cfg):
