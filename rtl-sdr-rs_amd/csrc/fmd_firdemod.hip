@@ -51,6 +51,9 @@ constexpr int kGroupsPerWave = 4;                         // a wave accumulates 
 constexpr uint32_t kMaxOutputs = 64u * 4u * kGroupsPerWave;   // FIR outputs one tile can form
 typedef int fd_i4 __attribute__((ext_vector_type(4)));
 
+struct FdRow { int32_t jA, jB; uint32_t eq, er; };            // geometry of one tile (fmd_tile_fast), tabulated by the host
+constexpr uint32_t kFdRows = 192;                               // 3 KB of the 4 KB of kernel arguments
+
 struct FirDemodLaunch {
     // ---- FIR (same meaning as FirLaunch in fmd_fir.hip) ----
     const uint32_t* iq;        // [C][stride_w] dwords
@@ -82,6 +85,8 @@ struct FirDemodLaunch {
     uint32_t seq;
     int32_t f64_skew;
     uint32_t dbg;              // ablation bits, honoured by -DFMD_EXPERIMENT builds only
+    uint32_t use_rows;         // 1: rows[tile] holds the tile's geometry
+    FdRow rows[kFdRows];
 };
 
 #ifndef FD_PREXOR
@@ -146,7 +151,14 @@ __global__ void __launch_bounds__(kThreads, 8) fmd_firdemod_kernel(const FirDemo
 
     const FmdRates& r = L.r;
     const FmdClassPlan& P = L.P;
-    const FmdTile T = fmd_tile_fast(r, P, L.tl, 0u, t);      // k0, k1, jA, jB, eq, er (its input range is the boxcar's: unused)
+    FmdTile T;
+    if (L.use_rows) {                                        // tabulated by the host (fd_enqueue): no division, no comparisons
+        T.last = t + 1u == P.nt;
+        T.k0 = t * r.kt;
+        T.k1 = T.k0 + r.kt < P.K ? T.k0 + r.kt : P.K;
+        T.jA = L.rows[t].jA; T.jB = L.rows[t].jB; T.eq = L.rows[t].eq; T.er = L.rows[t].er;
+        T.nLo = T.nHi = 0;
+    } else T = fmd_tile_fast(r, P, L.tl, 0u, t);             // k0, k1, jA, jB, eq, er (its input range is the boxcar's: unused)
     const int jfirst = T.jA - 1, cnt = T.jB - jfirst + 1;    // lp[jfirst .. jB]; lp[-1] is demod_pre
     const uint32_t o0 = jfirst > 0 ? (uint32_t)jfirst : 0u;  // first FIR output (of this call) the tile forms
     const uint32_t no = (uint32_t)T.jB - o0 + 1u;            // FIR outputs formed
@@ -361,6 +373,7 @@ struct fmd_firdemod {
     uint32_t seq = 0;
     uint64_t f64_guarded = 0, f64_patched = 0;
     FmdStreamOrder order;
+    bool no_rows = false;                                 // FMD_FD_ROWS=0: geometry on the device (A/B)
     size_t lds_budget = 20480;                            // LDS per tile (8 tiles per CU); FMD_FD_LDS (tuning)
     hipStream_t stream = nullptr;
     uint8_t* d_iq = nullptr; size_t d_iq_cap = 0;
@@ -432,6 +445,14 @@ int fd_enqueue(fmd_firdemod* f, const void* d_iq, size_t nbytes, void* d_out, si
 #endif
     L.small = ((uint64_t)L.P.M * r.sr + 2ull * r.fr < (1u << 24) && (uint64_t)r.fr < (1u << 24)) ? 1u : 0u;
     L.inv_fr = 1.0f / (float)r.fr;
+    L.use_rows = 0u;
+    if (L.P.nt <= kFdRows && !f->no_rows) {
+        for (uint32_t t = 0; t < L.P.nt; ++t) {
+            const FmdTile T = fmd_tile_fast(r, L.P, L.tl, 0u, t);
+            L.rows[t] = FdRow{T.jA, T.jB, T.eq, T.er};
+        }
+        L.use_rows = 1u;
+    }
     uint32_t lc, rb; size_t lds;
     if (!fd_sizes(f, r.kt, &lc, &rb, &lds)) { fmd_internal_set_err("tile sizing failed"); return FMD_ERR_UNSUPPORTED; }
     FD_TRY(f->order.before(stream));
@@ -522,6 +543,7 @@ int fmd_firdemod_new(const int16_t* taps, uint32_t n_taps, uint32_t decim, uint3
     uint32_t kt_env = 0;
     if (const char* e = getenv("FMD_FD_KT")) kt_env = (uint32_t)atoi(e);
     if (const char* e = getenv("FMD_FD_LDS")) f->lds_budget = (size_t)atoi(e);
+    if (const char* e = getenv("FMD_FD_ROWS")) f->no_rows = e[0] == '0';
     for (uint32_t kt = 1; kt <= 1024; ++kt) {
         if ((uint64_t)r.sr * (kt + 2) >= (1u << 24)) break;
         uint32_t lc, rb; size_t l;
