@@ -214,7 +214,8 @@ int fmd_fir_filter_device(fmd_fir *f, const void *d_iq, size_t nbytes, void *d_o
  *     lp[m] = floor( sum_{t < n_taps} taps[t] * x[decim * m + t] / 2^shift ),
  * followed by the reference's own fm_demod (:355-367, the f64 sample at the first filter output of every call) and
  * low_pass_real (:408-426, rate_out -> rate_resample).  With taps = 1...1, n_taps == decim == downsample, shift == 0
- * it returns exactly what fmd_demod_* (and the reference) return -- tested bit for bit; that is its anchor.
+ * it returns exactly what fmd_demod_* (and the oracle of the reference chain) return -- tested bit for bit; that is
+ * its anchor.
  * Domain: decim even and <= 64, 1 <= n_taps <= 1024, |taps| <= 2047, (128 * sum|taps|) >> shift <= 16384 (so that
  * |lp| stays in the discriminator's range, the boxcar's bound at downsample 128), shift <= 24.
  * A call that yields fewer than 2 filter outputs returns FMD_ERR_TOO_SHORT (assert at :356) and changes nothing.
