@@ -113,7 +113,7 @@ int choose_tiling(fmd_demod* d, uint32_t kt_req)
         const uint32_t nt_threads = d->block_threads, waves = nt_threads / 64u;
         const double budget = 20480.0 * (double)nt_threads / 256.0;
         const uint32_t dh = r.D % 2 == 0 && r.D / 2 <= 5 ? r.D / 2 : r.D;   // dwords per window (odd / large D: byte loop)
-        const double c_round = 64.0 + 12.0 * dh, c_audio = 70.0 + 6.0 * (double)(r.fr / r.sr), c_fixed = 150.0;
+        const double c_round = 64.0 + 12.0 * dh, c_audio = 70.0 + 6.0 * (double)(r.fr / r.sr), c_fixed = 60.0;   // (150 before the fast prologue)
         double best = 0.0;
         kt = 1;
         for (uint32_t k = 1; k <= 1024u; ++k) {
@@ -125,7 +125,10 @@ int choose_tiling(fmd_demod* d, uint32_t kt_req)
             const uint64_t cnt = ((uint64_t)k * r.fr + r.sr - 1) / r.sr + 1;            // decimated samples formed
             const uint64_t rounds = (cnt + 126) / 127, per_wave = (rounds + waves - 1) / waves;
             const uint64_t passes = (k + nt_threads - 1) / nt_threads;
-            const double work = per_wave * c_round + passes * c_audio + c_fixed + (((uint64_t)k * r.fr) % r.sr ? 25.0 : 0.0);
+            // a tile's time follows its busiest wave, the chip's issue slots follow the sum over the waves: both count
+            // (122 audio samples per tile = 8 rounds measured 1 % slower than 118 = 7 rounds at the bench configuration)
+            const double round_cost = 0.5 * (double)per_wave + 0.5 * (double)rounds / (double)waves;
+            const double work = round_cost * c_round + passes * c_audio + c_fixed;
             const double per_byte = work / (2.0 * r.D * (double)cnt);
             if (k == 1 || per_byte < best) { best = per_byte; kt = k; }
         }
