@@ -13,6 +13,7 @@
 
 #include <cstdint>
 #include <cstdio>
+#include <functional>
 #include <stdexcept>
 #include <string>
 #include <utility>
@@ -114,6 +115,45 @@ private:
     DemodConfig config_;
     uint32_t n_;
     fmd_demod* h_ = nullptr;
+};
+
+// The receive -> mpsc -> process -> output hand-off of the example (simple_fm.rs:55-60,114-127,150-156) with the GPU(s)
+// as consumer: fmd_sink_* (new surface, see include/fmd.h).  `on_audio(seq, channel, samples, n)` is output() per
+// channel, called in submission order from inside acquire() / drain() on the caller's thread.
+class Sink {
+public:
+    using Callback = std::function<void(uint64_t seq, uint32_t channel, const int16_t* samples, size_t n)>;
+
+    Sink(const DemodConfig& config, uint32_t n_channels, size_t nbytes, const std::vector<int32_t>& device_ids,
+         uint32_t depth, Callback on_audio)
+        : n_(n_channels), nbytes_(nbytes), cb_(std::move(on_audio))
+    {
+        check(fmd_sink_new(&config, n_channels, device_ids.data(), (uint32_t)device_ids.size(), nbytes, depth, &Sink::trampoline,
+                           this, &h_));
+    }
+    ~Sink() { fmd_sink_free(h_); }
+    Sink(const Sink&) = delete;
+    Sink& operator=(const Sink&) = delete;
+
+    // the next slot to fill: n_channels buffers of nbytes back to back (page-locked; read_sync writes straight into it)
+    uint8_t* acquire() { uint8_t* p = nullptr; check(fmd_sink_acquire(h_, &p)); return p; }
+    void submit() { check(fmd_sink_submit(h_)); }
+    void drain() { check(fmd_sink_drain(h_)); if (status_ != FMD_OK) throw Error(status_); }
+    uint32_t channels() const { return n_; }
+    size_t nbytes() const { return nbytes_; }
+
+private:
+    static void trampoline(void* user, uint64_t seq, const int16_t* audio, const size_t* out_len, size_t out_cap, int status)
+    {
+        Sink* self = static_cast<Sink*>(user);
+        if (status != FMD_OK) { if (self->status_ == FMD_OK) self->status_ = status; return; }
+        for (uint32_t c = 0; c < self->n_; ++c) self->cb_(seq, c, audio + (size_t)c * out_cap, out_len[c]);
+    }
+    uint32_t n_;
+    size_t nbytes_;
+    Callback cb_;
+    int status_ = FMD_OK;
+    fmd_sink* h_ = nullptr;
 };
 
 // output(buf: Vec<i16>), simple_fm.rs:430-438: raw native-endian s16 to stdout, flushed.

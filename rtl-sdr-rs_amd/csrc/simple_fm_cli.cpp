@@ -8,7 +8,8 @@
 // (:25-27) through optimal_settings (:48,189-214).
 //
 // Several input files: one channel per file in ONE bank (one Demod per stream, :137), block-synchronous; audio of
-// file k goes to <prefix>.<k>.s16 (-o prefix, default "audio") and the run ends with the shortest file.
+// file k goes to <prefix>.<k>.s16 (-o prefix, default "audio") and the run ends with the shortest file.  With -g N the
+// same goes through the pipelined multi-GPU sink (fmd_sink_*): channels split over N devices, byte-identical output.
 //
 // EOF policy (the reference ignores the read count and never terminates at EOF): only COMPLETE
 // blocks are demodulated; a trailing partial block is dropped with a note on stderr.  Logging goes to stderr
@@ -20,6 +21,49 @@
 #include <vector>
 
 #include "demod.hpp"
+
+// one channel per file through the pipelined sink (-g N): the channels are split over N GPUs (device k % visible), the
+// file reads of block n+1 overlap the transfers and the kernel of block n
+static int run_sink(const std::vector<const char*>& paths, const char* prefix, uint32_t freq, uint32_t rate, uint32_t resample, int gpus)
+{
+    const size_t C = paths.size(), N = fm::DEFAULT_BUF_LENGTH;
+    std::vector<FILE*> in(C, nullptr), out(C, nullptr);
+    int rc = 0;
+    try {
+        for (size_t c = 0; c < C; ++c) {
+            if (!(in[c] = fopen(paths[c], "rb"))) { perror(paths[c]); throw 2; }
+            char name[4096];
+            snprintf(name, sizeof name, "%s.%zu.s16", prefix, c);
+            if (!(out[c] = fopen(name, "wb"))) { perror(name); throw 2; }
+        }
+        int visible = 0;
+        fm::check(fmd_device_count(&visible));
+        if (visible < 1) throw fm::Error(FMD_ERR_NO_DEVICE);
+        if ((size_t)gpus > C) gpus = (int)C;
+        std::vector<int32_t> ids;
+        for (int k = 0; k < gpus; ++k) ids.push_back(k % visible);
+        const auto settings = fm::optimal_settings(freq, rate, resample);
+        fm::Sink sink(settings.second, (uint32_t)C, N, ids, 3,
+                      [&](uint64_t, uint32_t c, const int16_t* a, size_t n) { if (n) fwrite(a, sizeof(int16_t), n, out[c]); });
+        size_t loops = 0;
+        for (;; ++loops) {
+            uint8_t* slot = sink.acquire();
+            bool full = true;
+            for (size_t c = 0; c < C && full; ++c) full = fread(slot + c * N, 1, N, in[c]) == N;
+            if (!full) break;                                   // the shortest file ends the run; partial blocks dropped
+            sink.submit();
+        }
+        sink.drain();
+        fprintf(stderr, "%zu channels x %zu blocks on %d device part(s)\n", C, loops, gpus);
+    } catch (const fm::Error& e) {
+        fprintf(stderr, "error: %s\n", e.what());
+        rc = 1;
+    } catch (int code) {
+        rc = code;
+    }
+    for (size_t c = 0; c < C; ++c) { if (in[c]) fclose(in[c]); if (out[c]) { fflush(out[c]); fclose(out[c]); } }
+    return rc;
+}
 
 // one channel per file, all channels in one bank
 static int run_bank(const std::vector<const char*>& paths, const char* prefix, uint32_t freq, uint32_t rate, uint32_t resample)
@@ -60,6 +104,7 @@ int main(int argc, char** argv)
 {
     uint32_t rate = 170000, resample = 32000, freq = 94900000;
     size_t per_launch = 1;                                   // -b: reference blocks handed to the GPU per launch
+    int gpus = 0;                                            // -g N: several files through the pipelined sink on N GPUs
     const char* path = nullptr;
     const char* prefix = "audio";
     std::vector<const char*> paths;
@@ -68,14 +113,16 @@ int main(int argc, char** argv)
         else if (!strcmp(argv[i], "-r") && i + 1 < argc) resample = (uint32_t)strtoul(argv[++i], nullptr, 10);
         else if (!strcmp(argv[i], "-f") && i + 1 < argc) freq = (uint32_t)strtoul(argv[++i], nullptr, 10);
         else if (!strcmp(argv[i], "-o") && i + 1 < argc) prefix = argv[++i];
+        else if (!strcmp(argv[i], "-g") && i + 1 < argc) gpus = atoi(argv[++i]);
         else if (!strcmp(argv[i], "-b") && i + 1 < argc) { per_launch = strtoul(argv[++i], nullptr, 10); if (!per_launch) per_launch = 1; }
         else if (!strcmp(argv[i], "-h") || !strcmp(argv[i], "--help")) {
             fprintf(stderr, "usage: %s [-f freq_hz] [-s sample_rate_hz] [-r resample_hz] [-b blocks_per_launch] <capture.bin | ->\n"
-                            "       %s [-s ...] [-r ...] [-o prefix] <a.bin> <b.bin> ...   (one channel per file)\n", argv[0], argv[0]);
+                            "       %s [-s ...] [-r ...] [-o prefix] [-g n_gpus] <a.bin> <b.bin> ...   (one channel per file)\n", argv[0], argv[0]);
             return 0;
         } else paths.push_back(argv[i]);
     }
     if (paths.empty()) { fprintf(stderr, "missing input file (use - for stdin)\n"); return 2; }
+    if (paths.size() > 1 && gpus > 0) return run_sink(paths, prefix, freq, rate, resample, gpus);
     if (paths.size() > 1) return run_bank(paths, prefix, freq, rate, resample);
     path = paths[0];
     FILE* in = strcmp(path, "-") ? fopen(path, "rb") : stdin;

@@ -70,3 +70,13 @@ def test_cli_bank_mode_one_channel_per_file(fmd, oracle, tmp_path):
         got = np.fromfile("%s.%d.s16" % (prefix, k), dtype=np.int16)
         exp = oracle_file_mode(oracle, cfg, datas[k][:2 * N], N)
         assert got.size == exp.size and np.array_equal(got, exp), k
+    # the same through the pipelined multi-GPU sink (-g N; device parts share the one GPU of a single-GPU box)
+    for g in ("1", "2"):
+        prefix2 = str(tmp_path / ("sink" + g))
+        r2 = subprocess.run([CLI, "-g", g, "-o", prefix2] + paths, capture_output=True, timeout=120)
+        assert r2.returncode == 0, r2.stderr.decode()
+        assert ("3 channels x 2 blocks on %s device part(s)" % g).encode() in r2.stderr
+        for k in range(3):
+            a = np.fromfile("%s.%d.s16" % (prefix2, k), dtype=np.int16)
+            b = np.fromfile("%s.%d.s16" % (prefix, k), dtype=np.int16)
+            assert np.array_equal(a, b), (g, k)
