@@ -194,6 +194,13 @@ impl Demod {
         Ok(out)
     }
 
+    /// Completion / verification point after device-side launches (`fmd_demod_check`): waits, surfaces device-side
+    /// assertions and settles the guarded f64 samples against the host libm.  The host entry points used by
+    /// `demodulate` do this themselves; it is here for callers that drive `fmd_demod_demodulate_device` directly.
+    pub fn check(&mut self) -> Result<()> {
+        check(unsafe { fmd_demod_check(self.handle) })
+    }
+
     pub fn state(&mut self) -> Result<DemodState> {
         let mut s = DemodState::default();
         check(unsafe { fmd_demod_get_state(self.handle, 0, &mut s) })?;
