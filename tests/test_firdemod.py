@@ -127,3 +127,40 @@ def test_gpu_fused_errors(fmd):
     with pytest.raises(fmd.FmdError) as ei:
         b.demodulate_batch(np.zeros((1, 8), np.uint8))                                 # one filter output: assert at :356
     assert ei.value.status == -3
+
+
+@pytest.mark.gpu
+def test_gpu_fused_fuzz(fmd, oracle):
+    """Random taps / decimation / shift / rates / call sizes, streaming (history, resampler phase and partial sums
+    carried), against the oracle's composition.  FMD_FUZZ_CASES scales the number of cases."""
+    import os
+    n_cases = int(os.environ.get("FMD_FUZZ_CASES", "30"))
+    rng = np.random.default_rng(int(os.environ.get("FMD_FUZZ_SEED", "777")))
+    for case in range(n_cases):
+        M = 2 * int(rng.choice([1, 2, 3, 4, 5, 8, 16, 25, 32]))
+        T = int(rng.choice([1, 2, 3, 7, 16, 31, 64, 127, 128, 200, 513]))
+        taps = rng.integers(-2047, 2048, T).astype(np.int16) if rng.integers(0, 4) else np.ones(T, np.int16)
+        shift = fmd.auto_shift(taps) + int(rng.integers(0, 4))
+        slow = int(rng.choice([8000, 32000, 44100, 48000]))
+        fast = slow * int(rng.integers(1, 60)) + int(rng.integers(0, slow)) * int(rng.integers(0, 2))
+        nch = int(rng.integers(1, 5))
+        try:
+            fd = fmd.FirDemodBank(taps, M, fast, slow, nch, shift=shift)
+        except fmd.FmdError as e:
+            assert e.status == -6, (T, M, fast, slow, e)                     # outside the documented domain only
+            continue
+        hs = [oracle.firdemod_new(taps, M, shift, fast, slow) for _ in range(nch)]
+        first = 8 * ((T + 2 * M) // 4 + 2)
+        for call in range(int(rng.integers(2, 6))):
+            n = first if call == 0 else 8 * int(rng.integers(M, 2500))
+            iq = rng.integers(0, 256, (nch, n), dtype=np.uint8)
+            if rng.integers(0, 5) == 0:
+                iq[:] = np.where(rng.integers(0, 2, (nch, n)) > 0, 255, 0)
+            got = fd.demodulate_batch(iq)
+            for c in range(nch):
+                exp = oracle.firdemod(hs[c], iq[c])
+                assert got[c].shape == exp.shape and np.array_equal(got[c], exp), (case, T, M, shift, fast, slow, call, c, n)
+        for c in range(nch):
+            assert state_tuple(fd.get_state(c).as_dict()) == state_tuple(oracle.firdemod_state(hs[c])), (case, c)
+            oracle.lib.fmo_firdemod_free(hs[c])
+        fd.close()
