@@ -337,6 +337,8 @@ def main():
                        "channels_per_gpu": nch, "block_bytes": BLOCK, "downsample": D, "rate_out": FAST,
                        "rate_resample": SLOW, "audio_per_call": int(lens[0]), "tiling": bank.tiling(),
                        "settle_steps_untimed": args.settle,
+                       "runtime": {"hip": getattr(torch.version, "hip", None), "torch": torch.__version__,
+                                   "device": torch.cuda.get_device_name(dev_index)},
                        "parallelism": "channels sharded x%d, no collective" % world},
             "timing": {"regions": len(regions), "steps_per_region": args.steps, "statistic": "median region, max over ranks",
                        "ms_per_step_min": round(walls[0] / args.steps * 1e3, 4),

@@ -52,6 +52,10 @@ def check_stream(fmd, oracle, D, fast, slow, blocks, n_channels=1, kt=None):
 def test_library_and_device(fmd):
     assert fmd.device_count() >= 1, "no gfx950 device: the product has no CPU path"
     assert fmd.lib().fmd_version() >= 1
+    import torch
+    # the f64 sample is guarded against ocml / libm differences (test_gpu_f64_guard.py); the versions these results
+    # were produced with are recorded anyway
+    print("runtime: hip %s, torch %s, %s" % (getattr(torch.version, "hip", None), torch.__version__, torch.cuda.get_device_name(0)))
 
 
 def test_synth_gpu_equals_numpy(fmd):
