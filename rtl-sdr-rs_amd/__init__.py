@@ -9,9 +9,9 @@ from ._ffi import (DEFAULT_BUF_LENGTH, DemodConfig, DemodState, DeviceConfig, Fm
                    SynthParams, build, check, lib)
 from .demod import Demod, DemodBank, PinnedBuffer, device_count, optimal_settings, out_cap
 from .fir import FirBank, FirDemodBank, auto_shift
-from .sink import Sink
+from .sink import Sink, pump
 from . import shard, synth
 
-__all__ = ["DEFAULT_BUF_LENGTH", "Demod", "DemodBank", "PinnedBuffer", "FirBank", "Sink", "FirDemodBank", "auto_shift", "DemodConfig", "DemodState", "DeviceConfig", "FmdError",
+__all__ = ["DEFAULT_BUF_LENGTH", "Demod", "DemodBank", "PinnedBuffer", "FirBank", "Sink", "pump", "FirDemodBank", "auto_shift", "DemodConfig", "DemodState", "DeviceConfig", "FmdError",
            "RadioConfig", "SynthParams", "build", "check", "lib", "device_count", "optimal_settings", "out_cap",
            "shard", "synth"]

@@ -65,3 +65,23 @@ class Sink:
         cap, nd, fl = C.c_size_t(), C.c_uint32(), C.c_uint32()
         check(lib().fmd_sink_info(self._h, C.byref(cap), C.byref(nd), C.byref(fl)))
         return {"out_cap": cap.value, "n_devices": nd.value, "in_flight": fl.value}
+
+
+def pump(sources, sink, max_buffers=None):
+    """receive() of the example (simple_fm.rs:100-132) for many streams: every source fills its row of the next slot
+    with `read_sync` (src/lib.rs:153; e.g. rtl_tcp_source.RtlTcpSource, any object with read_sync(buf) -> bytes
+    written), the slot is submitted, repeat.  A short read on any source ends the run like the reference's
+    "samples lost" exit (:122-125).  Returns the number of buffers submitted; completion callbacks run on this
+    thread, the rest of them inside the final drain()."""
+    if len(sources) != sink.n_channels:
+        raise ValueError("one source per channel")
+    n = 0
+    while max_buffers is None or n < max_buffers:
+        slot = sink.acquire()
+        if any(src.read_sync(slot[c]) < sink.nbytes for c, src in enumerate(sources)):
+            break
+        sink.submit()
+        n += 1
+    # an acquired but unsubmitted slot is simply dropped with the sink; everything submitted is delivered
+    sink.drain()
+    return n

@@ -92,3 +92,31 @@ def test_stream_fm_over_rtl_tcp_matches_oracle(fmd, oracle):
     exp, _ = oracle.demodulate_stream(cfg, data[:3 * N], N)
     assert np.array_equal(np.frombuffer(sink.getvalue(), dtype=np.int16), exp)
     assert (rts.CMD_SET_FREQUENCY, 95_155_000) in srv.commands     # offset tuning of optimal_settings (:195)
+
+
+@pytest.mark.gpu
+def test_three_rtl_tcp_streams_through_the_sink(fmd, oracle):
+    """Three rtl_tcp servers (three dongles on other hosts) -> one pipelined sink with two device parts: the
+    receive -> hand-off -> process -> output structure of simple_fm.rs:55-60 for several streams at once."""
+    N = fmd.DEFAULT_BUF_LENGTH
+    datas = [fmd.synth.synth_iq(1, 4 * N + 776 * k, seed=500 + k, amplitude=50 + 20 * k)[0] for k in range(3)]
+    servers = [FakeServer(d.tobytes()) for d in datas]
+    _, cfg = fmd.optimal_settings(94_900_000, 170_000)
+    audio = [[] for _ in range(3)]
+
+    def on_audio(seq, rows, status):
+        assert status == 0
+        for c in range(3):
+            audio[c].append(rows[c])
+
+    sink = fmd.Sink(cfg, 3, N, device_ids=[0, 1 % fmd.device_count()], depth=3, on_audio=on_audio)
+    srcs = [rts.RtlTcpSource("127.0.0.1", s.port) for s in servers]
+    n = fmd.pump(srcs, sink)
+    assert n == 4                                               # the 5th read is short on every stream
+    for s in srcs:
+        s.close()
+    _, ocfg = oracle.optimal_settings(94_900_000, 170_000)
+    for c in range(3):
+        exp, _ = oracle.demodulate_stream(ocfg, datas[c][:4 * N], N)
+        assert np.array_equal(np.concatenate(audio[c]), exp), c
+    sink.close()
