@@ -38,14 +38,18 @@ MIN_TIMED_S = 0.050              # repeat the K-step region until this much has 
 PMC_SUMMARY = os.path.join("profiles", "r02_pmc_summary.json")
 
 
+# what the headline kernel is built from (the FIR kernels, the sink and the CLI do not enter it)
+HEADLINE_SOURCES = ("fmd_tile_kernel.hip", "fmd_kernels.h", "fmd_device.h", "fmd_index.h", "fmd_host.h", "fmd_internal.h",
+                    "fmd_api.cpp")
+
+
 def kernel_source_hash():
-    """sha256 over the kernel sources: ties a committed PMC summary to the code it was measured on."""
+    """sha256 over the headline kernel's sources: ties a committed PMC summary to the code it was measured on."""
     h = hashlib.sha256()
     csrc = os.path.join(ROOT, "rtl-sdr-rs_amd", "csrc")
-    for f in sorted(os.listdir(csrc)):
-        if f.endswith((".hip", ".h", ".cpp")) and f != "simple_fm_cli.cpp":      # the CLI is host glue above the C ABI
-            h.update(f.encode())
-            h.update(open(os.path.join(csrc, f), "rb").read())
+    for f in HEADLINE_SOURCES:
+        h.update(f.encode())
+        h.update(open(os.path.join(csrc, f), "rb").read())
     return h.hexdigest()[:16]
 
 
@@ -355,6 +359,26 @@ def main():
                          "kernel_ms_events_per_launch_min_max": [round(per_launch[0], 4), round(per_launch[-1], 4)]},
         }
         if world == 1 and not args.no_extra:
+            # what this box's HBM does on a plain device-to-device copy of one input batch (SURVEY 8d asks for the
+            # measured reference beside the 8 TB/s spec): bytes read + bytes written over the HIP-event time
+            try:
+                dst = torch.empty_like(bufs[1])
+                for _ in range(3):
+                    dst.copy_(bufs[0])
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(10):
+                    dst.copy_(bufs[0])
+                e1.record()
+                torch.cuda.synchronize()
+                copy_gbs = 2 * bufs[0].numel() * 10 / (e0.elapsed_time(e1) * 1e-3) / 1e9
+                res["roofline"]["box_reference"] = {
+                    "d2d_copy_GBps": round(copy_gbs, 1),
+                    "what": "hipMemcpyDtoD (torch copy_) of one %d-byte input batch on this box, read + write bytes / HIP-event time; "
+                            "the kernel's `achieved` is %.2f x this" % (bufs[0].numel(), achieved / copy_gbs)}
+                del dst
+            except Exception as e:
+                res["roofline"]["box_reference"] = {"error": repr(e)}
             del bufs[1:]
             res["extra"] = {}
             for name, fused in (("config4_fir", False), ("config4_fir_demod_fused", True)):

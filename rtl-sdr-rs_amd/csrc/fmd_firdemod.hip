@@ -15,9 +15,10 @@
 //      banded tap matrix); instead of 8 bytes per output going to HBM the normalised sample is packed to
 //      re | im << 16 and kept in LDS,
 //   3. discriminator per output against its predecessor (disc_nosel: |lp| <= 16384 is enforced at creation; the f64
-//      sample of the call start on one lane, guarded like the boxcar kernel's),
-//   4. low_pass_real: 16 lanes per audio sample sum its group (decimation ratios of a tapped front end are large:
-//      52 discriminator samples per audio sample at 2.5 Msps -> 48 kHz), DPP reduction, one exact small divide.
+//      sample of the call start on one lane, guarded like the boxcar kernel's): `lg` lanes per audio group, each taking
+//      `ch` consecutive samples of it and adding its partial sum to the group's accumulator in LDS (decimation ratios of
+//      a tapped front end are large: 52 discriminator samples per audio sample at 2.5 Msps -> 48 kHz = 14 lanes x 4),
+//   4. low_pass_real: one exact small divide per audio sample.
 // HBM traffic: the u8 input once + 2 bytes per AUDIO sample (the stand-alone FIR writes 8 bytes per output).
 #include "../../include/fmd.h"
 
@@ -67,8 +68,6 @@ struct FirDemodLaunch {
     uint32_t n_pass, col_bytes, shift;
     int32_t mre[2], mim[2];
     uint32_t n_channels, tiles, xcd;
-    uint32_t small;            // 1: the group lookups fit the exact f32-reciprocal divide (fmd_udiv_small)
-    float inv_fr;
     // ---- demod (fmd_index.h) ----
     FmdRates r;
     FmdClassPlan P;            // M = FIR outputs of this call, K = audio samples, nt, eq0, er0 (p0 = 0)
@@ -86,6 +85,8 @@ struct FirDemodLaunch {
     int32_t f64_skew;
     uint32_t dbg;              // ablation bits, honoured by -DFMD_EXPERIMENT builds only
     uint32_t use_rows;         // 1: rows[tile] holds the tile's geometry
+    uint32_t lg, lg_magic, ch; // discriminator pass: `lg` lanes per audio group (tid / lg = tid * lg_magic >> 16), `ch` consecutive samples per lane
+    uint32_t sr_shift;         // log2(sr) when the reduced resample rate is a power of two, else 32
     FdRow rows[kFdRows];
 };
 
@@ -142,7 +143,8 @@ template <int NKU>
 __global__ void __launch_bounds__(kThreads, 8) fmd_firdemod_kernel(const FirDemodLaunch L)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
-    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u;
+    const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid >> 6));   // scalar: the group tests below become s_cbranch
     __builtin_amdgcn_s_setprio(3);                           // get the loads out first (see fmd_tile_kernel.hip)
     uint32_t c, t;
     if (L.xcd == 3u) { c = blockIdx.x * gridDim.z + blockIdx.z; t = blockIdx.y; }   // grid (8, tiles, ceil(C / 8))
@@ -176,7 +178,7 @@ __global__ void __launch_bounds__(kThreads, 8) fmd_firdemod_kernel(const FirDemo
     const gq amat = (gq)(uintptr_t)L.amat + lane;
     fd_i4 A[NKU];                                            // first pass' tap fragments: in flight with the data
 #pragma unroll
-    for (int k = 0; k < NKU; ++k) A[k] = amat[k * 64];
+    for (int k = 0; k < NKU; ++k) A[k] = FD_ABLATE(4) ? fd_i4{(int)lane, k, 1, 2} : amat[k * 64];
 
     const bool fast = ((((uintptr_t)L.iq + ((uint64_t)c * L.stride_w + (uint64_t)w0 - L.Hw) * 4u)) & 15u) == 0u;
     const bool whole = fast && w0 >= L.Hw && (uint64_t)(w0 - L.Hw) + 4ull * nq <= L.stride_w;
@@ -233,16 +235,17 @@ __global__ void __launch_bounds__(kThreads, 8) fmd_firdemod_kernel(const FirDemo
     // the window-parity constant, normalise, pack to re | im << 16 and keep it in LDS
     const uint32_t par_tile = (L.par_first + o0 * L.half_M) & 1u;
     const uint32_t par = (par_tile ^ (L.half_M * q)) & 1u;
-    const int cre = L.mre[par], cim = L.mim[par];
+    const int cre = par ? L.mre[1] : L.mre[0], cim = par ? L.mim[1] : L.mim[0];   // two scalars + a select (an indexed kernel-argument array is a VMEM load)
+    const uint32_t sgn = 0u - par_tile;                      // wave-uniform sign mask: (v ^ m) - m = m ? -v : v
 #pragma unroll
     for (int gi = 0; gi < kGroupsPerWave; ++gi) {
         const uint32_t g = wave + 4u * gi;
         const uint32_t o = 64u * g + 4u * j + q;
         if (g < groups && o < no) {
-            int re = acc[gi].x + (acc[gi].y << 7), im = acc[gi].z + (acc[gi].w << 7);
-            if (par_tile) { re = -re; im = -im; }
-            re = (re + cre) >> L.shift; im = (im + cim) >> L.shift;          // floor(y / 2^shift)
-            ypk[(int)(o0 + o) - jfirst] = pack_lp(re, im);
+            const uint32_t ure = (uint32_t)acc[gi].x + ((uint32_t)acc[gi].y << 7), uim = (uint32_t)acc[gi].z + ((uint32_t)acc[gi].w << 7);
+            const int re = ((int)((ure ^ sgn) - sgn) + cre) >> L.shift;          // floor(y / 2^shift)
+            const int im = ((int)((uim ^ sgn) - sgn) + cim) >> L.shift;
+            ypk[(int)(o0 + o) - jfirst] = __builtin_amdgcn_perm((uint32_t)im, (uint32_t)re, 0x05040100u);   // re | im << 16
         }
     }
     if (jfirst < 0 && tid == 0) ypk[0] = pack_lp(st.demod_pre_re, st.demod_pre_im);     // lp[-1]
@@ -259,51 +262,56 @@ __global__ void __launch_bounds__(kThreads, 8) fmd_firdemod_kernel(const FirDemo
     __syncthreads();
 
     // ---- fm_demod (:355-367) + the sums of low_pass_real (:408-417) ----------------------------------------------
-    // A thread takes `ch` CONSECUTIVE discriminator samples and adds them up per audio group as it goes (a group is
-    // fa or fa + 1 samples long: with 52 per group a thread's run touches one group, rarely two), then adds its
-    // partial sums to the tile's group accumulators in LDS.  The resampler that is left is one divide per audio
-    // sample.  (Summing groups in a separate pass over an array of discriminator samples cost 115 VALU instructions
-    // per wave -- every lane of a group redoing the index arithmetic -- against 171 for the discriminator itself.)
+    // `lg` lanes per audio group, each taking `ch` CONSECUTIVE discriminator samples of it (chosen by the host so
+    // that lanes x ch covers the longest group, fa + 1 samples, and a tile's groups fit one pass of the 256 threads): the group's first and last sample come from ONE small
+    // division per lane (as in the boxcar kernel's resampler), a lane never crosses a group, and it adds its partial sum
+    // to the group's accumulator in LDS with one atomic.  The resampler that is left is one divide per audio sample.
+    // History: summing groups in a separate pass over an array of discriminator samples cost 115 VALU instructions per
+    // wave; a lane walking 4 samples from an arbitrary start and tracking the group boundaries itself needed two exact
+    // divisions per lane plus a boundary test per sample (~270 per wave in all, against ~200 here).
     const uint32_t nk = T.k1 - T.k0;
-    const uint32_t ch = ((uint32_t)cnt - 1u + kThreads - 1u) / kThreads;
+    const uint32_t ng = nk + (T.last ? 1u : 0u);             // + the trailing partial group that is carried to the next call
     int d_first = 0, cr0 = 0, ci0 = 0;
     bool any_guard = false;
     {
-        const int i_lo = 1 + (int)(tid * ch), i_hi = i_lo + (int)ch <= cnt ? i_lo + (int)ch : cnt;   // samples [i_lo, i_hi)
-        if (i_lo < i_hi && !FD_ABLATE(1)) {
-            const int j_lo = jfirst + i_lo;
-            // audio sample k whose group holds j_lo, and where that group ends: e(k) = ((k + 1) fr - i0r - 1) / sr
-            const uint32_t k = L.small ? fmd_udiv_small((uint32_t)j_lo * r.sr + P.i0r, r.fr, L.inv_fr) : ((uint32_t)j_lo * r.sr + P.i0r) / r.fr;
-            const uint32_t xk = (k + 1u) * r.fr - P.i0r - 1u;
-            uint32_t e = L.small ? fmd_udiv_small(xk, r.sr, L.inv_sr) : xk / r.sr;
-            uint32_t rem = xk - e * r.sr;
-            uint32_t q = k - T.k0;                           // the tile's local audio index (>= nk: the carried tail)
-            int part = 0;
-            uint32_t prev = ypk[i_lo - 1];
-            for (int i = i_lo; i < i_hi; ++i) {
-                const int j = jfirst + i;
-                while ((uint32_t)j > e) {                    // next group: e(k + 1) from e(k) by the remainder
-                    atomicAdd(&gsum[q < nk ? q : nk], part);
-                    part = 0; ++q;
-                    rem += L.fb; e += L.fa;
-                    if (rem >= r.sr) { rem -= r.sr; ++e; }
+        const uint32_t gq0 = (tid * L.lg_magic) >> 16, lg = tid - gq0 * L.lg;           // tid / lg, tid % lg
+        const uint32_t gpp = ((uint32_t)kThreads * L.lg_magic) >> 16;                    // whole groups per pass: the lanes beyond
+        for (uint32_t gq = gq0 < gpp ? gq0 : ng; gq < ng && !FD_ABLATE(1); gq += gpp) { //   gpp * lg sit out
+            // audio sample k0 + gq ends at e = eq + gq * fa + (er + gq * fb) / sr and holds fa samples, or fa + 1 when the
+            // remainder of that division is below fb (fmd_tile_kernel.hip, low_pass_real)
+            const uint32_t x = T.er + gq * L.fb;
+            uint32_t u, xrem;
+            if (L.sr_shift < 32u) { u = x >> L.sr_shift; xrem = x & (r.sr - 1u); }
+            else { u = fmd_udiv_small(x, r.sr, L.inv_sr); xrem = x - u * r.sr; }
+            int e = (int)(T.eq + gq * L.fa + u);
+            int s = e - (int)L.fa + (xrem < L.fb ? 0 : 1);
+            s = s > 0 ? s : 0;                               // the call's first group starts at sample 0
+            e = e < T.jB ? e : T.jB;                         // the carried group ends with the call
+            const int j0 = s + (int)(lg * L.ch);
+            const int j1 = j0 + (int)L.ch - 1 < e ? j0 + (int)L.ch - 1 : e;
+            if (j0 <= j1) {
+                const uint32_t* yp = ypk + (j0 - jfirst);
+                uint32_t prev = yp[-1];
+                int part = 0;
+                for (int i = 0; i <= j1 - j0; ++i) {
+                    const uint32_t a = yp[i];
+                    part += (int)(int16_t)disc_nosel(a, prev);   // (:362) `as i16`, summed as i32 (:414)
+                    prev = a;
                 }
-                const uint32_t a = ypk[i];
-                int d;
-                if (j == 0) {                                // the first sample of the call: f64 path (:359), tid 0
-                    fmd_mul_conj(lp_re(a), lp_im(a), lp_re(prev), lp_im(prev), cr0, ci0);
+                if (j0 == 0) {                               // the first sample of the call takes the f64 path (:359): thread 0 only
+                    const uint32_t a = yp[0], b = yp[-1];
+                    fmd_mul_conj(lp_re(a), lp_im(a), lp_re(b), lp_im(b), cr0, ci0);
                     bool g;
-                    d = polar_f64(cr0, ci0, L.f64_guard, &g);
+                    int d = polar_f64(cr0, ci0, L.f64_guard, &g);
 #ifdef FMD_EXPERIMENT
                     if (g) d += L.f64_skew;
 #endif
                     any_guard = g;
                     d_first = (int)(int16_t)d;
-                } else d = disc_nosel(a, prev);              // (:362)
-                part += (int)(int16_t)d;                     // `as i16` (:362), summed as i32 (:414)
-                prev = a;
+                    part += d_first - (int)(int16_t)disc_nosel(a, b);
+                }
+                atomicAdd(&gsum[gq], part);
             }
-            atomicAdd(&gsum[q < nk ? q : nk], part);
         }
     }
     __syncthreads();
@@ -389,6 +397,24 @@ void fd_counts(const fmd_firdemod* f, uint64_t ns, uint64_t* m0, uint64_t* m1)
     *m1 = S + ns >= T ? (S + ns - T) / M + 1 : 0;
 }
 
+// Discriminator pass: `lg` lanes per audio group, `ch` consecutive samples per lane, lg * ch >= fa + 1 (a group holds fa
+// or fa + 1 samples).  The smallest ch >= 4 whose kt + 1 groups (the tile's audio samples + the carried partial group)
+// fit one pass of the 256 threads; one pass is not required (the kernel loops), only cheaper.
+void fd_lanes(uint32_t fa, uint32_t kt, uint32_t* lg, uint32_t* magic, uint32_t* ch)
+{
+    uint32_t c = 4, l = (fa + 1u + c - 1u) / c;
+    while (l > 1u && (uint64_t)(kt + 1u) * l > (uint32_t)kThreads && c < fa + 1u) { ++c; l = (fa + 1u + c - 1u) / c; }
+    if (l > (uint32_t)kThreads) { l = kThreads; c = (fa + 1u + l - 1u) / l; }
+    uint32_t m = 65536u / l + 1u;
+    for (uint32_t t = 0; t <= (uint32_t)kThreads; ++t)
+        if (((t * m) >> 16) != t / l) { m = 0; break; }
+    if (!m) {                                             // never seen; keep the arithmetic exact anyway: a power of two
+        l = 1; while (l * c < fa + 1u && l < (uint32_t)kThreads) l *= 2;
+        c = (fa + 1u + l - 1u) / l; m = 65536u / l;
+    }
+    *lg = l; *magic = m; *ch = c;
+}
+
 // LDS per tile for `kt` audio samples: raw bytes of the windows + packed samples + discriminator samples
 bool fd_sizes(const fmd_firdemod* f, uint32_t kt, uint32_t* lp_cap, uint32_t* raw_bytes, size_t* lds)
 {
@@ -443,8 +469,9 @@ int fd_enqueue(fmd_firdemod* f, const void* d_iq, size_t nbytes, void* d_out, si
 #ifdef FMD_EXPERIMENT
     { const char* e = getenv("FMD_DBG"); L.dbg = e ? (uint32_t)atoi(e) : 0u; }
 #endif
-    L.small = ((uint64_t)L.P.M * r.sr + 2ull * r.fr < (1u << 24) && (uint64_t)r.fr < (1u << 24)) ? 1u : 0u;
-    L.inv_fr = 1.0f / (float)r.fr;
+    fd_lanes(L.fa, r.kt, &L.lg, &L.lg_magic, &L.ch);
+    L.sr_shift = 32u;
+    if ((r.sr & (r.sr - 1u)) == 0u) { L.sr_shift = 0u; while ((1u << L.sr_shift) < r.sr) ++L.sr_shift; }
     L.use_rows = 0u;
     if (L.P.nt <= kFdRows && !f->no_rows) {
         for (uint32_t t = 0; t < L.P.nt; ++t) {

@@ -22,3 +22,19 @@ for k, v in acc.items():
     print("%-26s n=%d mean=%.6g" % (k, len(v), sum(v) / len(v)))
 PY
 done
+python3 - $OUT <<'PY'
+import csv, sys, glob, collections, json
+out = {}
+for n in ("sq1", "sq2", "sq3", "tcc1", "tcc2", "grbm"):
+    for f in glob.glob("%s/%s/*counter_collection.csv" % (sys.argv[1], n)):
+        acc = collections.defaultdict(list)
+        for r in csv.DictReader(open(f)):
+            acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
+        for k, v in acc.items():
+            out[k] = {"mean_per_launch": sum(v) / len(v), "launches": len(v)}
+    for f in glob.glob("%s/%s/*kernel_trace.csv" % (sys.argv[1], n)):
+        d = [float(r["End_Timestamp"]) - float(r["Start_Timestamp"]) for r in csv.DictReader(open(f)) if "firdemod" in r["Kernel_Name"]]
+        if d:
+            out.setdefault("kernel_ns_under_pmc", {})[n] = sum(d) / len(d)
+open("%s/summary.json" % sys.argv[1], "w").write(json.dumps(out, indent=1))
+PY
