@@ -175,22 +175,26 @@ __device__ __forceinline__ int disc_nosel(uint32_t a, uint32_t b)
     return (int)(res & (uint32_t)((int)(0u - den) >> 31));               // x == 0 && y == 0 -> 0 (:388)
 }
 
-// The same function in f32, for downsample <= 11 (FMD_DISC_F32_MAX_D): there |x| + |y| < 2^23, so every quantity
-// below is an integer that f32 holds exactly.  Why: on gfx950 only add / sub / and / or / xor / shift-right and f32
-// add / sub / mul (with their free abs / neg / clamp modifiers) issue in 2 cycles per wave; selects, compares,
-// conversions, integer multiplies, max ... take 4 (tools/valubench.hip).  This form is ~100 cycles against ~124 for
-// the integer one (-10 % on the whole launch at the reference's own rates).
+// The same function in f32, for downsample <= 16 (FMD_DISC_F32_MAX_D): there |x|, |y| <= 2 (128 D)^2 <= 2^23 and
+// |x| + |y| < 2^24, so x, y, their sum and difference are integers that f32 holds exactly.  Why: on gfx950 only add /
+// sub / and / or / xor / shift-right and f32 add / sub / mul (with their free abs / neg / clamp modifiers) issue in 2
+// cycles per wave; selects, compares, conversions, integer multiplies, max ... take 4 (tools/valubench.hip).  This form
+// is ~100 cycles against ~124 for the integer one (-10 % on the whole launch at the reference's own rates).
 //   den = |x| + |y|;  s = x >= 0 ? x - |y| : x + |y| = +-(|x| - |y|)                          (:390-400)
 //   `(4096_i64 * s) as i32` keeps s mod 2^20 in [-2^19, 2^19): adding 1.5 * 2^43 (ulp 2^20) rounds s + 0.5 to a
-//     multiple of 2^20 -- never a tie, s is an integer -- and subtracting it again leaves k * 2^20, k = floor(s / 2^20 + 1/2)
+//     multiple of 2^20 -- never a tie, s is an integer -- and subtracting it again leaves k * 2^20, k = floor(s / 2^20 + 1/2).
+//     THIS step sets the limit: s + 0.5 must be representable, i.e. |s| <= 2^23 (downsample 18 fails here: an odd
+//     multiple of 2^19 above 2^23 loses its + 0.5 and the big add becomes a tie)
 //   q = floor(4096 |sp| / den): the estimate uses 4096 (1 - 2^-21) so that rcp's ulp and two roundings (2^-22 in all)
-//     can only make it too SMALL, by < 0.004: floor() is q or q - 1; the remainder n4 - qf * den is exact in ONE fma
-//     (it is below 2 den < 2^24) and a clamped subtract turns `remainder >= den` into the +1
+//     can only make it too SMALL, by < 0.004: floor() is q or q - 1; the remainder n4 - qf * den lies in [0, 2 den) and
+//     ONE fma returns it exactly while it is below 2^24 -- which covers every remainder < den -- and rounded but still
+//     >= 2^24 > den - 1 otherwise; a clamped subtract turns `remainder >= den` into the +1
 //   the sign of the truncating quotient is sp's, the base angle is 8192 - (+-4096) by the sign of x, the result takes
 //     y's sign; (0, 0) -> den = 0 -> the final factor clamp(den + den) is 0 (:388), 1 otherwise.
 // tests/test_disc_f32_model.py replays this sequence in numpy f32 with the reciprocal pushed to both ends of its
-// 1-ulp band against fast_atan2 itself; the GPU parity and fuzz tests run it on the hardware.
-#define FMD_DISC_F32_MAX_D 11
+// 1-ulp band against fast_atan2 itself, for boxcar sums up to 128 * 16 and at 128 * 18 to show the limit; the GPU
+// parity and fuzz tests run it on the hardware.
+#define FMD_DISC_F32_MAX_D 16
 __device__ __forceinline__ float clamp01(float v) { return __builtin_amdgcn_fmed3f(v, 0.0f, 1.0f); }   // folds into a clamp modifier
 __device__ __forceinline__ float u2f(uint32_t u) { return __builtin_bit_cast(float, u); }
 __device__ __forceinline__ uint32_t f2u(float f) { return __builtin_bit_cast(uint32_t, f); }

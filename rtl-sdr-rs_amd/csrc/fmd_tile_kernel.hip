@@ -41,6 +41,9 @@ using namespace fmd_dev;
 #define FMD_ABLATE(bit) false
 #define FMD_F64_SKEW 0
 #endif
+#ifndef FMD_ROT_MASK
+#define FMD_ROT_MASK 3               /* rotate the window walk when the dword count is a multiple of 4 (see tile_body) */
+#endif
 #ifndef FMD_MASKED_UNROLL
 #define FMD_MASKED_UNROLL 1      /* 0: run-time masked-window loop for every dword count (A/B builds) */
 #endif
@@ -192,7 +195,7 @@ __device__ __forceinline__ void tile_exc_flush(const FmdLaunch& L, const TileCtx
     }
 }
 
-// Masked-window rounds with the dword count known at compile time (odd downsample 3 ... 11, or an even one at an
+// Masked-window rounds with the dword count known at compile time (odd downsample 3 ... 15, 14, or an even one at an
 // odd boxcar phase): a window of D samples covers NDW dwords of which the first and / or the last counts only
 // half.  Which half is fixed per lane (a lane's windows are an even number of samples apart), so the masks fold
 // into 2 * NDW per-lane weight registers and the body is the same 3 VALU instructions per dword as the whole-dword
@@ -303,7 +306,7 @@ __device__ __forceinline__ void tile_body(const FmdLaunch& L, const TileCtx& X, 
             const uint32_t prev2 = wave_shr1_old(wave_ror1(pk1), pk2);   // lane l <- second of l-1; lane 0 <- first of 63
             int d1, d2;
             if (FMD_ABLATE(0)) { d1 = (int)(pk1 ^ prev1); d2 = (int)(pk2 ^ prev2); }    // ablation: no discriminator
-            else if (FMD_USE_F32) { d1 = disc_f32(pk1, prev1); d2 = disc_f32(pk2, prev2); }   // (:362); whole-dword windows: downsample <= 10
+            else if (FMD_USE_F32) { d1 = disc_f32(pk1, prev1); d2 = disc_f32(pk2, prev2); }   // (:362); whole-dword windows: downsample <= 10 (<= FMD_DISC_F32_MAX_D)
             else { d1 = disc_fast(pk1, prev1); d2 = disc_fast(pk2, prev2); }
             // (Measured and rejected in round 2: storing the full rounds without predication -- lane 0 to a dummy slot --
             //  so that both discriminators run as one interleaved stream: +2 % at downsample 6 / 10, +7 % at 7.  The
@@ -335,7 +338,9 @@ __device__ __forceinline__ void tile_body(const FmdLaunch& L, const TileCtx& X, 
         // are ndw dwords apart, so up to 32 of them would hit one LDS bank (PMC at downsample 64: 94 % of the LDS
         // cycles were bank conflicts).  Each lane therefore walks its window from a different even offset and
         // wraps; an even rotation keeps the A, B weight order.
-        const bool rotate = (D & 1) == 0 && (p0 & 1u) == 0u && (ndw & 1) == 0 && ndw >= 4;
+        // (A window length of 2 mod 4 dwords -- downsample 12, 20, 28 -- is only a 2-way conflict: cheaper to take than
+        //  to rotate around; those run the plain loops.)
+        const bool rotate = (D & 1) == 0 && (p0 & 1u) == 0u && (ndw & FMD_ROT_MASK) == 0 && ndw >= 4;
         const bool smallD = FMD_USE_F32 && D <= FMD_DISC_F32_MAX_D;
         uint32_t rot0 = 0;
         if (rotate) {
@@ -349,7 +354,7 @@ __device__ __forceinline__ void tile_body(const FmdLaunch& L, const TileCtx& X, 
         if (!rotate && FMD_MASKED_UNROLL) {
             done = true;
             switch (ndw) {                                   // wave-uniform
-                FMD_MASKED(2); FMD_MASKED(3); FMD_MASKED(4); FMD_MASKED(5); FMD_MASKED(6);
+                FMD_MASKED(2); FMD_MASKED(3); FMD_MASKED(4); FMD_MASKED(5); FMD_MASKED(6); FMD_MASKED(7); FMD_MASKED(8);
                 default: done = false;
             }
         }
@@ -374,7 +379,9 @@ __device__ __forceinline__ void tile_body(const FmdLaunch& L, const TileCtx& X, 
                 const uint32_t pk1 = pack_lp_perm(re1, im1), pk2 = pack_lp_perm(re2, im2);
                 const uint32_t prev1 = wave_shr1(pk1);
                 const uint32_t prev2 = wave_shr1_old(wave_ror1(pk1), pk2);
-                const int d1 = disc_nosel(pk1, prev1), d2 = disc_nosel(pk2, prev2);     // rotate: downsample >= 8, mostly > 11
+                int d1, d2;                                                              // rotate: downsample 8, 12, 16, 20, ...
+                if (smallD) { d1 = disc_f32(pk1, prev1); d2 = disc_f32(pk2, prev2); }   // wave-uniform
+                else { d1 = disc_nosel(pk1, prev1); d2 = disc_nosel(pk2, prev2); }
                 if (lane > 0 && i1 < cnt) d16[i1] = (int16_t)d1;
                 if (i2 < cnt) d16[i2] = (int16_t)d2;
                 continue;

@@ -1,16 +1,19 @@
 """The f32 form of polar_discriminant_fast / fast_atan2 (simple_fm.rs:377-405) used by the tile kernel for
-downsample <= 11 (disc_f32, rtl-sdr-rs_amd/csrc/fmd_tile_kernel.hip), replayed step by step in numpy float32 --
+downsample <= 16 (disc_f32, rtl-sdr-rs_amd/csrc/fmd_device.h), replayed step by step in numpy float32 --
 same operations, same constants, same order -- with the hardware reciprocal (v_rcp_f32: 1 ulp) pushed to BOTH ends
 of its error band, against the integer definition (vectorised here, itself checked against the C oracle).
-Every input class the kernel can produce: products a * conj(b) of boxcar sums up to |lp| = 128 * 11, the i32 wrap
-ties (s = 2^19 mod 2^20), exact quotients, both axes, (0, 0)."""
+Every input class the kernel can produce: products a * conj(b) of boxcar sums up to |lp| = 128 * 16, the i32 wrap
+ties (s = 2^19 mod 2^20), exact quotients, both axes, (0, 0); and the same at 128 * 18, where the f32 form must FAIL
+(|s| above 2^23 loses the + 0.5 of the wrap step), which is why the kernel stops at 16."""
 import ctypes as C
 
 import numpy as np
 import pytest
 
 F = np.float32
-LIM = 128 * 11                      # |lp| <= 128 * D, D <= FMD_DISC_F32_MAX_D
+LIM = 128 * 16                      # |lp| <= 128 * D, D <= FMD_DISC_F32_MAX_D
+XMAX = 2 * LIM * LIM                # |x|, |y| <= 2 (128 D)^2 = 2^23
+DENMAX = int(1.41422 * XMAX)        # |x| + |y| <= sqrt(2) |a| |b| < 2^24
 
 
 def fast_atan2_ref(y, x):
@@ -44,8 +47,11 @@ def disc_f32_model(x, y, rcp_ulps):
     c = rc * F(4095.998046875)
     qf = np.floor(np.abs(sp) * c)
     n4 = np.abs(sp) * F(4096.0)
-    r = (n4.astype(np.float64) - qf.astype(np.float64) * den.astype(np.float64)).astype(F)   # one fma: exact, then rounded
-    assert np.all(r.astype(np.float64) == n4.astype(np.float64) - qf.astype(np.float64) * den.astype(np.float64)), "fma not exact"
+    r_exact = n4.astype(np.float64) - qf.astype(np.float64) * den.astype(np.float64)
+    r = r_exact.astype(F)                                       # one fma: exact product and sum, one rounding
+    small = r_exact < 2.0 ** 24                                 # every remainder below den (< 2^24) comes back exactly
+    assert np.all(r.astype(np.float64)[small] == r_exact[small]), "fma not exact below 2^24"
+    assert np.all(r[~small] >= F(2.0 ** 24))                    # the rounded ones are still >= den
     q = qf + np.clip(r - (den - F(1.0)), F(0), F(1))
     qs = (q.view(np.uint32) ^ (sp.view(np.uint32) & np.uint32(0x80000000))).view(F)
     base = F(8192.0) - (np.uint32(0x45800000) ^ sx).view(F)
@@ -59,7 +65,9 @@ def products(ar, ai, br, bi):
     return ar * br + ai * bi, ai * br - ar * bi                # c = a * conj(b): (re, im)
 
 
-def cases():
+def cases(LIM=LIM):
+    XMAX = 2 * LIM * LIM
+    DENMAX = int(1.41422 * XMAX)
     rng = np.random.default_rng(2026)
     xs, ys = [], []
     n = 400000
@@ -70,10 +78,10 @@ def cases():
     a = rng.integers(-60, 61, (4, 100000))                                     # weak signals: small den, no wrap
     x, y = products(*a); xs.append(x); ys.append(y)
     # the wrap ties: |x| - |y| = 2^19 (2k + 1) exactly, both signs of x and y
-    k = rng.integers(0, 3, 60000)
-    yy = rng.integers(0, 2**21, 60000)
+    k = rng.integers(0, 1 + XMAX // 2**20, 60000)
+    yy = rng.integers(0, XMAX // 2, 60000)
     xx = yy + 2**19 * (2 * k + 1)
-    ok = xx + yy < 2**23
+    ok = (xx <= XMAX) & (xx + yy <= DENMAX)
     sgx, sgy = rng.choice([-1, 1], ok.sum()), rng.choice([-1, 1], ok.sum())
     xs.append(xx[ok] * sgx); ys.append(yy[ok] * sgy)
     # exact quotients: den divides 4096 * sp
@@ -82,7 +90,7 @@ def cases():
     xx = (den + sp) // 2; yy = den - xx
     xs.append(xx * rng.choice([-1, 1], 40000)); ys.append(yy * rng.choice([-1, 1], 40000))
     # near-exact quotients around every boundary: 4096 * t = q * den + {-1, 0, +1 ...}
-    den = rng.integers(1, 2**23, 200000)
+    den = rng.integers(1, DENMAX, 200000)
     q = rng.integers(0, 4097, 200000)
     t = (q * den + rng.integers(-3, 4, 200000) + 4095) // 4096
     t = np.clip(t, 0, den)
@@ -91,7 +99,7 @@ def cases():
     xs.append(np.array([0, 0, 0, 5, -5, 1, -1, 2**22, -2**22, 524288, 524287, -524288, 0, 0]))
     ys.append(np.array([0, 7, -7, 0, 0, 1, -1, 0, 0, 0, 0, 0, 524288, -524288]))
     x, y = np.concatenate(xs), np.concatenate(ys)
-    keep = np.abs(x) + np.abs(y) < 2**23
+    keep = (np.abs(x) <= XMAX) & (np.abs(y) <= XMAX) & (np.abs(x) + np.abs(y) <= DENMAX)
     return x[keep], y[keep]
 
 
@@ -114,3 +122,21 @@ def test_f32_discriminator_is_exact(rcp_ulps):
     assert bad.size == 0, [(int(x[i]), int(y[i]), int(ref[i]), int(got[i])) for i in bad[:8]]
     # the wrap is really exercised, and so is the +1 correction
     assert np.count_nonzero(np.abs(np.abs(x) - np.abs(y)) >= 2**19) > 100000
+
+
+def test_f32_discriminator_limit_is_where_the_kernel_stops():
+    """One step beyond FMD_DISC_F32_MAX_D = 16 (boxcar sums up to 128 * 18) the f32 form is no longer exact."""
+    x, y = cases(128 * 18)
+    big = np.abs(np.abs(x) - np.abs(y)) > 2**23
+    assert np.count_nonzero(big) > 1000
+    try:
+        got = disc_f32_model(x, y, 0)
+    except AssertionError:
+        return                                                  # x / y / den no longer exact in f32: equally disqualifying
+    assert np.count_nonzero(got != fast_atan2_ref(y, x)) > 0
+
+
+def test_kernel_limit_matches_this_model():
+    import os, re
+    hdr = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "rtl-sdr-rs_amd", "csrc", "fmd_device.h")).read()
+    assert int(re.search(r"#define FMD_DISC_F32_MAX_D (\d+)", hdr).group(1)) * 128 == LIM
