@@ -199,11 +199,9 @@ __device__ __forceinline__ float clamp01(float v) { return __builtin_amdgcn_fmed
 __device__ __forceinline__ float u2f(uint32_t u) { return __builtin_bit_cast(float, u); }
 __device__ __forceinline__ uint32_t f2u(float f) { return __builtin_bit_cast(uint32_t, f); }
 
-__device__ __forceinline__ int disc_f32(uint32_t a, uint32_t b)
+// fast_atan2 (:383-405) of the exact f32 product (xf, yf) = a * conj(b); see above.
+__device__ __forceinline__ int disc_f32_xy(float xf, float yf)
 {
-    const uint32_t a_sw = __builtin_amdgcn_alignbit(a, a, 16);          // (im, re)
-    const uint32_t b_cj = (b & 0xFFFFu) | ((0u - (b >> 16)) << 16);      // (re, -im)
-    const float xf = (float)sdot2(a, b), yf = (float)sdot2(a_sw, b_cj);  // c = a * conj(b), exact
     const float den = __builtin_fabsf(xf) + __builtin_fabsf(yf);
     const float t = __builtin_fabsf(xf) - __builtin_fabsf(yf);
     const uint32_t sx = f2u(xf) & 0x80000000u;
@@ -218,6 +216,28 @@ __device__ __forceinline__ int disc_f32(uint32_t a, uint32_t b)
     const float base = 8192.0f - u2f(0x45800000u ^ sx);                  // 4096 or 12288 (:395,400)
     const float res = u2f(f2u(base - qs) ^ (f2u(yf) & 0x80000000u));
     return (int)(res * clamp01(den + den));
+}
+
+__device__ __forceinline__ int disc_f32(uint32_t a, uint32_t b)
+{
+    const uint32_t a_sw = __builtin_amdgcn_alignbit(a, a, 16);          // (im, re)
+    const uint32_t b_cj = (b & 0xFFFFu) | ((0u - (b >> 16)) << 16);      // (re, -im)
+    return disc_f32_xy((float)sdot2(a, b), (float)sdot2(a_sw, b_cj));    // c = a * conj(b), exact
+}
+
+// The same with the samples' components already in f32 (exact integers): c = a * conj(b) by two multiplies and two
+// fmas -- every product is below 2^22 and every sum below 2^23 for downsample <= 16, so nothing rounds -- instead of
+// pack, swap, conjugate, two dot products and two conversions.
+#ifndef FMD_ZERO_FIX
+#define FMD_ZERO_FIX 0.0f            /* -0.0f in a test build switches the canonicalisation off: test_near_silence must then fail */
+#endif
+__device__ __forceinline__ int disc_f32_c(float ar, float ai, float br, float bi)
+{
+    // + 0.0f: a product such as 0 * -5 is -0, and (-0) + (-0) stays -0; fast_atan2 takes its signs from x < 0 / y < 0,
+    // where zero is not negative, and disc_f32_xy reads sign BITS (tests/test_gpu_parity.py::test_near_silence)
+    const float xf = __builtin_fmaf(ai, bi, ar * br) + FMD_ZERO_FIX;        // ar*br + ai*bi
+    const float yf = __builtin_fmaf(ai, br, -(ar * bi)) + FMD_ZERO_FIX;     // ai*br - ar*bi
+    return disc_f32_xy(xf, yf);
 }
 
 // Decimated samples travel packed: re in the low, im in the high 16 bits (|lp| <= 128 * D <= 16384).

@@ -44,6 +44,9 @@ using namespace fmd_dev;
 #ifndef FMD_ROT_MASK
 #define FMD_ROT_MASK 3               /* rotate the window walk when the dword count is a multiple of 4 (see tile_body) */
 #endif
+#ifndef FMD_PAIR
+#define FMD_PAIR 1                   /* 0: windows i and i + 64 per lane, packed samples (A/B builds) */
+#endif
 #ifndef FMD_MASKED_UNROLL
 #define FMD_MASKED_UNROLL 1      /* 0: run-time masked-window loop for every dword count (A/B builds) */
 #endif
@@ -280,7 +283,42 @@ __device__ __forceinline__ void tile_body(const FmdLaunch& L, const TileCtx& X, 
     // A wave-round is 128 windows, two per lane (i and i + 64: two independent dependency chains the
     // scheduler interleaves), producing 127 new discriminator samples; lane 0's first window repeats the
     // previous round's last one and only serves as predecessor.
-    if (fastwin) {
+    if (fastwin && FMD_USE_F32 && FMD_PAIR && DH != 4) {      // DH == 4: lanes 8 dwords apart, a 4-way conflict that costs more than the pair form saves
+        // Whole-dword windows, f32 discriminator (downsample 2 ... 10).  Lane l takes the ADJACENT windows i = base + 2l
+        // and i + 1: the second window's predecessor is the lane's own first one, and only the first one's comes from
+        // the neighbour (the second window of lane l - 1; lane 0's first window is the round's overlap and is not
+        // stored).  With the components kept in f32 the product a * conj(b) is two multiplies and two fmas -- no pack,
+        // swap, conjugate, dot products or conversions of the product -- and half the DPP traffic.  A lane's windows are
+        // 2 DH dwords apart (a 2-way LDS bank conflict for odd DH: cheaper than what it saves); the rotation parity of
+        // the first window is the same for every lane of a wave, the second window's differs by DH.
+        const int wbase = wofs - (int)hp + DH * jfirst;      // LDS dword index of window i is wbase + DH * i
+        const int jw = jfirst + (int)wave * RS;
+        const bool o1 = ((((DH & 1) ? ((uint32_t)jw ^ hp) : hp)) & 1u) != 0u, o2 = o1 != ((DH & 1) != 0);
+        const uint32_t r1A = o1 ? FMD_W_RE_ODD : FMD_W_RE_EVEN, r1B = o1 ? FMD_W_RE_EVEN : FMD_W_RE_ODD;
+        const uint32_t m1A = o1 ? FMD_W_IM_ODD : FMD_W_IM_EVEN, m1B = o1 ? FMD_W_IM_EVEN : FMD_W_IM_ODD;
+        const uint32_t r2A = o2 ? FMD_W_RE_ODD : FMD_W_RE_EVEN, r2B = o2 ? FMD_W_RE_EVEN : FMD_W_RE_ODD;
+        const uint32_t m2A = o2 ? FMD_W_IM_ODD : FMD_W_IM_EVEN, m2B = o2 ? FMD_W_IM_EVEN : FMD_W_IM_ODD;
+        const int c1 = 2 * (o1 ? DH / 2 : (DH + 1) / 2), c2 = 2 * (o2 ? DH / 2 : (DH + 1) / 2);
+        for (int base = (int)wave * RS; base < last && !FMD_ABLATE(6); base += NW * RS) {
+            const int i1 = base + 2 * (int)lane, i2 = i1 + 1;
+            const uint32_t* __restrict__ pa = raw_w + (uint32_t)(wbase + DH * i1);
+            int re1 = DH, im1 = c1, re2 = DH, im2 = c2;
+#pragma unroll
+            for (int u = 0; u < (DH > 0 ? DH : 1); ++u) {
+                const uint32_t wa = pa[u] ^ 0x80808080u, wb = pa[u + DH] ^ 0x80808080u;   // u8 -> s8 (b - 128)
+                re1 = sdot4(wa, (u & 1) ? r1B : r1A, re1);
+                im1 = sdot4(wa, (u & 1) ? m1B : m1A, im1);
+                re2 = sdot4(wb, (u & 1) ? r2B : r2A, re2);
+                im2 = sdot4(wb, (u & 1) ? m2B : m2A, im2);
+            }
+            const float ar1 = (float)re1, ai1 = (float)im1, ar2 = (float)re2, ai2 = (float)im2;
+            const float br1 = u2f(wave_shr1(f2u(ar2))), bi1 = u2f(wave_shr1(f2u(ai2)));   // second window of lane l - 1
+            const int d1 = disc_f32_c(ar1, ai1, br1, bi1);   // (:362)
+            const int d2 = disc_f32_c(ar2, ai2, ar1, ai1);
+            if (lane > 0 && i1 < cnt) d16[i1] = (int16_t)d1;
+            if (i2 < cnt) d16[i2] = (int16_t)d2;
+        }
+    } else if (fastwin) {
         // Hot loop: no branches, no special cases.  Lanes whose window lies outside the tile (the two
         // call-start samples of tile 0, surplus lanes of the last round) read whatever LDS holds there --
         // out-of-range DS reads return 0 -- and their results are either not stored or patched below.

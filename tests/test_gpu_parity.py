@@ -113,6 +113,27 @@ def test_configs_batched_random(fmd, oracle, D, fast, slow):
     check_stream(fmd, oracle, D, fast, slow, blocks, n_channels=nch)
 
 
+@pytest.mark.parametrize("D,fast,slow", [(2, 500000, 32000), (4, 256000, 48000), CFG_REF, (7, 166666, 32000), CFG_24,
+                                         (13, 208000, 32000), (16, 150000, 32000)])
+def test_near_silence(fmd, oracle, D, fast, slow):
+    """Bytes within +-2 of the centre: decimated samples are small, components and whole products are zero all the
+    time -- (0, 0) samples, x == 0 with y != 0, y == 0 with either sign of x.  fast_atan2 (simple_fm.rs:383-405)
+    branches on x >= 0 and y < 0, where zero is not negative; an f32 form that reads sign bits must not see a -0
+    (found by the randomised test in one sample of 10^5 when the complex product moved to f32 multiplies)."""
+    rng = np.random.default_rng(1000 + D)
+    nch = 6
+    blocks = []
+    for i in range(3):
+        n = int(rng.integers(200, 900)) * 8 + 16 * D
+        blk = rng.integers(126, 131, (nch, n)).astype(np.uint8)
+        if i == 1:
+            blk[:, ::2] = 128                                  # I constant, Q moving: one component identically small
+        if i == 2:
+            blk[rng.integers(0, 2, (nch, n)) > 0] = 128        # sparse
+        blocks.append(blk)
+    check_stream(fmd, oracle, D, fast, slow, blocks, n_channels=nch)
+
+
 @pytest.mark.parametrize("kt", [1, 2, 7, 64, 300])
 def test_tiling_invariance(fmd, oracle, kt):
     rng = np.random.default_rng(kt)
