@@ -163,7 +163,21 @@ def spawn_ranks(args):
     for r in range(args.gpus):
         e = dict(env, RANK=str(r), LOCAL_RANK=str(r))
         procs.append(subprocess.Popen(cmd, env=e, stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
-    out0, _ = procs[0].communicate()
+    out0 = b""
+    while True:                                                  # a rank that dies takes the job down instead of leaving the
+        try:                                                     # others waiting in the rendezvous / a collective
+            out0, _ = procs[0].communicate(timeout=1.0)
+            break
+        except subprocess.TimeoutExpired:
+            if any(p.poll() not in (None, 0) for p in procs[1:]):
+                deadline = time.time() + 15.0                    # let the others report their own error first
+                while time.time() < deadline and any(p.poll() is None for p in procs):
+                    time.sleep(0.2)
+                for p in procs:
+                    if p.poll() is None:
+                        p.kill()                                 # the exact children started above, by handle
+                out0, _ = procs[0].communicate()
+                break
     rcs = [procs[0].returncode] + [p.wait() for p in procs[1:]]
     sys.stdout.write(out0.decode())
     sys.stdout.flush()

@@ -31,6 +31,27 @@ def test_gpus_flag_spawns_ranks_and_fails_loudly_without_gpu(fmd):
     assert p.stdout.decode().strip() == ""
 
 
+def test_a_dead_rank_takes_the_job_down(monkeypatch):
+    """One rank exits with an error while another would sit in the rendezvous: the launcher ends the job (after a grace
+    period for the others' own messages) instead of waiting for a collective timeout."""
+    import importlib.util
+    import time
+    import types
+    spec = importlib.util.spec_from_file_location("bench_under_test", BENCH)
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    real = subprocess.Popen
+
+    def fake(cmd, env=None, stdout=None):
+        code = "import time; time.sleep(120)" if env["RANK"] == "0" else "import sys; sys.exit(3)"
+        return real([sys.executable, "-c", code], stdout=stdout)
+
+    monkeypatch.setattr(bench.subprocess, "Popen", fake)
+    t0 = time.time()
+    rc = bench.spawn_ranks(types.SimpleNamespace(gpus=2))
+    assert rc == 1 and time.time() - t0 < 60
+
+
 def test_world_size_must_match_gpus():
     env = dict(clean_env(), WORLD_SIZE="2", RANK="0", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT="29533")
     p = subprocess.run([sys.executable, BENCH, "--gpus", "1", "--steps", "2"], capture_output=True, env=env, timeout=300)
