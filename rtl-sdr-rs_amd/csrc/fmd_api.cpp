@@ -116,7 +116,7 @@ int choose_tiling(fmd_demod* d, uint32_t kt_req)
         const double c_round = 64.0 + 12.0 * dh, c_audio = 70.0 + 6.0 * (double)(r.fr / r.sr), c_fixed = 60.0;   // (150 before the fast prologue)
         double best = 0.0;
         kt = 1;
-        for (uint32_t k = 1; k <= 1024u; ++k) {
+        for (uint32_t k = 1; k <= 8192u; ++k) {              // (1024 until the end of round 2: at rate ratios near 1 that left most of the LDS unused)
             r.kt = k;
             if ((uint64_t)r.sr * (k + 2) >= (1u << 24)) break;
             const uint32_t lp = fmd_tile_lp_cap(r), raw = fmd_tile_raw_cap(r);

@@ -392,7 +392,7 @@ __device__ __forceinline__ void tile_body(const FmdLaunch& L, const TileCtx& X, 
         if (!rotate && FMD_MASKED_UNROLL) {
             done = true;
             switch (ndw) {                                   // wave-uniform
-                FMD_MASKED(2); FMD_MASKED(3); FMD_MASKED(4); FMD_MASKED(5); FMD_MASKED(6); FMD_MASKED(7); FMD_MASKED(8);
+                FMD_MASKED(1); FMD_MASKED(2); FMD_MASKED(3); FMD_MASKED(4); FMD_MASKED(5); FMD_MASKED(6); FMD_MASKED(7); FMD_MASKED(8);
                 default: done = false;
             }
         }
