@@ -200,6 +200,8 @@ __device__ __forceinline__ float u2f(uint32_t u) { return __builtin_bit_cast(flo
 __device__ __forceinline__ uint32_t f2u(float f) { return __builtin_bit_cast(uint32_t, f); }
 
 // fast_atan2 (:383-405) of the exact f32 product (xf, yf) = a * conj(b); see above.
+// NOWRAP: the caller guarantees |s| < 2^19 (downsample <= 3: 2 (128 * 3)^2 = 294 912), where `(4096 * s) as i32` cannot wrap.
+template <bool NOWRAP = false>
 __device__ __forceinline__ int disc_f32_xy(float xf, float yf)
 {
     const float den = __builtin_fabsf(xf) + __builtin_fabsf(yf);
@@ -207,7 +209,7 @@ __device__ __forceinline__ int disc_f32_xy(float xf, float yf)
     const uint32_t sx = f2u(xf) & 0x80000000u;
     const float s = u2f(f2u(t) ^ sx);
     const float big = 13194139533312.0f;                                 // 1.5 * 2^43
-    const float sp = s - (((s + 0.5f) + big) - big);                     // s mod 2^20, signed
+    const float sp = NOWRAP ? s : s - (((s + 0.5f) + big) - big);        // s mod 2^20, signed
     const float c = __builtin_amdgcn_rcpf(den + 0x1p-30f) * 4095.998046875f;   // + 2^-30: finite for den == 0, no change otherwise
     const float qf = __builtin_floorf(__builtin_fabsf(sp) * c);
     const float r = __builtin_fmaf(-qf, den, __builtin_fabsf(sp) * 4096.0f);
@@ -231,13 +233,14 @@ __device__ __forceinline__ int disc_f32(uint32_t a, uint32_t b)
 #ifndef FMD_ZERO_FIX
 #define FMD_ZERO_FIX 0.0f            /* -0.0f in a test build switches the canonicalisation off: test_near_silence must then fail */
 #endif
+template <bool NOWRAP = false>
 __device__ __forceinline__ int disc_f32_c(float ar, float ai, float br, float bi)
 {
     // + 0.0f: a product such as 0 * -5 is -0, and (-0) + (-0) stays -0; fast_atan2 takes its signs from x < 0 / y < 0,
     // where zero is not negative, and disc_f32_xy reads sign BITS (tests/test_gpu_parity.py::test_near_silence)
     const float xf = __builtin_fmaf(ai, bi, ar * br) + FMD_ZERO_FIX;        // ar*br + ai*bi
     const float yf = __builtin_fmaf(ai, br, -(ar * bi)) + FMD_ZERO_FIX;     // ai*br - ar*bi
-    return disc_f32_xy(xf, yf);
+    return disc_f32_xy<NOWRAP>(xf, yf);
 }
 
 // Decimated samples travel packed: re in the low, im in the high 16 bits (|lp| <= 128 * D <= 16384).

@@ -313,8 +313,8 @@ __device__ __forceinline__ void tile_body(const FmdLaunch& L, const TileCtx& X, 
             }
             const float ar1 = (float)re1, ai1 = (float)im1, ar2 = (float)re2, ai2 = (float)im2;
             const float br1 = u2f(wave_shr1(f2u(ar2))), bi1 = u2f(wave_shr1(f2u(ai2)));   // second window of lane l - 1
-            const int d1 = disc_f32_c(ar1, ai1, br1, bi1);   // (:362)
-            const int d2 = disc_f32_c(ar2, ai2, ar1, ai1);
+            const int d1 = disc_f32_c<DH == 1>(ar1, ai1, br1, bi1);   // (:362); DH == 1 is downsample 2: no i32 wrap to emulate
+            const int d2 = disc_f32_c<DH == 1>(ar2, ai2, ar1, ai1);
             if (lane > 0 && i1 < cnt) d16[i1] = (int16_t)d1;
             if (i2 < cnt) d16[i2] = (int16_t)d2;
         }
