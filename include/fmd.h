@@ -217,7 +217,9 @@ int fmd_fir_filter_device(fmd_fir *f, const void *d_iq, size_t nbytes, void *d_o
  * it returns exactly what fmd_demod_* (and the oracle of the reference chain) return -- tested bit for bit; that is
  * its anchor.
  * Domain: decim even and <= 64, 1 <= n_taps <= 1024, |taps| <= 2047, (128 * sum|taps|) >> shift <= 16384 (so that
- * |lp| stays in the discriminator's range, the boxcar's bound at downsample 128), shift <= 24.
+ * |lp| stays in the discriminator's range, the boxcar's bound at downsample 128), shift <= 24.  A shift that brings
+ * (128 * sum|taps|) >> shift down to 2048 -- the boxcar's range at downsample 16 -- selects the kernel's f32 form of
+ * the discriminator (same results, ~8 % faster); the Python mirror's auto_shift() picks that one by default.
  * A call that yields fewer than 2 filter outputs returns FMD_ERR_TOO_SHORT (assert at :356) and changes nothing.
  * All channels of a bank advance together (equal-sized buffers), so there is no per-channel set_state. */
 typedef struct fmd_firdemod fmd_firdemod;

@@ -87,6 +87,7 @@ struct FirDemodLaunch {
     uint32_t use_rows;         // 1: rows[tile] holds the tile's geometry
     uint32_t lg, lg_magic, ch; // discriminator pass: `lg` lanes per audio group (tid / lg = tid * lg_magic >> 16), `ch` consecutive samples per lane
     uint32_t sr_shift;         // log2(sr) when the reduced resample rate is a power of two, else 32
+    uint32_t f32_disc;         // 1: |lp| <= 2048 (the boxcar's range at downsample 16): the f32 discriminator is exact (fmd_device.h)
     FdRow rows[kFdRows];
 };
 
@@ -293,10 +294,20 @@ __global__ void __launch_bounds__(kThreads, 8) fmd_firdemod_kernel(const FirDemo
                 const uint32_t* yp = ypk + (j0 - jfirst);
                 uint32_t prev = yp[-1];
                 int part = 0;
-                for (int i = 0; i <= j1 - j0; ++i) {
-                    const uint32_t a = yp[i];
-                    part += (int)(int16_t)disc_nosel(a, prev);   // (:362) `as i16`, summed as i32 (:414)
-                    prev = a;
+                if (L.f32_disc) {                            // wave-uniform: components in f32, c = a * conj(b) by mul + fma
+                    float pr = (float)lp_re(prev), pi = (float)lp_im(prev);
+                    for (int i = 0; i <= j1 - j0; ++i) {
+                        const uint32_t a = yp[i];
+                        const float ar = (float)lp_re(a), ai = (float)lp_im(a);
+                        part += disc_f32_c(ar, ai, pr, pi);  // (:362); the value fits i16, `as i16` changes nothing
+                        pr = ar; pi = ai;
+                    }
+                } else {
+                    for (int i = 0; i <= j1 - j0; ++i) {
+                        const uint32_t a = yp[i];
+                        part += (int)(int16_t)disc_nosel(a, prev);   // (:362) `as i16`, summed as i32 (:414)
+                        prev = a;
+                    }
                 }
                 if (j0 == 0) {                               // the first sample of the call takes the f64 path (:359): thread 0 only
                     const uint32_t a = yp[0], b = yp[-1];
@@ -364,6 +375,7 @@ void launch(const FirDemodLaunch& L, dim3 g, size_t lds, hipStream_t s)
 
 struct fmd_firdemod {
     uint32_t T = 0, M = 0, C = 0, NP = 0, Hw = 0, shift = 0;
+    uint32_t lp_bound = 0;                                // (128 * sum|taps|) >> shift: the largest |lp| component
     int device = 0;
     uint64_t pos = 0;                                     // samples consumed per channel
     FmdFirMfmaPlan plan;
@@ -470,6 +482,7 @@ int fd_enqueue(fmd_firdemod* f, const void* d_iq, size_t nbytes, void* d_out, si
     { const char* e = getenv("FMD_DBG"); L.dbg = e ? (uint32_t)atoi(e) : 0u; }
 #endif
     fd_lanes(L.fa, r.kt, &L.lg, &L.lg_magic, &L.ch);
+    L.f32_disc = f->lp_bound <= 2048u && !getenv("FMD_FD_INT_DISC") ? 1u : 0u;
     L.sr_shift = 32u;
     if ((r.sr & (r.sr - 1u)) == 0u) { L.sr_shift = 0u; while ((1u << L.sr_shift) < r.sr) ++L.sr_shift; }
     L.use_rows = 0u;
@@ -553,6 +566,7 @@ int fmd_firdemod_new(const int16_t* taps, uint32_t n_taps, uint32_t decim, uint3
     fmd_firdemod* f = new (std::nothrow) fmd_firdemod();
     if (!f) return FMD_ERR_NOMEM;
     f->T = n_taps; f->M = decim; f->C = dev->n_channels; f->device = device; f->shift = shift;
+    f->lp_bound = (uint32_t)((128ull * sum_abs) >> shift);
     f->NP = ((n_taps + 1) / 2 + 3u) & ~3u;
     const uint32_t H = n_taps - 1, Hp = H + (H & 1u);
     f->Hw = Hp / 2;

@@ -49,11 +49,14 @@ class FirBank:
         return n.value
 
 
-def auto_shift(taps):
-    """Smallest normalisation shift that keeps |lp| in the discriminator's range: (128 * sum|taps|) >> shift <= 16384."""
+def auto_shift(taps, limit=2048):
+    """Smallest normalisation shift with (128 * sum|taps|) >> shift <= limit.  The default, 2048, is the range of the
+    reference chain itself at downsample 16 (|lp| <= 128 * 16): there the fused kernel's f32 discriminator is exact.
+    limit=16384 is the most the discriminator admits (three more bits of the filter output, integer form, a few
+    percent slower); the library enforces only that bound."""
     g = 128 * int(np.abs(np.asarray(taps, dtype=np.int64)).sum())
     s = 0
-    while (g >> s) > 16384:
+    while (g >> s) > limit:
         s += 1
     return s
 

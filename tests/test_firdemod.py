@@ -60,7 +60,7 @@ def test_gpu_all_ones_is_the_boxcar_kernel_and_the_reference(fmd, oracle, D, fas
 def test_gpu_fused_matches_composition(fmd, oracle, T, M, fast, slow):
     rng = np.random.default_rng(T * 11 + M)
     taps = rng.integers(-2047, 2048, T).astype(np.int16)
-    shift = fmd.auto_shift(taps) + int(rng.integers(0, 3))
+    shift = fmd.auto_shift(taps, 16384) + int(rng.integers(0, 6))     # both discriminator forms (|lp| <= 2048: f32)
     nch = 5
     fd = fmd.FirDemodBank(taps, M, fast, slow, nch, shift=shift)
     hs = [oracle.firdemod_new(taps, M, shift, fast, slow) for _ in range(nch)]
@@ -140,7 +140,7 @@ def test_gpu_fused_fuzz(fmd, oracle):
         M = 2 * int(rng.choice([1, 2, 3, 4, 5, 8, 16, 25, 32]))
         T = int(rng.choice([1, 2, 3, 7, 16, 31, 64, 127, 128, 200, 513]))
         taps = rng.integers(-2047, 2048, T).astype(np.int16) if rng.integers(0, 4) else np.ones(T, np.int16)
-        shift = fmd.auto_shift(taps) + int(rng.integers(0, 4))
+        shift = fmd.auto_shift(taps, 16384) + int(rng.integers(0, 7))     # both discriminator forms (|lp| <= 2048: f32)
         slow = int(rng.choice([8000, 32000, 44100, 48000]))
         fast = slow * int(rng.integers(1, 60)) + int(rng.integers(0, slow)) * int(rng.integers(0, 2))
         nch = int(rng.integers(1, 5))
