@@ -87,6 +87,7 @@ struct FirDemodLaunch {
     uint32_t use_rows;         // 1: rows[tile] holds the tile's geometry
     uint32_t lg, lg_magic, ch; // discriminator pass: `lg` lanes per audio group (tid / lg = tid * lg_magic >> 16), `ch` consecutive samples per lane
     uint32_t sr_shift;         // log2(sr) when the reduced resample rate is a power of two, else 32
+    uint32_t reuse;            // host only: 1 selects the REUSE instantiation (decim == 8, one pass)
     uint32_t f32_disc;         // 1: |lp| <= 2048 (the boxcar's range at downsample 16): the f32 discriminator is exact (fmd_device.h)
     FdRow rows[kFdRows];
 };
@@ -140,7 +141,7 @@ static __device__ __noinline__ void exc_emit_direct(FmdExcBuf* exc, uint32_t c, 
     if (slot < FMD_EXC_CAP) exc->rec[slot] = e; else atomicOr(&exc->err, FMD_DEVERR_EXC_CAP);
 }
 
-template <int NKU>
+template <int NKU, bool REUSE>
 __global__ void __launch_bounds__(kThreads, 8) fmd_firdemod_kernel(const FirDemodLaunch L)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
@@ -213,7 +214,27 @@ __global__ void __launch_bounds__(kThreads, 8) fmd_firdemod_kernel(const FirDemo
     fd_i4 acc[kGroupsPerWave];
 #pragma unroll
     for (int gi = 0; gi < kGroupsPerWave; ++gi) acc[gi] = fd_i4{0, 0, 0, 0};
-    for (uint32_t pass = 0; pass < L.n_pass && !FD_ABLATE(0); ++pass) {
+    // Operand-fragment reuse (decim == 8, all k-steps in one pass -- BASELINE config 4): the tile's outputs are split
+    // into 64 columns of PC consecutive outputs (16 columns per wave); a column's 4 output groups (outputs 4 jj .. 4 jj + 3)
+    // start 64 bytes = ONE k-step apart, so group jj at k-step s needs exactly the tap fragment A[s - jj]: every 16-byte
+    // operand fragment is read and sign-flipped once and feeds up to 4 accumulators (4 independent MFMA chains),
+    // instead of once per group -- NKU + 3 fragments per wave where the plain mapping reads 4 NKU.  Bytes read beyond
+    // the staged range only meet zero taps or outputs that are discarded.
+    const uint32_t PC = (no + 63u) >> 6;                     // outputs per column
+    if (REUSE && !FD_ABLATE(0)) {
+        const uint8_t* col = lb + ((16u * wave + j) * PC) * (L.col_bytes >> 2) + 16u * q;
+#pragma unroll
+        for (int sft = 0; sft < NKU + 3; ++sft) {
+            fd_i4 B = *reinterpret_cast<const fd_i4*>(col + 64 * sft);
+            B = B ^ (int)0x80808080;                                                       // u8 -> s8
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) {
+                if (sft - jj >= 0 && sft - jj < NKU && 4u * (uint32_t)jj < PC)              // the first two at compile time
+                    acc[jj] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A[sft - jj], B, acc[jj], 0, 0, 0);
+            }
+        }
+    }
+    for (uint32_t pass = 0; pass < L.n_pass && !FD_ABLATE(0) && !REUSE; ++pass) {
         if (pass) {
 #pragma unroll
             for (int k = 0; k < NKU; ++k) A[k] = amat[(pass * NKU + k) * 64u];
@@ -241,8 +262,9 @@ __global__ void __launch_bounds__(kThreads, 8) fmd_firdemod_kernel(const FirDemo
 #pragma unroll
     for (int gi = 0; gi < kGroupsPerWave; ++gi) {
         const uint32_t g = wave + 4u * gi;
-        const uint32_t o = 64u * g + 4u * j + q;
-        if (g < groups && o < no) {
+        // plain mapping: group g, column j, output q of the column; reuse mapping: column 16 wave + j, group gi of it
+        const uint32_t o = REUSE ? (16u * wave + j) * PC + 4u * (uint32_t)gi + q : 64u * g + 4u * j + q;
+        if ((REUSE ? 4u * (uint32_t)gi + q < PC : g < groups) && o < no) {
             const uint32_t ure = (uint32_t)acc[gi].x + ((uint32_t)acc[gi].y << 7), uim = (uint32_t)acc[gi].z + ((uint32_t)acc[gi].w << 7);
             const int re = ((int)((ure ^ sgn) - sgn) + cre) >> L.shift;          // floor(y / 2^shift)
             const int im = ((int)((uim ^ sgn) - sgn) + cim) >> L.shift;
@@ -353,7 +375,8 @@ __global__ void __launch_bounds__(kThreads, 8) fmd_firdemod_kernel(const FirDemo
 template <int NKU>
 void launch(const FirDemodLaunch& L, dim3 g, size_t lds, hipStream_t s)
 {
-    hipLaunchKernelGGL(fmd_firdemod_kernel<NKU>, g, dim3(kThreads), lds, s, L);
+    if (L.reuse) hipLaunchKernelGGL((fmd_firdemod_kernel<NKU, true>), g, dim3(kThreads), lds, s, L);
+    else hipLaunchKernelGGL((fmd_firdemod_kernel<NKU, false>), g, dim3(kThreads), lds, s, L);
 }
 
 #define FD_TRY(expr)                                                                        \
@@ -482,6 +505,7 @@ int fd_enqueue(fmd_firdemod* f, const void* d_iq, size_t nbytes, void* d_out, si
     { const char* e = getenv("FMD_DBG"); L.dbg = e ? (uint32_t)atoi(e) : 0u; }
 #endif
     fd_lanes(L.fa, r.kt, &L.lg, &L.lg_magic, &L.ch);
+    L.reuse = f->M == 8u && f->plan.n_pass == 1u && !getenv("FMD_FD_NOREUSE") ? 1u : 0u;
     L.f32_disc = f->lp_bound <= 2048u && !getenv("FMD_FD_INT_DISC") ? 1u : 0u;
     L.sr_shift = 32u;
     if ((r.sr & (r.sr - 1u)) == 0u) { L.sr_shift = 0u; while ((1u << L.sr_shift) < r.sr) ++L.sr_shift; }
