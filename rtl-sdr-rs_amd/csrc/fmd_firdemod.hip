@@ -272,7 +272,23 @@ __global__ void __launch_bounds__(kThreads, 8) fmd_firdemod_kernel(const FirDemo
         }
     }
     if (jfirst < 0 && tid == 0) ypk[0] = pack_lp(st.demod_pre_re, st.demod_pre_im);     // lp[-1]
-    for (uint32_t k = tid; k <= r.kt; k += kThreads) gsum[k] = 0;
+    // audio group k of the tile (k == nk: the trailing partial group): zero its accumulator and tabulate its first and
+    // last discriminator sample -- sample k0 + k ends at e = eq + k * fa + (er + k * fb) / sr and holds fa samples, or
+    // fa + 1 when the remainder of that division is below fb (fmd_tile_kernel.hip, low_pass_real): one division per
+    // GROUP here instead of one per lane in the pass below
+    int* const gse = gsum + (r.kt + 2u);
+    for (uint32_t k = tid; k <= r.kt; k += kThreads) {
+        gsum[k] = 0;
+        const uint32_t x = T.er + k * L.fb;
+        uint32_t u, xrem;
+        if (L.sr_shift < 32u) { u = x >> L.sr_shift; xrem = x & (r.sr - 1u); }
+        else { u = fmd_udiv_small(x, r.sr, L.inv_sr); xrem = x - u * r.sr; }
+        int e = (int)(T.eq + k * L.fa + u);
+        int s0 = e - (int)L.fa + (xrem < L.fb ? 0 : 1);
+        s0 = s0 > 0 ? s0 : 0;                                // the call's first group starts at sample 0
+        e = e < T.jB ? e : T.jB;                             // the carried group ends with the call
+        gse[2u * k] = s0; gse[2u * k + 1u] = e;
+    }
     // the channel's last tile also writes the next call's history (the raw bytes are all in global memory)
     if (T.last) {
         typedef const FMD_AS_GLOBAL uint32_t* gw;
@@ -300,16 +316,7 @@ __global__ void __launch_bounds__(kThreads, 8) fmd_firdemod_kernel(const FirDemo
         const uint32_t gq0 = (tid * L.lg_magic) >> 16, lg = tid - gq0 * L.lg;           // tid / lg, tid % lg
         const uint32_t gpp = ((uint32_t)kThreads * L.lg_magic) >> 16;                    // whole groups per pass: the lanes beyond
         for (uint32_t gq = gq0 < gpp ? gq0 : ng; gq < ng && !FD_ABLATE(1); gq += gpp) { //   gpp * lg sit out
-            // audio sample k0 + gq ends at e = eq + gq * fa + (er + gq * fb) / sr and holds fa samples, or fa + 1 when the
-            // remainder of that division is below fb (fmd_tile_kernel.hip, low_pass_real)
-            const uint32_t x = T.er + gq * L.fb;
-            uint32_t u, xrem;
-            if (L.sr_shift < 32u) { u = x >> L.sr_shift; xrem = x & (r.sr - 1u); }
-            else { u = fmd_udiv_small(x, r.sr, L.inv_sr); xrem = x - u * r.sr; }
-            int e = (int)(T.eq + gq * L.fa + u);
-            int s = e - (int)L.fa + (xrem < L.fb ? 0 : 1);
-            s = s > 0 ? s : 0;                               // the call's first group starts at sample 0
-            e = e < T.jB ? e : T.jB;                         // the carried group ends with the call
+            const int s = gse[2u * gq], e = gse[2u * gq + 1u];  // the group's first and last sample (tabulated above)
             const int j0 = s + (int)(lg * L.ch);
             const int j1 = j0 + (int)L.ch - 1 < e ? j0 + (int)L.ch - 1 : e;
             if (j0 <= j1) {
@@ -460,7 +467,7 @@ bool fd_sizes(const fmd_firdemod* f, uint32_t kt, uint32_t* lp_cap, uint32_t* ra
     const uint64_t staged = (((((uint64_t)(cap - 1) * half_M + f->NP + 3) / 4) + 3) & ~(uint64_t)3) * 16;
     const uint64_t touched = (uint64_t)16 * ((cap + 63) / 64) * (8u * f->M) + (uint64_t)64 * f->plan.n_pass * f->plan.nku;
     const uint64_t raw = ((staged > touched ? staged : touched) + 15) & ~(uint64_t)15;
-    const uint64_t total = raw + 4ull * (cap + 1) + 4ull * (kt + 2) + 16;
+    const uint64_t total = raw + 4ull * (cap + 1) + 12ull * (kt + 2) + 16;   // + group sums and the (first, last) table
     if (total > 60 * 1024) return false;
     *lp_cap = cap; *raw_bytes = (uint32_t)raw; *lds = (size_t)total;
     return true;
