@@ -323,7 +323,15 @@ __global__ void __launch_bounds__(kThreads, 8) fmd_firdemod_kernel(const FirDemo
                 const uint32_t* yp = ypk + (j0 - jfirst);
                 uint32_t prev = yp[-1];
                 int part = 0;
-                if (L.f32_disc) {                            // wave-uniform: components in f32, c = a * conj(b) by mul + fma
+                if (L.f32_disc && L.ch == 4u) {              // wave-uniform.  Four samples straight-line (four independent chains,
+                    const int n = j1 - j0;                   // no loop control); the ones beyond the lane's run are computed on
+                    const uint32_t a0 = yp[0], a1 = yp[1], a2 = yp[2], a3 = yp[3];   // whatever LDS holds there and dropped by a select
+                    const float r0 = (float)lp_re(a0), i0 = (float)lp_im(a0), r1 = (float)lp_re(a1), i1 = (float)lp_im(a1);
+                    const float r2 = (float)lp_re(a2), i2 = (float)lp_im(a2), r3 = (float)lp_re(a3), i3 = (float)lp_im(a3);
+                    const int d0 = disc_f32_c(r0, i0, (float)lp_re(prev), (float)lp_im(prev));
+                    const int d1 = disc_f32_c(r1, i1, r0, i0), d2 = disc_f32_c(r2, i2, r1, i1), d3 = disc_f32_c(r3, i3, r2, i2);
+                    part = d0 + (n >= 1 ? d1 : 0) + (n >= 2 ? d2 : 0) + (n >= 3 ? d3 : 0);
+                } else if (L.f32_disc) {                     // wave-uniform: components in f32, c = a * conj(b) by mul + fma
                     float pr = (float)lp_re(prev), pi = (float)lp_im(prev);
                     for (int i = 0; i <= j1 - j0; ++i) {
                         const uint32_t a = yp[i];
