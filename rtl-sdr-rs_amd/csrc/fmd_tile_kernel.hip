@@ -357,14 +357,17 @@ __device__ __forceinline__ void tile_body(const FmdLaunch& L, const TileCtx& X, 
         // s/2 .. (s + D - 1)/2; the half dwords at its ends are masked out of the byte weights.  s mod 4 (the
         // rotation phase), hence weights, masks and the additive constants, are again fixed per lane: a lane's
         // windows are 64 and 4*127 samples apart.  The dword count is the same for every window of the call.
-        const int D = (int)r.D;
+        // DH > 0 instantiations only ever run downsample 2 DH (here: at an odd boxcar phase, i.e. DH + 1 dwords per
+        // window): telling the compiler so prunes every other window length, the wrap-around walk and the general loop
+        // from those kernels (the launch's hot loop is the same; the kernel around it shrinks to a third)
+        const int D = DH > 0 ? 2 * DH : (int)r.D;
         const int s00 = D * jfirst - (int)p0;                // start sample of window i is s00 + D*i
         const int sl = s00 + D * ((int)wave * RS + (int)lane);
         const uint32_t sm = (uint32_t)sl & 3u;               // two's complement: right for the clipped windows too
         const bool podd = ((sl >> 1) & 1) != 0;              // call-dword parity of the first dword
         const uint32_t wreA = podd ? FMD_W_RE_ODD : FMD_W_RE_EVEN, wreB = podd ? FMD_W_RE_EVEN : FMD_W_RE_ODD;
         const uint32_t wimA = podd ? FMD_W_IM_ODD : FMD_W_IM_EVEN, wimB = podd ? FMD_W_IM_EVEN : FMD_W_IM_ODD;
-        const int ndw = (D & 1) ? (D + 1) / 2 : D / 2 + (int)(p0 & 1u);
+        const int ndw = DH > 0 ? DH + 1 : (D & 1) ? (D + 1) / 2 : D / 2 + (int)(p0 & 1u);   // (DH > 0 gets here with an odd phase only)
         const uint32_t mf = (sm & 1u) ? 0xFFFF0000u : 0xFFFFFFFFu;
         const uint32_t ml = ((sm + (uint32_t)D) & 1u) ? 0x0000FFFFu : 0xFFFFFFFFu;
         const bool lastB = ((ndw - 1) & 1) != 0;
