@@ -44,6 +44,9 @@ using namespace fmd_dev;
 #ifndef FMD_ROT_MASK
 #define FMD_ROT_MASK 3               /* rotate the window walk when the dword count is a multiple of 4 (see tile_body) */
 #endif
+#ifndef FMD_ODD_KERNELS
+#define FMD_ODD_KERNELS 1
+#endif
 #ifndef FMD_PAIR
 #define FMD_PAIR 1                   /* 0: windows i and i + 64 per lane, packed samples (A/B builds) */
 #endif
@@ -360,7 +363,7 @@ __device__ __forceinline__ void tile_body(const FmdLaunch& L, const TileCtx& X, 
         // DH > 0 instantiations only ever run downsample 2 DH (here: at an odd boxcar phase, i.e. DH + 1 dwords per
         // window): telling the compiler so prunes every other window length, the wrap-around walk and the general loop
         // from those kernels (the launch's hot loop is the same; the kernel around it shrinks to a third)
-        const int D = DH > 0 ? 2 * DH : (int)r.D;
+        const int D = DH > 0 ? 2 * DH : DH < 0 ? -DH : (int)r.D;             // DH < 0: an odd downsample -DH with a kernel of its own
         const int s00 = D * jfirst - (int)p0;                // start sample of window i is s00 + D*i
         const int sl = s00 + D * ((int)wave * RS + (int)lane);
         const uint32_t sm = (uint32_t)sl & 3u;               // two's complement: right for the clipped windows too
@@ -816,7 +819,7 @@ hipError_t fmd_launch_tile(const FmdLaunch& L, hipStream_t stream)
 {
     const size_t lds = fmd_tile_lds_bytes(L);
     if (L.n_channels == 0 || L.tiles == 0) return hipErrorInvalidValue;
-    const uint32_t dh = (L.r.D % 2 == 0) ? L.r.D / 2 : 0;
+    const int dh = (L.r.D % 2 == 0) ? (int)(L.r.D / 2) : -(int)L.r.D;
     uint32_t gy = L.n_channels < 65535u ? L.n_channels : 65535u;
     uint32_t gz = (L.n_channels + 65534u) / 65535u;
     dim3 g(L.tiles, gy, gz);
@@ -835,6 +838,20 @@ hipError_t fmd_launch_tile(const FmdLaunch& L, hipStream_t stream)
         case 3: launch_one<3>(K, g, lds, stream); break;
         case 4: launch_one<4>(K, g, lds, stream); break;
         case 5: launch_one<5>(K, g, lds, stream); break;
+#if FMD_ODD_KERNELS
+        // kernels of their own for the other downsample factors the f32 discriminator covers: with the factor a
+        // compile-time constant each one holds a single window loop and gets its own register allocation (one kernel
+        // with every window length in it measured 2-4 % slower at downsample 5 and 7).  DH < 0: odd downsample -DH.
+        case 6: launch_one<6>(K, g, lds, stream); break;     // downsample 12, 14: whole-dword windows like 2 ... 10
+        case 7: launch_one<7>(K, g, lds, stream); break;
+        case -3: launch_one<-3>(K, g, lds, stream); break;
+        case -5: launch_one<-5>(K, g, lds, stream); break;
+        case -7: launch_one<-7>(K, g, lds, stream); break;
+        case -9: launch_one<-9>(K, g, lds, stream); break;
+        case -11: launch_one<-11>(K, g, lds, stream); break;
+        case -13: launch_one<-13>(K, g, lds, stream); break;
+        case -15: launch_one<-15>(K, g, lds, stream); break;
+#endif
         default: launch_one<0>(K, g, lds, stream); break;
     }
     return hipGetLastError();
