@@ -395,7 +395,9 @@ __device__ __forceinline__ void tile_body(const FmdLaunch& L, const TileCtx& X, 
         // compile-time dword counts (see masked_rounds); anything else runs the general loop below
 #define FMD_MASKED(N) case N: masked_rounds<N, NT>(raw_w, d16, wofs, s00, D, cnt, lane, wave, wreA, wreB, wimA, wimB, mf, ml, cre, cim, smallD); break
         bool done = false;
-        if (!rotate && FMD_MASKED_UNROLL) {
+        // (the catch-all kernel, DH == 0, only sees downsample >= 16 once every smaller factor has a kernel of its own:
+        //  windows of 9 dwords and more, none of the compile-time counts below)
+        if (!rotate && FMD_MASKED_UNROLL && (DH != 0 || !FMD_ODD_KERNELS)) {
             done = true;
             switch (ndw) {                                   // wave-uniform
                 FMD_MASKED(1); FMD_MASKED(2); FMD_MASKED(3); FMD_MASKED(4); FMD_MASKED(5); FMD_MASKED(6); FMD_MASKED(7); FMD_MASKED(8);
@@ -844,6 +846,7 @@ hipError_t fmd_launch_tile(const FmdLaunch& L, hipStream_t stream)
         // with every window length in it measured 2-4 % slower at downsample 5 and 7).  DH < 0: odd downsample -DH.
         case 6: launch_one<6>(K, g, lds, stream); break;     // downsample 12, 14: whole-dword windows like 2 ... 10
         case 7: launch_one<7>(K, g, lds, stream); break;
+        case -1: launch_one<-1>(K, g, lds, stream); break;
         case -3: launch_one<-3>(K, g, lds, stream); break;
         case -5: launch_one<-5>(K, g, lds, stream); break;
         case -7: launch_one<-7>(K, g, lds, stream); break;
