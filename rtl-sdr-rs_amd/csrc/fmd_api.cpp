@@ -112,7 +112,7 @@ int choose_tiling(fmd_demod* d, uint32_t kt_req)
         // 10 % slower than 256 at the reference's own rates.  Weights are instruction counts of the kernel.
         const uint32_t nt_threads = d->block_threads, waves = nt_threads / 64u;
         const double budget = 20480.0 * (double)nt_threads / 256.0;
-        const uint32_t dh = r.D % 2 == 0 && r.D / 2 <= 5 ? r.D / 2 : r.D;   // dwords per window (odd / large D: byte loop)
+        const uint32_t dh = (r.D + 1u) / 2u;                                 // dwords per window
         const double c_round = 64.0 + 12.0 * dh, c_audio = 70.0 + 6.0 * (double)(r.fr / r.sr), c_fixed = 60.0;   // (150 before the fast prologue)
         double best = 0.0;
         kt = 1;
