@@ -257,7 +257,9 @@ __device__ __forceinline__ void tile_body(const FmdLaunch& L, const TileCtx& X, 
     const uint32_t lane = tid & 63u, wave = tid >> 6;
     const uint32_t p0 = P.p0, c = X.c;
     const int jfirst = X.jfirst, cnt = X.cnt, wofs = X.wofs;
-    const bool fastwin = DH > 0 && (p0 & 1u) == 0u;          // windows are DH whole dwords
+    // DH >= 8 (downsample 16, 32, 64 with kernels of their own): whole-dword windows too, but a multiple of 4 dwords long --
+    // those take the wrap-around walk below, with the window length a compile-time constant
+    const bool fastwin = DH > 0 && DH < 8 && (p0 & 1u) == 0u;   // windows are DH whole dwords
     FmdChanState st{};
     if (jfirst <= 0 || T.k0 == 0 || T.last) {                // only call-start and call-end tiles need the state
         // st_in is read-only for the whole launch (st_out is the other buffer): constant address space ->
@@ -370,7 +372,8 @@ __device__ __forceinline__ void tile_body(const FmdLaunch& L, const TileCtx& X, 
         const bool podd = ((sl >> 1) & 1) != 0;              // call-dword parity of the first dword
         const uint32_t wreA = podd ? FMD_W_RE_ODD : FMD_W_RE_EVEN, wreB = podd ? FMD_W_RE_EVEN : FMD_W_RE_ODD;
         const uint32_t wimA = podd ? FMD_W_IM_ODD : FMD_W_IM_EVEN, wimB = podd ? FMD_W_IM_EVEN : FMD_W_IM_ODD;
-        const int ndw = DH > 0 ? DH + 1 : (D & 1) ? (D + 1) / 2 : D / 2 + (int)(p0 & 1u);   // (DH > 0 gets here with an odd phase only)
+        const int ndw = DH > 0 && DH < 8 ? DH + 1                            // (0 < DH < 8 gets here with an odd phase only)
+                                         : (D & 1) ? (D + 1) / 2 : D / 2 + (int)(p0 & 1u);
         const uint32_t mf = (sm & 1u) ? 0xFFFF0000u : 0xFFFFFFFFu;
         const uint32_t ml = ((sm + (uint32_t)D) & 1u) ? 0x0000FFFFu : 0xFFFFFFFFu;
         const bool lastB = ((ndw - 1) & 1) != 0;
@@ -846,6 +849,27 @@ hipError_t fmd_launch_tile(const FmdLaunch& L, hipStream_t stream)
         // with every window length in it measured 2-4 % slower at downsample 5 and 7).  DH < 0: odd downsample -DH.
         case 6: launch_one<6>(K, g, lds, stream); break;     // downsample 12, 14: whole-dword windows like 2 ... 10
         case 7: launch_one<7>(K, g, lds, stream); break;
+        // downsample 16 ... 32, 64, 128 and the odd factors to 31: the wrap-around walk / the general window loop with
+        // compile-time trip counts (16: -7 %, 32: -7.5 %, 64: -6.3 % against the catch-all kernel)
+        case 8: launch_one<8>(K, g, lds, stream); break;
+        case 9: launch_one<9>(K, g, lds, stream); break;
+        case 10: launch_one<10>(K, g, lds, stream); break;
+        case 11: launch_one<11>(K, g, lds, stream); break;
+        case 12: launch_one<12>(K, g, lds, stream); break;
+        case 13: launch_one<13>(K, g, lds, stream); break;
+        case 14: launch_one<14>(K, g, lds, stream); break;
+        case 15: launch_one<15>(K, g, lds, stream); break;
+        case 16: launch_one<16>(K, g, lds, stream); break;
+        case 32: launch_one<32>(K, g, lds, stream); break;
+        case 64: launch_one<64>(K, g, lds, stream); break;
+        case -17: launch_one<-17>(K, g, lds, stream); break;
+        case -19: launch_one<-19>(K, g, lds, stream); break;
+        case -21: launch_one<-21>(K, g, lds, stream); break;
+        case -23: launch_one<-23>(K, g, lds, stream); break;
+        case -25: launch_one<-25>(K, g, lds, stream); break;
+        case -27: launch_one<-27>(K, g, lds, stream); break;
+        case -29: launch_one<-29>(K, g, lds, stream); break;
+        case -31: launch_one<-31>(K, g, lds, stream); break;
         case -1: launch_one<-1>(K, g, lds, stream); break;
         case -3: launch_one<-3>(K, g, lds, stream); break;
         case -5: launch_one<-5>(K, g, lds, stream); break;
