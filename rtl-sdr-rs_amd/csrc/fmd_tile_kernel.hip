@@ -44,6 +44,9 @@ using namespace fmd_dev;
 #ifndef FMD_ROT_MASK
 #define FMD_ROT_MASK 3               /* rotate the window walk when the dword count is a multiple of 4 (see tile_body) */
 #endif
+#ifndef FMD_DH4_B128
+#define FMD_DH4_B128 1
+#endif
 #ifndef FMD_ODD_KERNELS
 #define FMD_ODD_KERNELS 1
 #endif
@@ -288,7 +291,11 @@ __device__ __forceinline__ void tile_body(const FmdLaunch& L, const TileCtx& X, 
     // A wave-round is 128 windows, two per lane (i and i + 64: two independent dependency chains the
     // scheduler interleaves), producing 127 new discriminator samples; lane 0's first window repeats the
     // previous round's last one and only serves as predecessor.
-    if (fastwin && FMD_USE_F32 && FMD_PAIR && DH != 4) {      // DH == 4: lanes 8 dwords apart, a 4-way conflict that costs more than the pair form saves
+    // DH == 4 (downsample 8): lanes 8 dwords apart are a 4-way conflict for dword reads, which costs more than the pair
+    // form saves -- unless the windows are 16-byte aligned in LDS (channel buffers aligned, boxcar phase 0: the usual
+    // case), where one ds_read_b128 fetches a whole window: then the pair form is taken with two such reads per lane.
+    const bool dh4_aligned = DH == 4 && FMD_DH4_B128 && (((wofs - (int)hp) & 3) == 0);     // block-uniform
+    if (fastwin && FMD_USE_F32 && FMD_PAIR && (DH != 4 || dh4_aligned)) {
         // Whole-dword windows, f32 discriminator (downsample 2 ... 10).  Lane l takes the ADJACENT windows i = base + 2l
         // and i + 1: the second window's predecessor is the lane's own first one, and only the first one's comes from
         // the neighbour (the second window of lane l - 1; lane 0's first window is the round's overlap and is not
@@ -308,13 +315,26 @@ __device__ __forceinline__ void tile_body(const FmdLaunch& L, const TileCtx& X, 
             const int i1 = base + 2 * (int)lane, i2 = i1 + 1;
             const uint32_t* __restrict__ pa = raw_w + (uint32_t)(wbase + DH * i1);
             int re1 = DH, im1 = c1, re2 = DH, im2 = c2;
+            if constexpr (DH == 4) {                         // (aligned: checked above) one 16-byte read per window
+                const uint4 va = *reinterpret_cast<const uint4*>(pa), vb = *reinterpret_cast<const uint4*>(pa + 4);
+                const uint32_t a4[4] = {va.x, va.y, va.z, va.w}, b4[4] = {vb.x, vb.y, vb.z, vb.w};
 #pragma unroll
-            for (int u = 0; u < (DH > 0 ? DH : 1); ++u) {
-                const uint32_t wa = pa[u] ^ 0x80808080u, wb = pa[u + DH] ^ 0x80808080u;   // u8 -> s8 (b - 128)
-                re1 = sdot4(wa, (u & 1) ? r1B : r1A, re1);
-                im1 = sdot4(wa, (u & 1) ? m1B : m1A, im1);
-                re2 = sdot4(wb, (u & 1) ? r2B : r2A, re2);
-                im2 = sdot4(wb, (u & 1) ? m2B : m2A, im2);
+                for (int u = 0; u < 4; ++u) {
+                    const uint32_t wa = a4[u] ^ 0x80808080u, wb = b4[u] ^ 0x80808080u;    // u8 -> s8 (b - 128)
+                    re1 = sdot4(wa, (u & 1) ? r1B : r1A, re1);
+                    im1 = sdot4(wa, (u & 1) ? m1B : m1A, im1);
+                    re2 = sdot4(wb, (u & 1) ? r2B : r2A, re2);
+                    im2 = sdot4(wb, (u & 1) ? m2B : m2A, im2);
+                }
+            } else {
+#pragma unroll
+                for (int u = 0; u < (DH > 0 ? DH : 1); ++u) {
+                    const uint32_t wa = pa[u] ^ 0x80808080u, wb = pa[u + DH] ^ 0x80808080u;   // u8 -> s8 (b - 128)
+                    re1 = sdot4(wa, (u & 1) ? r1B : r1A, re1);
+                    im1 = sdot4(wa, (u & 1) ? m1B : m1A, im1);
+                    re2 = sdot4(wb, (u & 1) ? r2B : r2A, re2);
+                    im2 = sdot4(wb, (u & 1) ? m2B : m2A, im2);
+                }
             }
             const float ar1 = (float)re1, ai1 = (float)im1, ar2 = (float)re2, ai2 = (float)im2;
             const float br1 = u2f(wave_shr1(f2u(ar2))), bi1 = u2f(wave_shr1(f2u(ai2)));   // second window of lane l - 1
