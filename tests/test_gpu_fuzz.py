@@ -15,7 +15,8 @@ RATES = [8000, 11025, 12500, 16000, 22050, 24000, 32000, 44100, 48000]
 
 
 def random_case(rng):
-    D = int(rng.choice([1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 21, 32, 50, 81, 128]))
+    D = int(rng.choice([1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 24, 25, 27, 28, 30, 31, 32, 33, 50, 64,
+                       81, 128]))      # every factor with a kernel of its own up to 18, a sample of the others, the catch-all
     slow = int(rng.choice(RATES))
     fast = int(slow * rng.uniform(1.0, 9.0)) if rng.random() < 0.7 else int(rng.choice([170000, 240000, 250000, 166666, 1000000 // D + 1]))
     fast = max(fast, slow)
