@@ -113,7 +113,7 @@ int choose_tiling(fmd_demod* d, uint32_t kt_req)
         const uint32_t nt_threads = d->block_threads, waves = nt_threads / 64u;
         const double budget = 20480.0 * (double)nt_threads / 256.0;
         const uint32_t dh = (r.D + 1u) / 2u;                                 // dwords per window
-        const double c_round = 64.0 + 12.0 * dh, c_audio = 70.0 + 6.0 * (double)(r.fr / r.sr), c_fixed = 60.0;   // (150 before the fast prologue)
+        const double c_round = 64.0 + 12.0 * dh, c_audio = 70.0 + 6.0 * (double)(r.fr / r.sr), c_fixed = 90.0;   // per wave: prologue, staging, barriers, epilogue
         double best = 0.0;
         kt = 1;
         for (uint32_t k = 1; k <= 8192u; ++k) {              // (1024 until the end of round 2: at rate ratios near 1 that left most of the LDS unused)
@@ -124,11 +124,14 @@ int choose_tiling(fmd_demod* d, uint32_t kt_req)
             if (lds > budget && k > 1) break;
             const uint64_t cnt = ((uint64_t)k * r.fr + r.sr - 1) / r.sr + 1;            // decimated samples formed
             const uint64_t rounds = (cnt + 126) / 127, per_wave = (rounds + waves - 1) / waves;
-            const uint64_t passes = (k + nt_threads - 1) / nt_threads;
-            // a tile's time follows its busiest wave, the chip's issue slots follow the sum over the waves: both count
-            // (122 audio samples per tile = 8 rounds measured 1 % slower than 118 = 7 rounds at the bench configuration)
-            const double round_cost = 0.5 * (double)per_wave + 0.5 * (double)rounds / (double)waves;
-            const double work = round_cost * c_round + passes * c_audio + c_fixed;
+            // The chip is VALU-issue-saturated at almost every rate, so what counts is the wave-instructions a
+            // tile costs in all -- its rounds, the resampler once per wave that has an audio sample to form, the per-wave
+            // prologue / epilogue -- plus a share of the round slots that stay idle when the rounds do not divide by the
+            // waves (the tile's LDS is held until its busiest wave is done).  Checked against tiling sweeps at downsample 4,
+            // 5, 6, 10, 13, 14, 32, 64 (e.g. 64: 27 audio samples = one full round, not 31 = a second, nearly empty one: -7 %).
+            const uint64_t wave_passes = (k + 63) / 64;
+            const double idle = (double)(per_wave * waves - rounds);
+            const double work = ((double)rounds + 0.35 * idle) * c_round + (double)wave_passes * c_audio + (double)waves * c_fixed;
             const double per_byte = work / (2.0 * r.D * (double)cnt);
             if (k == 1 || per_byte < best) { best = per_byte; kt = k; }
         }
