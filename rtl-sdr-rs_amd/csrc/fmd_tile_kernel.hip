@@ -47,6 +47,9 @@ using namespace fmd_dev;
 #ifndef FMD_DH4_B128
 #define FMD_DH4_B128 1
 #endif
+#ifndef FMD_DPP_DEAD
+#define FMD_DPP_DEAD 1
+#endif
 #ifndef FMD_ODD_KERNELS
 #define FMD_ODD_KERNELS 1
 #endif
@@ -85,6 +88,13 @@ __device__ __forceinline__ uint32_t wave_shr1(uint32_t v)
 __device__ __forceinline__ uint32_t wave_shr1_old(uint32_t old, uint32_t v)
 {
     return (uint32_t)__builtin_amdgcn_update_dpp((int)old, (int)v, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
+}
+
+// wave_shr:1 with a register that is DEAD at the call site as `old` (lane 0 keeps it: only for results lane 0 never uses):
+// the destination is tied to `old`, so the v_mov 0 of wave_shr1 disappears.  bound_ctrl stays off (see fmd_device.h).
+__device__ __forceinline__ uint32_t wave_shr1_dead(uint32_t dead, uint32_t v)
+{
+    return (uint32_t)__builtin_amdgcn_update_dpp(FMD_DPP_DEAD ? (int)dead : 0, (int)v, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
 }
 
 // lane l <- v[(l + 63) % 64]: lane 0 receives lane 63.
@@ -315,6 +325,7 @@ __device__ __forceinline__ void tile_body(const FmdLaunch& L, const TileCtx& X, 
             const int i1 = base + 2 * (int)lane, i2 = i1 + 1;
             const uint32_t* __restrict__ pa = raw_w + (uint32_t)(wbase + DH * i1);
             int re1 = DH, im1 = c1, re2 = DH, im2 = c2;
+            uint32_t dead1 = 0, dead2 = 0;                   // the last sign-flipped dwords: dead after the dot products
             if constexpr (DH == 4) {                         // (aligned: checked above) one 16-byte read per window
                 const uint4 va = *reinterpret_cast<const uint4*>(pa), vb = *reinterpret_cast<const uint4*>(pa + 4);
                 const uint32_t a4[4] = {va.x, va.y, va.z, va.w}, b4[4] = {vb.x, vb.y, vb.z, vb.w};
@@ -325,6 +336,7 @@ __device__ __forceinline__ void tile_body(const FmdLaunch& L, const TileCtx& X, 
                     im1 = sdot4(wa, (u & 1) ? m1B : m1A, im1);
                     re2 = sdot4(wb, (u & 1) ? r2B : r2A, re2);
                     im2 = sdot4(wb, (u & 1) ? m2B : m2A, im2);
+                    dead1 = wa; dead2 = wb;
                 }
             } else {
 #pragma unroll
@@ -334,10 +346,11 @@ __device__ __forceinline__ void tile_body(const FmdLaunch& L, const TileCtx& X, 
                     im1 = sdot4(wa, (u & 1) ? m1B : m1A, im1);
                     re2 = sdot4(wb, (u & 1) ? r2B : r2A, re2);
                     im2 = sdot4(wb, (u & 1) ? m2B : m2A, im2);
+                    dead1 = wa; dead2 = wb;
                 }
             }
             const float ar1 = (float)re1, ai1 = (float)im1, ar2 = (float)re2, ai2 = (float)im2;
-            const float br1 = u2f(wave_shr1(f2u(ar2))), bi1 = u2f(wave_shr1(f2u(ai2)));   // second window of lane l - 1
+            const float br1 = u2f(wave_shr1_dead(dead1, f2u(ar2))), bi1 = u2f(wave_shr1_dead(dead2, f2u(ai2)));   // second window of lane l - 1
             const int d1 = disc_f32_c<DH == 1>(ar1, ai1, br1, bi1);   // (:362); DH == 1 is downsample 2: no i32 wrap to emulate
             const int d2 = disc_f32_c<DH == 1>(ar2, ai2, ar1, ai1);
             if (lane > 0 && i1 < cnt) d16[i1] = (int16_t)d1;
