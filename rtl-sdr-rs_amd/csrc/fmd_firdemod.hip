@@ -432,6 +432,7 @@ struct fmd_firdemod {
     uint64_t f64_guarded = 0, f64_patched = 0;
     FmdStreamOrder order;
     bool no_rows = false;                                 // FMD_FD_ROWS=0: geometry on the device (A/B)
+    bool no_reuse = false, int_disc = false;              // FMD_FD_NOREUSE / FMD_FD_INT_DISC: plain MFMA mapping / integer discriminator (A/B), read at creation
     size_t lds_budget = 20480;                            // LDS per tile (8 tiles per CU); FMD_FD_LDS (tuning)
     hipStream_t stream = nullptr;
     uint8_t* d_iq = nullptr; size_t d_iq_cap = 0;
@@ -520,8 +521,8 @@ int fd_enqueue(fmd_firdemod* f, const void* d_iq, size_t nbytes, void* d_out, si
     { const char* e = getenv("FMD_DBG"); L.dbg = e ? (uint32_t)atoi(e) : 0u; }
 #endif
     fd_lanes(L.fa, r.kt, &L.lg, &L.lg_magic, &L.ch);
-    L.reuse = f->M == 8u && f->plan.n_pass == 1u && !getenv("FMD_FD_NOREUSE") ? 1u : 0u;
-    L.f32_disc = f->lp_bound <= 2048u && !getenv("FMD_FD_INT_DISC") ? 1u : 0u;
+    L.reuse = f->M == 8u && f->plan.n_pass == 1u && !f->no_reuse ? 1u : 0u;
+    L.f32_disc = f->lp_bound <= 2048u && !f->int_disc ? 1u : 0u;
     L.sr_shift = 32u;
     if ((r.sr & (r.sr - 1u)) == 0u) { L.sr_shift = 0u; while ((1u << L.sr_shift) < r.sr) ++L.sr_shift; }
     L.use_rows = 0u;
@@ -624,6 +625,8 @@ int fmd_firdemod_new(const int16_t* taps, uint32_t n_taps, uint32_t decim, uint3
     if (const char* e = getenv("FMD_FD_KT")) kt_env = (uint32_t)atoi(e);
     if (const char* e = getenv("FMD_FD_LDS")) f->lds_budget = (size_t)atoi(e);
     if (const char* e = getenv("FMD_FD_ROWS")) f->no_rows = e[0] == '0';
+    f->no_reuse = getenv("FMD_FD_NOREUSE") != nullptr;
+    f->int_disc = getenv("FMD_FD_INT_DISC") != nullptr;
     for (uint32_t kt = 1; kt <= 1024; ++kt) {
         if ((uint64_t)r.sr * (kt + 2) >= (1u << 24)) break;
         uint32_t lc, rb; size_t l;
