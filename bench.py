@@ -10,10 +10,14 @@ channels with no data-path collective (weak scaling).  Prints ONE JSON line on r
 Launching:  `python bench.py --gpus N` starts N rank processes ITSELF (fresh children, created before this
 process touches the GPU; the parent only relays rank 0's line);  under `python -m torch.distributed.run
 --nproc-per-node N bench.py --gpus N` (RANK / WORLD_SIZE set) each process is one rank.  Both ways: one rank
-per GPU, RCCL ("nccl") only for the barrier / max-over-ranks timing.
+per GPU, RCCL ("nccl") only for the barrier / max-over-ranks timing.  `--force-dist` takes that same
+torch.distributed code path with world size 1 (so the RCCL branch runs on a one-GPU box too).
 
 Timing: exactly K steps per timed region, each region bracketed by barrier + synchronize, MAX over ranks;
-the region is repeated until >= 50 ms have been timed and the MEDIAN region is reported (min / max beside it).
+the region is repeated until >= 1 s has been timed and the MEDIAN region is reported (min / max beside it).
+After the timing: a parity bit (a fresh bank, two steps from the zero state, >= 64 channels against the oracle),
+side lines for the other BASELINE configurations (`extra.*`, each outside the headline's timed region) and the CPU
+baseline (the oracle, the only place besides the parity bit where bench.py touches it).
 """
 import argparse
 import ctypes as C
@@ -32,10 +36,12 @@ sys.path.insert(0, ROOT)
 CHANNELS = 4096
 BLOCK = 16 * 16384
 D, FAST, SLOW = 10, 240000, 32000
+CFG_REF = (6, 170000, 32000)     # optimal_settings(94.9 MHz, 170 kHz), examples/simple_fm.rs:25-27,48,189-214
 HBM_PEAK_GBS = 8000.0            # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 KERNEL = "fmd_demod_tile_kernel<5, 256, 2>"   # the dominant kernel of this workload (rocprofv3 --kernel-trace name)
-MIN_TIMED_S = 0.050              # repeat the K-step region until this much has been timed
-PMC_SUMMARY = os.path.join("profiles", "r02_pmc_summary.json")
+MIN_TIMED_S = 1.0                # repeat the K-step region until this much has been timed
+MAX_REGIONS = 4000
+PMC_SUMMARY = os.path.join("profiles", "r03_pmc_summary.json")
 
 
 # what the headline kernel is built from (the FIR kernels, the sink and the CLI do not enter it)
@@ -53,13 +59,19 @@ def kernel_source_hash():
     return h.hexdigest()[:16]
 
 
+def load_oracle():
+    """The CPU oracle (oracle/fm_oracle.c): checker and CPU baseline only -- never on the measured path."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib
+    return oracle_lib.load()
+
+
 def cpu_baseline(fmd, torch, cfg, iq_dev, target_s=12.0):
     """The oracle (oracle/fm_oracle.c, a C restatement of the reference passes: kind 'port') timed on this
-    box's host cores over a bounded sample of the same workload."""
-    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    box's host cores over a bounded sample of the same workload; BASELINE.md's CPU-1 line (the reference's own
+    configuration, one channel, one thread, >= 8 blocks) beside it."""
     import numpy as np
-    import oracle_lib
-    o = oracle_lib.load()
+    o = load_oracle()
     cores = os.cpu_count() or 1
     ocfg = o.config(cfg.downsample, cfg.rate_out, cfg.rate_resample)
     chans = min(CHANNELS, cores * 2)
@@ -82,19 +94,80 @@ def cpu_baseline(fmd, torch, cfg, iq_dev, target_s=12.0):
         total += t
         passes += 1
     samples = passes * chans * calls * (BLOCK // 2)
-    # one thread, one channel, same blocks -- about 1 s
-    one_t, one_n = 0.0, 0
-    while one_t < 1.0 and one_n < 200:
-        t = o.lib.fmo_bench_batch(C.byref(ocfg), data.ctypes.data_as(u8p), 1, calls, BLOCK, 1, C.byref(chk), None)
-        if t <= 0:
-            break
-        one_t += t
-        one_n += 1
-    single = round(one_n * calls * (BLOCK // 2) / one_t / 1e6, 2) if one_t > 0 else None
+
+    def one_thread(c, blocks, budget_s):
+        """one thread, one channel, `blocks` consecutive 262144-byte calls; returns Msamples/s"""
+        d1 = np.ascontiguousarray(np.tile(host[0], blocks))
+        t_sum, n = 0.0, 0
+        while t_sum < budget_s and n < 400:
+            t = o.lib.fmo_bench_batch(C.byref(c), d1.ctypes.data_as(u8p), 1, blocks, BLOCK, 1, C.byref(chk), None)
+            if t <= 0:
+                return None
+            t_sum += t
+            n += 1
+        return round(n * blocks * (BLOCK // 2) / t_sum / 1e6, 2)
+
+    single = one_thread(ocfg, calls, 1.0)                     # SURVEY 8d (i): one thread, one channel, same blocks
+    ref_cfg = o.config(*CFG_REF)
+    cpu1 = one_thread(ref_cfg, 8, 2.0)                        # BASELINE.md CPU-1
     return {"value": round(samples / total / 1e6, 2), "unit": "Msamples/s", "cores": cores, "kind": "port",
             "single_thread_value": single,
+            "cfg_ref_single_thread": {"value": cpu1, "unit": "Msamples/s", "cores": 1,
+                                      "ns_per_iq_sample": round(1e3 / cpu1, 3) if cpu1 else None,
+                                      "what": "BASELINE.md CPU-1: downsample %d, %d -> %d Hz, 1 channel, 1 thread, 8 x %d B per pass" % (CFG_REF + (BLOCK,))},
             "sample": "%d passes x %d channels x %d calls x %d B of the same synthetic workload, %d threads, "
                       "%.1f s of oracle time (oracle/fm_oracle.c, gcc -O3 -fwrapv)" % (passes, chans, calls, BLOCK, cores, total)}
+
+
+def parity_bit(fmd, torch, cfg, bufs, dev_index, stream, n_check=64):
+    """Outside every timed region: a FRESH bank (zero state) runs two consecutive steps on the benchmark's own
+    input batches; audio of >= 64 channels (first, last, strided) and the final state are compared with the oracle."""
+    import numpy as np
+    o = load_oracle()
+    nch = bufs[0].shape[0]
+    picks = sorted(set([0, 1, nch - 1, nch // 2] + list(range(0, nch, max(1, nch // (n_check - 4))))))
+    bank = fmd.DemodBank(cfg, nch, device_id=dev_index)
+    cap = bank.out_cap(BLOCK)
+    obank = o.new_bank(o.config(cfg.downsample, cfg.rate_out, cfg.rate_resample), len(picks))
+    ok, bad = True, []
+    for call in range(2):
+        out = torch.zeros((nch, cap), dtype=torch.int16, device=bufs[0].device)
+        src = bufs[call % len(bufs)]
+        bank.demodulate_device(src.data_ptr(), BLOCK, out.data_ptr(), cap, None, stream)
+        bank.check()
+        lens = bank.last_out_len()
+        got = out[picks].cpu().numpy()
+        exp, elens = o.demodulate_batch(obank, src[picks].cpu().numpy())
+        for j, c in enumerate(picks):
+            if lens[c] != elens[j] or not np.array_equal(got[j, :elens[j]], exp[j, :elens[j]]):
+                ok = False
+                bad.append([call, int(c)])
+    for j in (0, len(picks) - 1):
+        if bank.get_state(picks[j]).as_dict() != o.state_of(obank[j]):
+            ok = False
+            bad.append(["state", int(picks[j])])
+    bank.close()
+    return {"channels_checked": len(picks), "calls": 2, "ok": ok, "mismatches": bad[:8],
+            "against": "oracle/fm_oracle.c on the same bytes, after the timed regions, fresh bank from the zero state"}
+
+
+def time_calls(torch, call, settle=150, steps=100, regions=5):
+    """Median / min / max ms per call over `regions` HIP-event-timed regions of `steps` calls on torch's current
+    stream (the stream every call here is enqueued on), after `settle` untimed calls."""
+    for i in range(settle):
+        call(i)
+    torch.cuda.synchronize()
+    regs, last = [], None
+    for _ in range(regions):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for i in range(steps):
+            last = call(i)
+        e1.record()
+        torch.cuda.synchronize()
+        regs.append(e0.elapsed_time(e1) / steps)
+    regs.sort()
+    return regs[len(regs) // 2], regs[0], regs[-1], last
 
 
 def extra_config4(fmd, torch, dev, stream, fused):
@@ -109,50 +182,144 @@ def extra_config4(fmd, torch, dev, stream, fused):
         t = torch.empty((nch, n), dtype=torch.uint8, device=dev)
         fmd.synth.fill_device(t.data_ptr(), nch, n, sample_offset=b * (n // 2), device_id=dev.index, stream=stream)
         bufs.append(t)
+    taps = rng.integers(-2047, 2048, T).astype(np.int16)             # the same taps for both lines
     if fused:
-        taps = rng.integers(-2047, 2048, T).astype(np.int16)         # the same taps as the stand-alone line; auto shift
-        fast, slow = 2_500_000, 48_000                               # 20 Msps / 8 -> 2.5 Msps -> 48 kHz audio
+        fast, slow = 2_500_000, 48_000                               # 20 Msps / 8 -> 2.5 Msps -> 48 kHz audio; auto shift
         bank = fmd.FirDemodBank(taps, M, fast, slow, nch, device_id=dev.index)
         cap = bank.out_cap(n)
         out = torch.zeros((nch, cap), dtype=torch.int16, device=dev)
         call = lambda i: bank.demodulate_device(bufs[i % 3].data_ptr(), n, out.data_ptr(), cap, stream)
         out_bytes = lambda k: 2 * k
     else:
-        taps = rng.integers(-2047, 2048, T).astype(np.int16)
         bank = fmd.FirBank(taps, M, nch, device_id=dev.index)
         cap = bank.out_cap(n)
         out = torch.zeros((nch, cap, 2), dtype=torch.int32, device=dev)
         call = lambda i: bank.filter_device(bufs[i % 3].data_ptr(), n, out.data_ptr(), cap, stream)
         out_bytes = lambda k: 8 * k
-    for i in range(150):                                              # untimed: clocks settle
-        call(i)
-    torch.cuda.synchronize()
-    regs = []
-    nout = 0
-    for r in range(5):
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for i in range(100):
-            nout = call(i)
-        e1.record()
-        torch.cuda.synchronize()
-        regs.append(e0.elapsed_time(e1) / 100)
-    regs.sort()
-    ms = regs[len(regs) // 2]
+    ms, lo, hi, nout = time_calls(torch, call)
+    if fused:
+        bank.check()
     alg = nch * n + nch * out_bytes(int(nout))
     res = {"workload": "BASELINE configs[3]: %d-tap FIR, decimate %d, %d channels x %d B/call (20 Msps x 52.4 ms)%s"
                        % (T, M, nch, n, ", fused with the discriminator and the %d -> %d Hz resampler" % (fast, slow) if fused else ""),
            "kernel": "fmd_firdemod_kernel" if fused else "fmd_fir_mfma_kernel", "ms_per_call": round(ms, 4),
-           "ms_min_max": [round(regs[0], 4), round(regs[-1], 4)],
+           "ms_min_max": [round(lo, 4), round(hi, 4)],
            "iq_msamples_per_s": round(nch * (n // 2) / ms / 1e3, 1), "outputs_per_channel": int(nout),
            "algorithmic_bytes_per_launch": alg, "GBps": round(alg / ms / 1e6, 1), "frac": round(alg / ms / 1e6 / HBM_PEAK_GBS, 4)}
     del bank, out, bufs
     return res
 
 
+def extra_cfg_ref(fmd, torch, dev, stream, bufs):
+    """The reference's OWN configuration -- what optimal_settings(94.9 MHz, 170 kHz) produces for the shipped example
+    (simple_fm.rs:25-27,48: downsample 6, 170 kHz -> 32 kHz) -- on the headline's batch shape and input buffers."""
+    d, fast, slow = CFG_REF
+    nch = bufs[0].shape[0]
+    cfg = fmd.DemodConfig(fast, fast, slow, d, max(1, (1 << 15) // (128 * d)))
+    bank = fmd.DemodBank(cfg, nch, device_id=dev.index)
+    cap = bank.out_cap(BLOCK)
+    out = torch.zeros((nch, cap), dtype=torch.int16, device=dev)
+    call = lambda i: bank.demodulate_device(bufs[i % len(bufs)].data_ptr(), BLOCK, out.data_ptr(), cap, None, stream)
+    ms, lo, hi, _ = time_calls(torch, call)
+    bank.check()
+    alg = nch * BLOCK + 2 * int(bank.last_out_len().sum())
+    res = {"workload": "cfg-ref: %d channels x %d B/call, downsample %d, %d -> %d Hz (examples/simple_fm.rs:25-27)" % (nch, BLOCK, d, fast, slow),
+           "kernel": "fmd_demod_tile_kernel<%d, 256, 2>" % (d // 2), "ms_per_call": round(ms, 4), "ms_min_max": [round(lo, 4), round(hi, 4)],
+           "iq_msamples_per_s": round(nch * (BLOCK // 2) / ms / 1e3, 1), "algorithmic_bytes_per_launch": alg,
+           "GBps": round(alg / ms / 1e6, 1), "frac": round(alg / ms / 1e6 / HBM_PEAK_GBS, 4), "tiling": bank.tiling()}
+    bank.close()
+    return res
+
+
+def extra_config2(fmd, torch, dev, stream):
+    """BASELINE configs[1]: ONE FM channel at 2.4 Msps: (a) one DEFAULT_BUF_LENGTH call per launch (launch-latency bound);
+    (b) 64 MiB per launch handed over as 256 reference calls of 262144 B (fmd_demod_set_block_len): the audio and the
+    state are those of feeding the reference the 256 blocks one by one."""
+    cfg = fmd.DemodConfig(FAST, FAST, SLOW, D, max(1, (1 << 15) // (128 * D)))
+    res = {"workload": "BASELINE configs[1]: 1 FM channel @ 2.4 Msps, device-resident input"}
+    for name, n, blk, steps in (("one_262144_B_call_per_launch", BLOCK, 0, 400), ("64MiB_per_launch_as_256_reference_calls", 64 << 20, BLOCK, 100)):
+        bank = fmd.DemodBank(cfg, 1, device_id=dev.index)
+        bank.set_block_len(blk)
+        iq = torch.empty((1, n), dtype=torch.uint8, device=dev)
+        fmd.synth.fill_device(iq.data_ptr(), 1, n, device_id=dev.index, stream=stream)
+        cap = bank.out_cap(n)
+        out = torch.zeros((1, cap), dtype=torch.int16, device=dev)
+        call = lambda i: bank.demodulate_device(iq.data_ptr(), n, out.data_ptr(), cap, None, stream)
+        ms, lo, hi, _ = time_calls(torch, call, settle=50, steps=steps, regions=3)
+        bank.check()
+        res[name] = {"ms_per_launch": round(ms, 5), "ms_min_max": [round(lo, 5), round(hi, 5)],
+                     "iq_msamples_per_s": round(n / 2 / ms / 1e3, 1), "realtime_factor_at_2.4Msps": round(n / 2 / ms / 1e3 / 2.4, 1),
+                     "GBps": round(n / ms / 1e6, 1)}
+        bank.close()
+        del iq, out
+    return res
+
+
+def extra_check_per_step(fmd, torch, bank, bufs, out, cap, stream, steps=200):
+    """The drop-in usage of the device entry point: fmd_demod_demodulate_device followed by fmd_demod_check (sync +
+    report read-back, the completion point a consumer needs before it reads the audio) for EVERY buffer.  Host wall
+    time per step, launch latency and the synchronisation included."""
+    for i in range(20):
+        bank.demodulate_device(bufs[i % len(bufs)].data_ptr(), BLOCK, out.data_ptr(), cap, None, stream)
+        bank.check()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        bank.demodulate_device(bufs[i % len(bufs)].data_ptr(), BLOCK, out.data_ptr(), cap, None, stream)
+        bank.check()
+    ms = (time.perf_counter() - t0) / steps * 1e3
+    nch = bufs[0].shape[0]
+    return {"what": "demodulate_device + fmd_demod_check after every step (host wall time, %d steps)" % steps,
+            "ms_per_step": round(ms, 4), "iq_msamples_per_s": round(nch * (BLOCK // 2) / ms / 1e3, 1)}
+
+
+def extra_sink_pcie(fmd, dev_index, nch=1024, steps=20):
+    """PCIe-INCLUSIVE rate (never `value`): 1024 read_sync-sized buffers per slot through the pipelined sink (fmd_sink_*,
+    ring of 3 page-locked slots; H2D, kernel and D2H overlap), with and without the memcpy that fills the slot."""
+    import numpy as np
+    from rtl_sdr_rs_amd._ffi import SINK_CALLBACK, check, lib
+    cfg = fmd.DemodConfig(FAST, FAST, SLOW, D, max(1, (1 << 15) // (128 * D)))
+    src = np.ascontiguousarray(np.tile(fmd.synth.synth_iq(8, BLOCK), (nch // 8, 1)))
+    count = [0, 0]
+
+    def _count(user, seq, audio, out_len, out_cap, status):
+        count[0] += 1
+        count[1] |= int(status != 0)
+    cb = SINK_CALLBACK(_count)
+    h = C.c_void_p()
+    ids = (C.c_int32 * 1)(dev_index)
+    check(lib().fmd_sink_new(C.byref(cfg), nch, ids, 1, BLOCK, 3, C.cast(cb, C.c_void_p), None, C.byref(h)))
+
+    def push(fill):
+        p = C.c_void_p()
+        check(lib().fmd_sink_acquire(h, C.byref(p)))
+        if fill:
+            C.memmove(p.value, src.ctypes.data, nch * BLOCK)     # stands for read_sync writing into the slot
+        check(lib().fmd_sink_submit(h))
+    res = {"what": "%d channels x %d B per buffer through fmd_sink_* (depth 3), host buffers: H2D + kernel + D2H" % (nch, BLOCK)}
+    try:
+        for _ in range(4):
+            push(True)
+        check(lib().fmd_sink_drain(h))
+        for name, fill in (("slots_filled_by_memcpy", True), ("slots_prefilled", False)):
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                push(fill)
+            check(lib().fmd_sink_drain(h))
+            dt = (time.perf_counter() - t0) / steps
+            res[name] = {"ms_per_buffer": round(dt * 1e3, 3), "host_GBps": round(nch * BLOCK / dt / 1e9, 2),
+                         "iq_msamples_per_s": round(nch * BLOCK / 2 / dt / 1e6, 1)}
+        res["delivered"] = count[0]
+        res["all_status_ok"] = count[1] == 0
+    finally:
+        lib().fmd_sink_free(h)
+    return res
+
+
 def spawn_ranks(args):
     """`python bench.py --gpus N` without a launcher: start N fresh rank processes (this process has not touched
-    the GPU and never will), relay rank 0's JSON line, fail if any rank fails."""
+    the GPU and never will), relay rank 0's JSON line, fail if any rank fails.  A rank that dies -- rank 0, which hosts
+    the rendezvous store, included -- takes the job down after a grace period instead of leaving the others waiting in
+    the rendezvous or a collective until their own timeout (10 to 30 minutes)."""
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
@@ -163,21 +330,28 @@ def spawn_ranks(args):
     for r in range(args.gpus):
         e = dict(env, RANK=str(r), LOCAL_RANK=str(r))
         procs.append(subprocess.Popen(cmd, env=e, stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+
+    def reap(grace_s):
+        """let the others report their own error (or finish) first, then kill what is left -- by handle"""
+        deadline = time.time() + grace_s
+        while time.time() < deadline and any(p.poll() is None for p in procs):
+            time.sleep(0.2)
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
     out0 = b""
-    while True:                                                  # a rank that dies takes the job down instead of leaving the
-        try:                                                     # others waiting in the rendezvous / a collective
+    while True:
+        try:
             out0, _ = procs[0].communicate(timeout=1.0)
-            break
+            break                                                # rank 0 is done (whatever its exit code)
         except subprocess.TimeoutExpired:
             if any(p.poll() not in (None, 0) for p in procs[1:]):
-                deadline = time.time() + 15.0                    # let the others report their own error first
-                while time.time() < deadline and any(p.poll() is None for p in procs):
-                    time.sleep(0.2)
-                for p in procs:
-                    if p.poll() is None:
-                        p.kill()                                 # the exact children started above, by handle
+                reap(15.0)
                 out0, _ = procs[0].communicate()
                 break
+    # rank 0 failed: 15 s for the others' own messages; rank 0 succeeded: the others are past the last barrier and exit
+    # by themselves -- a minute is generous
+    reap(15.0 if procs[0].returncode != 0 else 60.0)
     rcs = [procs[0].returncode] + [p.wait() for p in procs[1:]]
     sys.stdout.write(out0.decode())
     sys.stdout.flush()
@@ -195,11 +369,15 @@ def main():
     ap.add_argument("--channels", type=int, default=CHANNELS)
     ap.add_argument("--nbuf", type=int, default=3, help="distinct input batches rotated through (defeats the 256 MiB L3)")
     ap.add_argument("--kt", type=int, default=0, help="tiling override (audio samples per tile)")
-    ap.add_argument("--no-cpu", action="store_true")
-    ap.add_argument("--no-extra", action="store_true", help="skip the config-4 lines (extra.*)")
+    ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline and the parity bit (both use the oracle)")
+    ap.add_argument("--no-extra", action="store_true", help="skip the side lines (extra.*)")
+    ap.add_argument("--min-timed-s", type=float, default=MIN_TIMED_S, help="repeat the K-step region until this much has been timed")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="torch.distributed backend for the barrier / max-over-ranks timing (nccl = RCCL); with gloo "
                          "ranks may share a GPU (launch-path check on a single-GPU box)")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="initialise torch.distributed even with ONE rank: barrier / all_reduce / all_gather run through "
+                         "the same code as the N-GPU job (exercises the RCCL branch on a one-GPU box)")
     ap.add_argument("--settle", type=int, default=150,
                     help="untimed steps before the W warm-up steps: the first ~10 ms after an idle period run at "
                          "ramping clocks (measured 0.21-0.23 ms/step vs 0.193 settled); reported in config")
@@ -227,9 +405,13 @@ def main():
                          "share a GPU for a launch-path check)" % (world, ndev))
     dist = None
     dev_index = local_rank % ndev
-    if world > 1:
+    if world > 1 or args.force_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if "MASTER_PORT" not in os.environ:                      # --force-dist without a launcher
+            with socket.socket() as s:
+                s.bind(("127.0.0.1", 0))
+                os.environ["MASTER_PORT"] = str(s.getsockname()[1])
         torch.cuda.set_device(dev_index)
         if args.backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", dev_index))
@@ -293,8 +475,8 @@ def main():
         return max_over_ranks(own), own, ev0.elapsed_time(ev1) / args.steps
 
     regions = [timed_region()]
-    reps = min(400, max(1, int(math.ceil(1.3 * MIN_TIMED_S / regions[0][0]))))   # same on every rank (all-reduced time);
-    # 1.3: the first region of a short run is the slowest
+    # the same count on every rank (all-reduced time); 1.3: the first region of a short run is the slowest
+    reps = min(MAX_REGIONS, max(1, int(math.ceil(1.3 * args.min_timed_s / regions[0][0]))))
     for _ in range(reps - 1):
         regions.append(timed_region())
     walls = sorted(r[0] for r in regions)
@@ -326,7 +508,7 @@ def main():
         per_gpu = [float(t.item()) for t in every]
 
     # HBM bytes per launch: NOT measured by this run -- taken from the committed PMC passes of this same command
-    # (scripts/gpu_pmc.sh -> profiles/r02_pmc_summary.json; FETCH_SIZE x2 on gfx950 as MI355X_MICROARCH.md
+    # (scripts/gpu_pmc.sh -> profiles/r03_pmc_summary.json; FETCH_SIZE x2 on gfx950 as MI355X_MICROARCH.md
     # prescribes, + WRITE_SIZE), and only when that summary was taken on these very kernel sources.
     traffic, traffic_src = None, None
     try:
@@ -357,7 +539,9 @@ def main():
                        "settle_steps_untimed": args.settle,
                        "runtime": {"hip": getattr(torch.version, "hip", None), "torch": torch.__version__,
                                    "device": torch.cuda.get_device_name(dev_index)},
-                       "parallelism": "channels sharded x%d, no collective" % world},
+                       "parallelism": "channels sharded x%d, no collective" % world,
+                       "torch_distributed": None if dist is None else {"backend": args.backend, "world_size": world,
+                                                                      "collectives": "barrier per fence, all_reduce(MAX) per region, all_gather of the per-GPU rates"}},
             "timing": {"regions": len(regions), "steps_per_region": args.steps, "statistic": "median region, max over ranks",
                        "ms_per_step_min": round(walls[0] / args.steps * 1e3, 4),
                        "ms_per_step_max": round(walls[-1] / args.steps * 1e3, 4),
@@ -365,6 +549,7 @@ def main():
             "per_gpu_msamples_per_s": [round(v, 1) for v in per_gpu],
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
+                         "traffic_measured_in_this_run": False,
                          "kernel": KERNEL, "algorithmic_bytes_per_launch": alg_bytes,
                          # BASELINE's "% HBM-read roofline" (SURVEY 8d): 2 B per IQ sample only, writes not counted
                          "hbm_read_frac": round(nch * BLOCK / (kern_ms_region * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
@@ -372,11 +557,16 @@ def main():
                          "kernel_ms_events_per_launch_median": round(kern_ms_pair, 4),
                          "kernel_ms_events_per_launch_min_max": [round(per_launch[0], 4), round(per_launch[-1], 4)]},
         }
+        if world == 1 and not args.no_cpu:
+            try:
+                res["parity"] = parity_bit(fmd, torch, cfg, bufs, dev_index, stream)
+            except Exception as e:
+                res["parity"] = {"ok": False, "error": repr(e)}
         if world == 1 and not args.no_extra:
             # what this box's HBM does on a plain device-to-device copy of one input batch (SURVEY 8d asks for the
             # measured reference beside the 8 TB/s spec): bytes read + bytes written over the HIP-event time
             try:
-                dst = torch.empty_like(bufs[1])
+                dst = torch.empty_like(bufs[0])
                 for _ in range(3):
                     dst.copy_(bufs[0])
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -393,13 +583,16 @@ def main():
                 del dst
             except Exception as e:
                 res["roofline"]["box_reference"] = {"error": repr(e)}
-            del bufs[1:]
             res["extra"] = {}
-            for name, fused in (("config4_fir", False), ("config4_fir_demod_fused", True)):
+            side = [("cfg_ref", lambda: extra_cfg_ref(fmd, torch, dev, stream, bufs)),
+                    ("check_per_step", lambda: extra_check_per_step(fmd, torch, bank, bufs, out, cap, stream)),
+                    ("config2_1channel", lambda: extra_config2(fmd, torch, dev, stream)),
+                    ("config4_fir", lambda: extra_config4(fmd, torch, dev, stream, False)),
+                    ("config4_fir_demod_fused", lambda: extra_config4(fmd, torch, dev, stream, True)),
+                    ("sink_pcie", lambda: extra_sink_pcie(fmd, dev_index))]
+            for name, fn in side:
                 try:
-                    if fused and not hasattr(fmd, "FirDemodBank"):
-                        continue
-                    res["extra"][name] = extra_config4(fmd, torch, dev, stream, fused)
+                    res["extra"][name] = fn()
                 except Exception as e:          # side lines never break the headline
                     res["extra"][name] = {"error": repr(e)}
         if world == 1 and not args.no_cpu:

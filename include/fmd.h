@@ -143,8 +143,10 @@ int fmd_demod_set_block_len(fmd_demod *d, size_t block_bytes);
  * libm (the function the reference calls) and, if the truncated value differs, the audio sample (in the device
  * output buffer the launch wrote, which must still be allocated) or the carried partial sum is patched.
  * Outside that band the two results are provably equal.  The HOST entry points and fmd_demod_get_state do this
- * themselves before returning; after fmd_demod_demodulate_device call it before reading the output (and, for
- * the strict guarantee, before the next launch on the handle). */
+ * themselves before returning; after fmd_demod_demodulate_device call it before reading the output.  Only the MOST
+ * RECENT launch's output buffer is ever written by a patch (it must still be allocated); a sample of an OLDER launch
+ * that turns out to need one (probability ~2^-36 per reference call) makes this function return FMD_ERR_HIP instead of
+ * touching memory the caller may have reused: for the strict bit-exactness guarantee call it after every launch. */
 int fmd_demod_check(fmd_demod *d);
 
 /* Diagnostics of the above: f64 samples that fell into the guard band / whose value had to be patched. */
@@ -252,10 +254,18 @@ int fmd_firdemod_tiling(const fmd_firdemod *f, uint32_t *audio_per_tile, uint32_
  *   fmd_sink_acquire: the next slot to fill, [n_channels][nbytes] channel-major (blocks only when all `depth`
  *                     slots are in flight: then the oldest is completed first);
  *   fmd_sink_submit : enqueue it on every device and return without waiting;
+ *   fmd_sink_release: give the acquired slot back unsubmitted (a short read_sync ends the run, simple_fm.rs:122-125);
  *   completion, in submission order, from inside acquire / poll / drain on the caller's thread:
  *       callback(user, seq, audio [n_channels][out_cap], out_len [n_channels], out_cap, status)
  *     -- `audio` is valid during the callback only; status FMD_OK or the first error of that buffer.
- * Results are exactly those of feeding the same buffers to fmd_demod_demodulate_batch one by one. */
+ * Results are exactly those of feeding the same buffers to fmd_demod_demodulate_batch one by one, with ONE stated
+ * exception: a buffer so short that it yields no audio sample at all carries its f64 sample (simple_fm.rs:359) in the
+ * partial sum handed to the next buffer; with depth > 1 the next launch may already be enqueued when that sample turns
+ * out to need the host-libm correction (probability ~2^-36 per buffer, see fmd_demod_check) -- that buffer is then
+ * delivered with status FMD_ERR_HIP instead of silently different audio.  read_sync-sized buffers never get there.
+ * A submit that fails after it has touched a device cannot be rolled back (the Demod state of the parts before the
+ * failing one has advanced): it is terminal for the sink -- this and every later acquire / submit return the same
+ * error, poll / drain still deliver what was submitted before and then return it too. */
 typedef struct fmd_sink fmd_sink;
 typedef void (*fmd_sink_callback)(void *user, uint64_t seq, const int16_t *audio, const size_t *out_len,
                                   size_t out_cap, int status);
@@ -264,6 +274,7 @@ int fmd_sink_new(const fmd_demod_config *config, uint32_t n_channels, const int3
 void fmd_sink_free(fmd_sink *s);
 int fmd_sink_acquire(fmd_sink *s, uint8_t **iq);
 int fmd_sink_submit(fmd_sink *s);
+int fmd_sink_release(fmd_sink *s);
 int fmd_sink_poll(fmd_sink *s);     /* deliver what has finished; returns the number of buffers delivered or < 0 */
 int fmd_sink_drain(fmd_sink *s);    /* wait for and deliver everything in flight */
 int fmd_sink_info(const fmd_sink *s, size_t *out_cap, uint32_t *n_devices, uint32_t *in_flight);

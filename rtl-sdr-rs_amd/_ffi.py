@@ -105,6 +105,7 @@ PROTOTYPES = {
     "fmd_sink_free": (None, [_vp]),
     "fmd_sink_acquire": (C.c_int, [_vp, C.POINTER(_vp)]),
     "fmd_sink_submit": (C.c_int, [_vp]),
+    "fmd_sink_release": (C.c_int, [_vp]),
     "fmd_sink_poll": (C.c_int, [_vp]),
     "fmd_sink_drain": (C.c_int, [_vp]),
     "fmd_sink_info": (C.c_int, [_vp, _szp, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),

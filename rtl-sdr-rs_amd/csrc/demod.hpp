@@ -138,6 +138,7 @@ public:
     // the next slot to fill: n_channels buffers of nbytes back to back (page-locked; read_sync writes straight into it)
     uint8_t* acquire() { uint8_t* p = nullptr; check(fmd_sink_acquire(h_, &p)); return p; }
     void submit() { check(fmd_sink_submit(h_)); }
+    void release() { check(fmd_sink_release(h_)); }      // give the acquired slot back unsubmitted (short read, simple_fm.rs:122-125)
     void drain() { check(fmd_sink_drain(h_)); if (status_ != FMD_OK) throw Error(status_); }
     uint32_t channels() const { return n_; }
     size_t nbytes() const { return nbytes_; }

@@ -52,13 +52,6 @@ void set_err(const char* fmt, ...)
         }                                                                                    \
     } while (0)
 
-uint32_t env_u32(const char* name, uint32_t dflt)
-{
-    const char* s = getenv(name);
-    if (!s || !*s) return dflt;
-    return (uint32_t)strtoul(s, nullptr, 10);
-}
-
 // Channels sharing the data-independent phases (prev_index, prev_lpr_index / g).  Channels created
 // together and fed equal-sized buffers stay in one class forever; only set_state splits them.
 struct PhaseClass {
@@ -77,14 +70,16 @@ struct fmd_demod {
     uint32_t lp_cap = 0, raw_cap = 0;
     uint32_t block_ns = 0;                // fmd_demod_set_block_len: samples per reference call inside one launch
     bool force_generic = false;
+    uint32_t xcd_swizzle = 2;             // block -> (channel, tile) mapping (FMD_XCD, experiment build)
+    uint32_t dbg = 0;                     // ablation bits (FMD_DBG, experiment build)
     int n_cus = 0;                        // compute units of the device
-    uint32_t block_threads = 256;         // FMD_NT: workgroup size of the one-block-per-tile kernel
+    uint32_t block_threads = 256;         // workgroup size of the one-block-per-tile kernel (FMD_NT: 64 / 128 in the experiment build)
     uint32_t allow_fast = 2;              // FMD_FAST: 0 general prologue only, 1 closed form only, 2 (default) table, else closed form (A/B)
     FmdChanState* d_state[2] = {nullptr, nullptr};
     int cur = 0;
     FmdExcBuf* d_exc = nullptr;           // device error word + guarded f64 samples (fmd_kernels.h)
     FmdExcBuf* exc_override = nullptr;    // fmd_internal_set_report_buffer (pipelined sink: one buffer per in-flight launch)
-    double f64_guard = 0x1p-20;           // FMD_F64_GUARD_LOG2 (tests lower the bar to exercise the patch path)
+    double f64_guard = 0x1p-20;           // fixed in the shipped library; FMD_F64_GUARD_LOG2 in the experiment build (tests widen it to exercise the patch path)
     int32_t f64_skew = 0;                 // FMD_F64_SKEW, honoured by -DFMD_EXPERIMENT builds only
     uint32_t seq = 0;                     // launches enqueued
     uint64_t f64_guarded = 0, f64_patched = 0;
@@ -244,7 +239,7 @@ int enqueue(fmd_demod* d, const void* d_iq, size_t nbytes, void* d_out, size_t o
     L.r = d->r;
     L.ns = (uint32_t)(nbytes / 2);
     L.block_ns = d->block_ns;
-    L.xcd_swizzle = env_u32("FMD_XCD", 2);        // 2 (default): contiguous eighth of the channels per XCD; 0: plain
+    L.xcd_swizzle = d->xcd_swizzle;               // 2 (default): contiguous eighth of the channels per XCD; 0: plain
     L.n_channels = d->C;
     L.tiles = tiles;
     L.lp_cap = d->lp_cap;
@@ -259,7 +254,7 @@ int enqueue(fmd_demod* d, const void* d_iq, size_t nbytes, void* d_out, size_t o
     L.f64_guard = d->f64_guard;
     L.seq = d->seq + 1;
 #ifdef FMD_EXPERIMENT
-    L.dbg = env_u32("FMD_DBG", 0);
+    L.dbg = d->dbg;
     L.f64_skew = d->f64_skew;
 #endif
     {   // consecutive launches on different streams: the new stream waits for the previous launch (state ping-pong)
@@ -370,7 +365,16 @@ int fmd_internal_resolve_exc(FmdExcBuf* d_exc, int32_t R, uint32_t host_seq, uin
         const FmdF64Exc& e = *kv.second.second;
         const int16_t fixed = (int16_t)((e.sum + (int)kv.second.first) / R);              // low_pass_real, simple_fm.rs:421
         if (host_out && e.seq == host_seq) host_out[(size_t)e.channel * host_cap + (size_t)e.k] = fixed;
-        else HIP_TRY(hipMemcpy((void*)(uintptr_t)e.out_elem, &fixed, sizeof(fixed), hipMemcpyHostToDevice));
+        else if (e.seq == state_seq) HIP_TRY(hipMemcpy((void*)(uintptr_t)e.out_elem, &fixed, sizeof(fixed), hipMemcpyHostToDevice));
+        else {
+            // Nothing ties the address saved in an OLDER launch's record to memory that still holds that launch's audio:
+            // the caller may have reused the buffer for a later launch (a write would corrupt newer audio) or freed it.
+            // Only the most recent launch's buffer is ever written; for anything older the caller is told.
+            set_err("a guarded f64 sample of launch %u (channel %u, audio sample %d) needs the host-libm value, but later "
+                    "launches have been enqueued since: call the handle's check function after every *_device launch",
+                    e.seq, e.channel, e.k);
+            rc = FMD_ERR_HIP;
+        }
     }
     if (head[0] & FMD_DEVERR_EXC_CAP) {
         set_err("more than %u guarded f64 samples since the last check: some were not re-evaluated", FMD_EXC_CAP);
@@ -474,13 +478,16 @@ int fmd_demod_new(const fmd_demod_config* config, const fmd_device_config* dev, 
         set_err("rate_out / gcd = %u > 2^24 unsupported", r.fr);
         delete d; return FMD_ERR_UNSUPPORTED;
     }
-    d->force_generic = env_u32("FMD_FORCE_GENERIC", 0) != 0;
-    d->block_threads = env_u32("FMD_NT", 256);
+    // knobs: -DFMD_EXPERIMENT builds only (fmd_host.h); the shipped library takes the defaults, read once here
+    d->force_generic = fmd_knob_u32("FMD_FORCE_GENERIC", 0) != 0;
+    d->xcd_swizzle = fmd_knob_u32("FMD_XCD", 2);
+    d->dbg = fmd_knob_u32("FMD_DBG", 0);
+    d->block_threads = fmd_knob_u32("FMD_NT", 256);
     if (d->block_threads != 128 && d->block_threads != 64) d->block_threads = 256;
     // two waves per block step 2*127 windows per round: an odd downsample would flip a lane's rotation phase
     if (d->block_threads == 128 && (config->downsample & 1u)) d->block_threads = 256;
-    const uint32_t kt_env = env_u32("FMD_KT", 0);
-    d->allow_fast = env_u32("FMD_FAST", 2);
+    const uint32_t kt_env = fmd_knob_u32("FMD_KT", 0);
+    d->allow_fast = fmd_knob_u32("FMD_FAST", 2);
     int rc = choose_tiling(d, kt_env);
     if (rc) { delete d; return rc; }
 
@@ -509,8 +516,8 @@ int fmd_demod_new(const fmd_demod_config* config, const fmd_device_config* dev, 
     hipError_t e;
     FmdDeviceGuard guard(device);                             // the caller's current device comes back on return
     if ((e = guard.error()) != hipSuccess) return fail(e, "hipSetDevice");
-    if (const char* g = getenv("FMD_F64_GUARD_LOG2")) { if (*g) d->f64_guard = ldexp(1.0, atoi(g)); }
-    d->f64_skew = (int32_t)env_u32("FMD_F64_SKEW", 0);
+    if (const char* g = fmd_knob("FMD_F64_GUARD_LOG2")) d->f64_guard = ldexp(1.0, atoi(g));   // experiment build only: the
+    d->f64_skew = fmd_knob_i32("FMD_F64_SKEW", 0);                                              // shipped guard band is 2^-20, fixed
     const size_t sbytes = sizeof(FmdChanState) * (size_t)d->C;
     for (int i = 0; i < 2; ++i) {
         if ((e = hipMalloc(&d->d_state[i], sbytes)) != hipSuccess) return fail(e, "hipMalloc(state)");

@@ -301,13 +301,11 @@ __global__ void __launch_bounds__(kFirThreads, 8) fmd_fir_mfma_kernel(const FirL
 }
 
 template <int NKU>
-void launch_mfma(const FirLaunch& L, dim3 g, size_t lds, hipStream_t stream)
+void launch_mfma(const FirLaunch& L, dim3 g, size_t lds, hipStream_t stream, bool swz)
 {
     // The conflict-free LDS layout (SWZ) removes every bank conflict of the fragment reads (PMC: 10.5 M -> 0 cycles
     // per launch) but the lane-permuted DMA that produces it costs more than the conflicts did: 0.1365 vs 0.1344 ms
-    // per config-4 call, loads alone 0.0996 vs 0.0973 ms.  Off unless FMD_FIR_SWZ=1.
-    const char* e = getenv("FMD_FIR_SWZ");
-    const bool swz = e && e[0] == '1';
+    // per config-4 call, loads alone 0.0996 vs 0.0973 ms.  Off unless FMD_FIR_SWZ=1 (experiment build, read at creation).
     if (L.col_bytes == 64u && swz) hipLaunchKernelGGL((fmd_fir_mfma_kernel<NKU, true>), g, dim3(kFirThreads), lds, stream, L);
     else hipLaunchKernelGGL((fmd_fir_mfma_kernel<NKU, false>), g, dim3(kFirThreads), lds, stream, L);
 }
@@ -350,6 +348,8 @@ struct fmd_fir {
     uint32_t* d_wre = nullptr; uint32_t* d_wim = nullptr;
     uint32_t* d_amat = nullptr;                           // MFMA form: banded tap matrix, fragment order
     uint32_t n_pass = 0, nku = 0, groups = 0;             // n_pass == 0: VALU kernel only
+    uint32_t xcd_swizzle = 2, dbg = 0;                    // knobs of the -DFMD_EXPERIMENT build (fmd_host.h), read at creation
+    bool swz = false;
     int32_t mre[2] = {0, 0}, mim[2] = {0, 0};
     uint32_t* d_hist[2] = {nullptr, nullptr};
     int cur = 0;
@@ -400,11 +400,9 @@ int fir_enqueue(fmd_fir* f, const void* d_iq, size_t nbytes, void* d_out, size_t
     if (ot > 1024) ot = 1024;
     if (ot < 1) ot = 1;
     L.out_tile = (uint32_t)ot;
-#ifdef FMD_EXPERIMENT
-    { const char* e = getenv("FMD_DBG"); L.dbg = e ? (uint32_t)atoi(e) : 0u; }
-#endif
+    L.dbg = f->dbg;
     if (n_out && f->n_pass) {
-        { const char* ex = getenv("FMD_XCD"); L.xcd_swizzle = ex ? (uint32_t)atoi(ex) : 2u; }      // 0 = plain mapping (tuning)
+        L.xcd_swizzle = f->xcd_swizzle;                                                            // 0 = plain mapping (tuning)
         L.amat = f->d_amat; L.n_pass = f->n_pass; L.nku = f->nku; L.groups = f->groups; L.col_bytes = 8u * f->M;
         L.mre[0] = f->mre[0]; L.mre[1] = f->mre[1]; L.mim[0] = f->mim[0]; L.mim[1] = f->mim[1];
         L.out_tile = 64u * f->groups;
@@ -417,14 +415,14 @@ int fir_enqueue(fmd_fir* f, const void* d_iq, size_t nbytes, void* d_out, size_t
         const uint32_t per = (f->C + 7u) / 8u;                      // XCD-aware grid without index arithmetic
         if (L.xcd_swizzle && f->C >= 8u && g.x <= 65535u && per <= 65535u) { g = dim3(8u, g.x, per); L.xcd_swizzle = 3u; }
         switch (f->nku) {
-            case 1: launch_mfma<1>(L, g, lds, stream); break;
-            case 2: launch_mfma<2>(L, g, lds, stream); break;
-            case 3: launch_mfma<3>(L, g, lds, stream); break;
-            case 4: launch_mfma<4>(L, g, lds, stream); break;
-            case 5: launch_mfma<5>(L, g, lds, stream); break;
-            case 6: launch_mfma<6>(L, g, lds, stream); break;
-            case 7: launch_mfma<7>(L, g, lds, stream); break;
-            default: launch_mfma<8>(L, g, lds, stream); break;
+            case 1: launch_mfma<1>(L, g, lds, stream, f->swz); break;
+            case 2: launch_mfma<2>(L, g, lds, stream, f->swz); break;
+            case 3: launch_mfma<3>(L, g, lds, stream, f->swz); break;
+            case 4: launch_mfma<4>(L, g, lds, stream, f->swz); break;
+            case 5: launch_mfma<5>(L, g, lds, stream, f->swz); break;
+            case 6: launch_mfma<6>(L, g, lds, stream, f->swz); break;
+            case 7: launch_mfma<7>(L, g, lds, stream, f->swz); break;
+            default: launch_mfma<8>(L, g, lds, stream, f->swz); break;
         }
         FIR_TRY(hipGetLastError());
     } else if (n_out) {
@@ -499,13 +497,17 @@ int fmd_fir_new(const int16_t* taps, uint32_t n_taps, uint32_t decim, const fmd_
     // MFMA form: see the header comment.  Rows r = 4*i + reg (reg: re_lo, re_hi, im_lo, im_hi), K index = byte
     // offset v from the window start of output i = 0; fragment order [chunk][lane = row + 16*q][16 bytes].
     std::vector<uint32_t> amat;
-    const char* env_mfma = getenv("FMD_FIR_MFMA");
+    // knobs: -DFMD_EXPERIMENT builds only (fmd_host.h); constants in the shipped library
+    const char* env_mfma = fmd_knob("FMD_FIR_MFMA");
+    f->xcd_swizzle = fmd_knob_u32("FMD_XCD", 2);
+    f->dbg = fmd_knob_u32("FMD_DBG", 0);
+    f->swz = fmd_knob_u32("FMD_FIR_SWZ", 0) == 1u;
     FmdFirMfmaPlan plan;
     if (!(env_mfma && env_mfma[0] == '0') && fmd_fir_build_mfma(taps, n_taps, decim, plan)) {
         f->n_pass = plan.n_pass; f->nku = plan.nku;
         uint32_t groups = 16384u / (128u * decim);
         f->groups = groups < 1u ? 1u : (groups > 16u ? 16u : groups);
-        if (const char* eg = getenv("FMD_FIR_GROUPS")) { const uint32_t g = (uint32_t)atoi(eg); if (g >= 1 && g <= 4u * kFirGroupsPerWave) f->groups = g; }   // tuning
+        if (const char* eg = fmd_knob("FMD_FIR_GROUPS")) { const uint32_t g = (uint32_t)atoi(eg); if (g >= 1 && g <= 4u * kFirGroupsPerWave) f->groups = g; }   // tuning
         amat.swap(plan.amat);
         for (int par = 0; par < 2; ++par) { f->mre[par] = plan.mre[par]; f->mim[par] = plan.mim[par]; }
     }

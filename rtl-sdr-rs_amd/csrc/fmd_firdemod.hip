@@ -431,6 +431,7 @@ struct fmd_firdemod {
     uint32_t seq = 0;
     uint64_t f64_guarded = 0, f64_patched = 0;
     FmdStreamOrder order;
+    uint32_t dbg = 0;                                     // ablation bits (FMD_DBG, experiment build)
     bool no_rows = false;                                 // FMD_FD_ROWS=0: geometry on the device (A/B)
     bool no_reuse = false, int_disc = false;              // FMD_FD_NOREUSE / FMD_FD_INT_DISC: plain MFMA mapping / integer discriminator (A/B), read at creation
     size_t lds_budget = 20480;                            // LDS per tile (8 tiles per CU); FMD_FD_LDS (tuning)
@@ -517,9 +518,7 @@ int fd_enqueue(fmd_firdemod* f, const void* d_iq, size_t nbytes, void* d_out, si
     L.st_in = f->d_state[f->cur]; L.st_out = f->d_state[f->cur ^ 1];
     L.out = static_cast<int16_t*>(d_out); L.out_stride = out_cap;
     L.exc = f->d_exc; L.f64_guard = f->f64_guard; L.seq = f->seq + 1; L.f64_skew = f->f64_skew;
-#ifdef FMD_EXPERIMENT
-    { const char* e = getenv("FMD_DBG"); L.dbg = e ? (uint32_t)atoi(e) : 0u; }
-#endif
+    L.dbg = f->dbg;
     fd_lanes(L.fa, r.kt, &L.lg, &L.lg_magic, &L.ch);
     L.reuse = f->M == 8u && f->plan.n_pass == 1u && !f->no_reuse ? 1u : 0u;
     L.f32_disc = f->lp_bound <= 2048u && !f->int_disc ? 1u : 0u;
@@ -621,12 +620,13 @@ int fmd_firdemod_new(const int16_t* taps, uint32_t n_taps, uint32_t decim, uint3
     }
     // tiling: the most audio samples per tile that fit (<= 1024 filter outputs, ~20 KB of LDS -> 8 tiles per CU)
     uint32_t best = 0; size_t lds = 0;
-    uint32_t kt_env = 0;
-    if (const char* e = getenv("FMD_FD_KT")) kt_env = (uint32_t)atoi(e);
-    if (const char* e = getenv("FMD_FD_LDS")) f->lds_budget = (size_t)atoi(e);
-    if (const char* e = getenv("FMD_FD_ROWS")) f->no_rows = e[0] == '0';
-    f->no_reuse = getenv("FMD_FD_NOREUSE") != nullptr;
-    f->int_disc = getenv("FMD_FD_INT_DISC") != nullptr;
+    // knobs: -DFMD_EXPERIMENT builds only (fmd_host.h); constants in the shipped library
+    const uint32_t kt_env = fmd_knob_u32("FMD_FD_KT", 0);
+    f->lds_budget = (size_t)fmd_knob_u32("FMD_FD_LDS", (uint32_t)f->lds_budget);
+    f->no_rows = fmd_knob_u32("FMD_FD_ROWS", 1) == 0u;
+    f->no_reuse = fmd_knob("FMD_FD_NOREUSE") != nullptr;
+    f->int_disc = fmd_knob("FMD_FD_INT_DISC") != nullptr;
+    f->dbg = fmd_knob_u32("FMD_DBG", 0);
     for (uint32_t kt = 1; kt <= 1024; ++kt) {
         if ((uint64_t)r.sr * (kt + 2) >= (1u << 24)) break;
         uint32_t lc, rb; size_t l;
@@ -638,8 +638,8 @@ int fmd_firdemod_new(const int16_t* taps, uint32_t n_taps, uint32_t decim, uint3
     if (!best) { delete f; fmd_internal_set_err("one audio sample does not fit a tile: rate_out / rate_resample x decim too large"); return FMD_ERR_UNSUPPORTED; }
     r.kt = best;
     if (!fd_sizes(f, r.kt, &f->lp_cap, &f->raw_bytes, &lds)) { delete f; return FMD_ERR_UNSUPPORTED; }
-    if (const char* g = getenv("FMD_F64_GUARD_LOG2")) { if (*g) f->f64_guard = ldexp(1.0, atoi(g)); }
-    if (const char* g = getenv("FMD_F64_SKEW")) f->f64_skew = atoi(g);
+    if (const char* g = fmd_knob("FMD_F64_GUARD_LOG2")) f->f64_guard = ldexp(1.0, atoi(g));   // experiment build only
+    f->f64_skew = fmd_knob_i32("FMD_F64_SKEW", 0);
 
     auto fail = [&](const char* what) { fmd_internal_set_err(what); fmd_firdemod_free(f); return FMD_ERR_HIP; };
     FmdDeviceGuard guard(device);

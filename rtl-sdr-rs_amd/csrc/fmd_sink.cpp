@@ -82,6 +82,8 @@ struct fmd_sink {
     fmd_sink_callback cb = nullptr;
     void* user = nullptr;
     int acquired = -1;
+    int poisoned = FMD_OK;                // first error of a submit that had already touched a device: terminal (see fmd_sink_submit)
+    char poison_msg[256] = "";
 };
 
 namespace {
@@ -222,6 +224,7 @@ void fmd_sink_free(fmd_sink* s)
 int fmd_sink_acquire(fmd_sink* s, uint8_t** iq)
 {
     if (!s || !iq) { fmd_internal_set_err("null argument"); return FMD_ERR_INVALID_ARG; }
+    if (s->poisoned != FMD_OK) { fmd_internal_set_err(s->poison_msg); return s->poisoned; }
     if (s->acquired >= 0) { fmd_internal_set_err("a slot is already acquired: submit it first"); return FMD_ERR_INVALID_ARG; }
     // deliver whatever has finished; if the ring is full, wait for the oldest launch
     for (;;) {
@@ -236,15 +239,28 @@ int fmd_sink_acquire(fmd_sink* s, uint8_t** iq)
     return FMD_OK;
 }
 
-int fmd_sink_submit(fmd_sink* s)
+// Give an acquired slot back without submitting it (a short read ends the run, simple_fm.rs:122-125): the sink stays usable.
+int fmd_sink_release(fmd_sink* s)
 {
-    if (!s || s->acquired < 0) { fmd_internal_set_err("no slot acquired"); return FMD_ERR_INVALID_ARG; }
-    Slot& sl = s->slots[(size_t)s->acquired];
-    for (size_t k = 0; k < s->parts.size(); ++k) {
-        DevPart& p = s->parts[k];
-        SlotDev& sd = sl.dev[k];
-        FmdDeviceGuard guard(p.device);
-        const size_t nc = p.hi - p.lo;
+    if (!s) { fmd_internal_set_err("null argument"); return FMD_ERR_INVALID_ARG; }
+    if (s->acquired < 0) { fmd_internal_set_err("no slot acquired"); return FMD_ERR_INVALID_ARG; }
+    s->slots[(size_t)s->acquired].state = 0;
+    s->acquired = -1;
+    return FMD_OK;
+}
+
+}  // extern "C"
+
+namespace {
+
+// One device part of a submit.  Returns the first error; everything before it stays enqueued.
+int submit_part(fmd_sink* s, Slot& sl, size_t k)
+{
+    DevPart& p = s->parts[k];
+    SlotDev& sd = sl.dev[k];
+    FmdDeviceGuard guard(p.device);
+    const size_t nc = p.hi - p.lo;
+    {
         SK_TRY(hipMemcpyAsync(sd.d_iq, sl.h_iq + (size_t)p.lo * s->nbytes, s->nbytes * nc, hipMemcpyHostToDevice, p.s_in));
         SK_TRY(hipEventRecord(sd.e_in, p.s_in));
         SK_TRY(hipStreamWaitEvent(p.s_k, sd.e_in, 0));
@@ -258,8 +274,36 @@ int fmd_sink_submit(fmd_sink* s)
         SK_TRY(hipMemcpyAsync(sl.h_out + (size_t)p.lo * s->out_cap, sd.d_out, s->out_cap * nc * sizeof(int16_t), hipMemcpyDeviceToHost, p.s_out));
         SK_TRY(hipMemcpyAsync(sd.h_head, sd.d_exc, 16, hipMemcpyDeviceToHost, p.s_out));
         SK_TRY(hipEventRecord(sd.e_done, p.s_out));
-        const int rl = fmd_demod_last_out_len(p.demod, sl.out_len.data() + p.lo);
-        if (rl != FMD_OK) return rl;
+    }
+    return fmd_demod_last_out_len(p.demod, sl.out_len.data() + p.lo);
+}
+
+}  // namespace
+
+extern "C" {
+
+// A submit is all-or-nothing per buffer only up to its first enqueue: once one device part has advanced its Demod state
+// (or a copy out of the page-locked slot is in flight), a failure on a later part cannot be rolled back -- feeding the
+// buffer again would run it through part 0 twice and the audio would silently diverge from the reference's.  Such a
+// failure is therefore TERMINAL for the sink: everything already enqueued is waited for (so the caller may reuse the
+// slot's memory), the slot is dropped, and this and every later acquire / submit return the same error; poll / drain
+// still deliver the buffers submitted before it, then return it too.  fmd_sink_free is the only way on.
+int fmd_sink_submit(fmd_sink* s)
+{
+    if (!s) { fmd_internal_set_err("null argument"); return FMD_ERR_INVALID_ARG; }
+    if (s->poisoned != FMD_OK) { fmd_internal_set_err(s->poison_msg); return s->poisoned; }
+    if (s->acquired < 0) { fmd_internal_set_err("no slot acquired"); return FMD_ERR_INVALID_ARG; }
+    Slot& sl = s->slots[(size_t)s->acquired];
+    for (size_t k = 0; k < s->parts.size(); ++k) {
+        const int rc = submit_part(s, sl, k);
+        if (rc == FMD_OK) continue;
+        snprintf(s->poison_msg, sizeof s->poison_msg, "sink failed in submit (device part %zu of %zu): %s", k, s->parts.size(), fmd_last_error());
+        for (DevPart& p : s->parts) { FmdDeviceGuard guard(p.device); (void)hipDeviceSynchronize(); }   // nothing reads the slot any more
+        s->poisoned = rc;
+        sl.state = 0;
+        s->acquired = -1;
+        fmd_internal_set_err(s->poison_msg);
+        return rc;
     }
     sl.seq = s->next_seq++;
     sl.state = 2;
@@ -279,6 +323,7 @@ int fmd_sink_poll(fmd_sink* s)
         if (r == 0) break;
         ++n;
     }
+    if (s->poisoned != FMD_OK && s->in_flight == 0) { fmd_internal_set_err(s->poison_msg); return s->poisoned; }
     return n;
 }
 
@@ -289,6 +334,7 @@ int fmd_sink_drain(fmd_sink* s)
         const int r = complete_oldest(s, true);
         if (r < 0) return r;
     }
+    if (s->poisoned != FMD_OK) { fmd_internal_set_err(s->poison_msg); return s->poisoned; }
     return FMD_OK;
 }
 

@@ -779,8 +779,10 @@ template <int DH>
 void launch_one(const FmdLaunch& L, dim3 g, size_t lds, hipStream_t stream)
 {
     switch (L.block_threads) {
+#ifdef FMD_EXPERIMENT                                        // 64- / 128-thread blocks (FMD_NT): measured equal or slower, kept for A/B only
         case 128: hipLaunchKernelGGL((fmd_demod_tile_kernel<DH, 128, 0>), g, dim3(128), lds, stream, L); break;
         case 64: hipLaunchKernelGGL((fmd_demod_tile_kernel<DH, 64, 0>), g, dim3(64), lds, stream, L); break;
+#endif
         default:
             if (L.fast == 1u) hipLaunchKernelGGL((fmd_demod_tile_kernel<DH, 256, 1>), g, dim3(256), lds, stream, L);
             else if (L.fast == 2u) hipLaunchKernelGGL((fmd_demod_tile_kernel<DH, 256, 2>), g, dim3(256), lds, stream, L);

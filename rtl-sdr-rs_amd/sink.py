@@ -14,15 +14,22 @@ class Sink:
         self.n_channels, self.nbytes = int(n_channels), int(nbytes)
         self.on_audio = on_audio
         self.results = []                                   # (seq, [arrays], status) when no callback is given
+        self._pending_exc = None                            # first exception raised by on_audio inside the C callback
 
         def _cb(user, seq, audio, out_len, out_cap, status):
-            lens = [out_len[c] for c in range(self.n_channels)]
-            flat = np.ctypeslib.as_array(audio, shape=(self.n_channels, out_cap))
-            rows = [flat[c, :lens[c]].copy() for c in range(self.n_channels)]
-            if self.on_audio:
-                self.on_audio(seq, rows, status)
-            else:
-                self.results.append((seq, rows, status))
+            # ctypes prints and swallows an exception that escapes a callback: a failing consumer would not stop
+            # push / pump / drain.  Keep the first one and re-raise it from the call that delivered the buffer.
+            try:
+                lens = [out_len[c] for c in range(self.n_channels)]
+                flat = np.ctypeslib.as_array(audio, shape=(self.n_channels, out_cap))
+                rows = [flat[c, :lens[c]].copy() for c in range(self.n_channels)]
+                if self.on_audio:
+                    self.on_audio(seq, rows, status)
+                else:
+                    self.results.append((seq, rows, status))
+            except BaseException as e:                      # noqa: BLE001 -- re-raised by _reraise()
+                if self._pending_exc is None:
+                    self._pending_exc = e
 
         self._cb = SINK_CALLBACK(_cb)                       # keep alive
         ids = (C.c_int32 * len(device_ids))(*device_ids)
@@ -37,15 +44,28 @@ class Sink:
 
     __del__ = close
 
+    def _reraise(self):
+        if self._pending_exc is not None:
+            e, self._pending_exc = self._pending_exc, None
+            raise e
+
     def acquire(self):
         """The next slot as a writable uint8 array [n_channels, nbytes] (page-locked memory owned by the sink)."""
         p = C.c_void_p()
-        check(lib().fmd_sink_acquire(self._h, C.byref(p)))
+        rc = lib().fmd_sink_acquire(self._h, C.byref(p))
+        if rc == 0 and self._pending_exc is not None:       # a completion delivered inside acquire failed in on_audio
+            lib().fmd_sink_release(self._h)
+        self._reraise()
+        check(rc)
         raw = (C.c_uint8 * (self.n_channels * self.nbytes)).from_address(p.value)
         return np.frombuffer(raw, dtype=np.uint8).reshape(self.n_channels, self.nbytes)
 
     def submit(self):
         check(lib().fmd_sink_submit(self._h))
+
+    def release(self):
+        """Give the acquired slot back without submitting it (fmd_sink_release): the sink stays usable."""
+        check(lib().fmd_sink_release(self._h))
 
     def push(self, iq):
         """acquire + copy + submit: what receive() does with a freshly read buffer (simple_fm.rs:114-127)."""
@@ -54,12 +74,15 @@ class Sink:
 
     def poll(self):
         n = lib().fmd_sink_poll(self._h)
+        self._reraise()
         if n < 0:
             check(n)
         return n
 
     def drain(self):
-        check(lib().fmd_sink_drain(self._h))
+        rc = lib().fmd_sink_drain(self._h)
+        self._reraise()
+        check(rc)
 
     def info(self):
         cap, nd, fl = C.c_size_t(), C.c_uint32(), C.c_uint32()
@@ -79,9 +102,9 @@ def pump(sources, sink, max_buffers=None):
     while max_buffers is None or n < max_buffers:
         slot = sink.acquire()
         if any(src.read_sync(slot[c]) < sink.nbytes for c, src in enumerate(sources)):
+            sink.release()                                  # the sink stays usable after a short read
             break
         sink.submit()
         n += 1
-    # an acquired but unsubmitted slot is simply dropped with the sink; everything submitted is delivered
-    sink.drain()
+    sink.drain()                                            # everything submitted is delivered
     return n

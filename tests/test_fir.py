@@ -8,6 +8,7 @@ import numpy as np
 import pytest
 
 import oracle_lib
+from conftest import run_in_exp_child
 
 
 def rotated_stream(oracle, data):
@@ -65,13 +66,18 @@ def test_oracle_fir_equals_numpy_convolution(oracle, T, M):
 @pytest.mark.parametrize("form", ["mfma", "mfma_swz", "valu"])
 @pytest.mark.parametrize("T,M", [(127, 8), (6, 6), (10, 10), (5, 2), (16, 16), (33, 4), (1, 2), (64, 6), (255, 32),
                                  (300, 8), (1024, 2), (129, 64), (77, 66), (31, 128)])
-def test_gpu_fir_matches_oracle(fmd, oracle, monkeypatch, form, T, M):
-    """Both kernel forms (matrix-core form = default for decim <= 64; FMD_FIR_MFMA=0 forces the VALU form),
-    streaming over ragged calls; shapes cover one and several K passes, both window parities, decim > 64."""
-    if form == "valu":
-        monkeypatch.setenv("FMD_FIR_MFMA", "0")
+def test_gpu_fir_matches_oracle(fmd, oracle, request, form, T, M):
+    """Both kernel forms (matrix-core form = default for decim <= 64, VALU form beyond), streaming over ragged calls;
+    shapes cover one and several K passes, both window parities, decim > 64.  Forcing the VALU form for small decim
+    (FMD_FIR_MFMA=0) and the conflict-free LDS layout (FMD_FIR_SWZ=1) are knobs of the -DFMD_EXPERIMENT build: those
+    cases re-run themselves in a child process on that library."""
+    if form == "valu" and M <= 64 and run_in_exp_child(request, {"FMD_FIR_MFMA": "0"}):
+        return
     if form == "mfma_swz":                                        # conflict-free LDS layout (decim 8 only; off by default)
-        monkeypatch.setenv("FMD_FIR_SWZ", "1")
+        if M != 8:
+            pytest.skip("the swizzled layout exists for decim 8 only")
+        if run_in_exp_child(request, {"FMD_FIR_SWZ": "1"}):
+            return
     rng = np.random.default_rng(T * 7 + M)
     taps = np.ones(T, np.int16) if T == M else rng.integers(-2047, 2048, T).astype(np.int16)
     nch = 5

@@ -1,8 +1,9 @@
 """The one f64 sample of every reference call (Demod::polar_discriminant, simple_fm.rs:359,370-374) must not
 depend on the last bits of the GPU's atan2: exact directions are decided with integers, every other sample within
 the guard band of an integer is re-evaluated by the host libm and patched (include/fmd.h, fmd_demod_check).
-Here the guard band is widened until EVERY generic sample takes that path (FMD_F64_GUARD_LOG2=-1: half-width 0.5),
-and the -DFMD_EXPERIMENT build additionally makes the kernel's own value wrong on purpose (FMD_F64_SKEW) so that
+Here the guard band is widened until EVERY generic sample takes that path (FMD_F64_GUARD_LOG2=-1: half-width 0.5)
+and the kernel's own value is made wrong on purpose (FMD_F64_SKEW) -- both knobs of the -DFMD_EXPERIMENT build only; the
+shipped library's band is fixed at 2^-20 (test_default_guard_band_is_quiet runs on it) -- so that
 the results can only be right if the host patch works -- in the audio sample, in the carried partial sum, through
 the host and the device entry points, and with several reference calls per launch."""
 import json
@@ -19,11 +20,13 @@ EXP = os.path.join(ROOT, "rtl-sdr-rs_amd", "libfmd_hip_exp.so")
 
 def run_child(args, guard_log2=None, skew=None):
     env = dict(os.environ, PYTHONPATH=ROOT)
+    if guard_log2 is not None or skew is not None:
+        # both knobs exist in the -DFMD_EXPERIMENT build only: the shipped library's guard band is 2^-20, fixed
+        assert os.path.exists(EXP), "build() makes libfmd_hip_exp.so (make -C rtl-sdr-rs_amd/csrc exp)"
+        env["FMD_LIB"] = EXP
     if guard_log2 is not None:
         env["FMD_F64_GUARD_LOG2"] = str(guard_log2)
     if skew is not None:
-        assert os.path.exists(EXP), "build() makes libfmd_hip_exp.so (make -C rtl-sdr-rs_amd/csrc exp)"
-        env["FMD_LIB"] = EXP
         env["FMD_F64_SKEW"] = str(skew)
     p = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "f64_child.py")] + [str(a) for a in args],
                        capture_output=True, env=env, timeout=600)
@@ -69,3 +72,15 @@ def test_fused_fir_kernel_guard_and_patch():
     r = run_child(["firdemod"], guard_log2=-1, skew=7)
     assert r["bad"] == 0 and r["state_bad"] == 0
     assert r["stats"]["guarded"] > 50 and r["stats"]["patched"] == r["stats"]["guarded"]
+
+
+@pytest.mark.parametrize("D,fast,slow", [(6, 170000, 32000), (4, 48000, 48000)])
+def test_sink_settles_guarded_samples_in_its_host_copy(D, fast, slow):
+    """nothing exercised the sink's settle path (per-slot report buffer, host_out row offset of the device
+    part, launch_seq of a slot that is no longer the newest launch).  With every f64 sample guarded AND wrong on the
+    device, 9 buffers through 2 device parts and a ring of 3 are only right if each was patched in the slot's host copy.
+    Run once without the skew too: then nothing needs a patch and the path must leave the audio alone."""
+    r = run_child(["sink", D, fast, slow], guard_log2=-1)
+    assert r["bad"] == 0
+    r = run_child(["sink", D, fast, slow], guard_log2=-1, skew=9)
+    assert r["bad"] == 0

@@ -12,6 +12,7 @@ import numpy as np
 import pytest
 
 import oracle_lib
+from conftest import run_in_exp_child
 
 pytestmark = pytest.mark.gpu
 
@@ -304,6 +305,50 @@ def test_full_size_config3_exact(fmd, oracle):
     assert gpu_state(bank, 4095) == oracle.state_of(obank[4095])
 
 
+def test_config5_shape_on_one_gpu(fmd, oracle):
+    """BASELINE configs[4] (32768 channels over 8 GPUs, 4096 each) as far as ONE GPU can show it: for every rank r of the
+    8-GPU job, the rank's channel range, its input seeded exactly as bench.py seeds it (base seed + first global channel
+    id) and the full 4096-channel x 262144 B launch; >= 64 channels per rank (first, last, strided) must equal the oracle
+    fed the stream that global channel has in the 8-GPU job, and different ranks must produce different audio (one Demod per stream,
+    simple_fm.rs:137: rank r's channels are not rank 0's)."""
+    import torch
+    world, per = 8, 4096
+    N = fmd.DEFAULT_BUF_LENGTH
+    base_seed = fmd.synth.DEFAULTS["seed"]
+    cfg = mkcfg(fmd, *CFG_24)
+    iq = torch.empty((per, N), dtype=torch.uint8, device="cuda")
+    stream = torch.cuda.current_stream().cuda_stream
+    first_audio = []
+    for r in range(world):
+        lo, hi = fmd.shard.channel_range(world * per, world, r)
+        assert (lo, hi) == (r * per, (r + 1) * per)
+        fmd.synth.fill_device(iq.data_ptr(), per, N, sample_offset=0, stream=stream, seed=base_seed + lo)   # bench.py's seeding
+        bank = fmd.DemodBank(cfg, per)
+        cap = bank.out_cap(N)
+        out = torch.zeros((per, cap), dtype=torch.int16, device="cuda")
+        bank.demodulate_device(iq.data_ptr(), N, out.data_ptr(), cap, None, stream)
+        bank.check()
+        lens = bank.last_out_len()
+        picks = sorted(set([0, 1, per - 2, per - 1] + list(range(0, per, 67))))
+        assert len(picks) >= 64
+        got = out[picks].cpu().numpy()
+        # the oracle sees the stream global channel lo + c has in the 8-GPU job (seed = base + lo, row c -- bench.py's
+        # seeding), generated independently on the host by the numpy generator
+        host = np.concatenate([fmd.synth.synth_iq(1, N, seed=base_seed + lo, first_channel=c) for c in picks])
+        assert np.array_equal(host, iq[picks].cpu().numpy())                 # device generator == host generator
+        obank = oracle.new_bank(oracle.config(*CFG_24), len(picks))
+        exp, elens = oracle.demodulate_batch(obank, host)
+        for j, c in enumerate(picks):
+            assert lens[c] == elens[j]
+            assert np.array_equal(got[j, :elens[j]], exp[j, :elens[j]]), (r, c)
+        assert gpu_state(bank, per - 1) == oracle.state_of(obank[len(picks) - 1])
+        first_audio.append(got[0, :elens[0]].copy())
+        bank.close()
+        del out
+    for r in range(1, world):
+        assert not np.array_equal(first_audio[r], first_audio[0]), r
+
+
 def test_large_single_channel_call(fmd, oracle):
     """Config 2 throughput shape: one channel, 16 MiB in one call (time-tiled inside the channel)."""
     N = 16 << 20
@@ -312,10 +357,12 @@ def test_large_single_channel_call(fmd, oracle):
     check_stream(fmd, oracle, *CFG_24, [data[None, :]])
 
 
-def test_generic_kernel_forced(fmd, oracle, monkeypatch):
-    """The fallback kernel (in-kernel index divisions; used for > 4 phase classes, tilings that are
-    not a multiple of the reduced resample rate, downsample > 64) stays bit-exact too."""
-    monkeypatch.setenv("FMD_FORCE_GENERIC", "1")
+def test_generic_kernel_forced(fmd, oracle, request):
+    """The fallback kernel (in-kernel index divisions; what the library itself takes for > 16 phase classes -- see
+    test_phase_classes[23] -- and extreme rate ratios) stays bit-exact on ordinary streams too.  Forcing it is a knob of
+    the -DFMD_EXPERIMENT build: the case re-runs itself there."""
+    if run_in_exp_child(request, {"FMD_FORCE_GENERIC": "1"}):
+        return
     rng = np.random.default_rng(31)
     blocks = [rng.integers(0, 256, (6, 65536), dtype=np.uint8) for _ in range(3)]
     check_stream(fmd, oracle, *CFG_24, blocks, n_channels=6)
@@ -356,13 +403,13 @@ def test_phase_classes(fmd, oracle, nclasses):
 
 
 @pytest.mark.parametrize("force_generic", [False, True])
-def test_more_than_65535_channels(fmd, oracle, monkeypatch, force_generic):
+def test_more_than_65535_channels(fmd, oracle, request, force_generic):
     """Maximum-size edge: 70 001 channels in one bank (beyond one grid dimension), two small calls; a strided
     sample of channels incl. both sides of the 65535 boundary and the last one is compared with the oracle, and
     every channel that was given channel 5's input must reproduce channel 5's audio."""
     import torch
-    if force_generic:
-        monkeypatch.setenv("FMD_FORCE_GENERIC", "1")
+    if force_generic and run_in_exp_child(request, {"FMD_FORCE_GENERIC": "1"}):
+        return
     nch, N = 70001, 4096
     cfg = mkcfg(fmd, *CFG_24)
     bank = fmd.DemodBank(cfg, nch)

@@ -1,11 +1,13 @@
-"""GPU parity of the non-default kernel variants (same results by construction, selected by environment at
-Demod creation): 64/128-thread tile blocks (FMD_NT), the plain and index-arithmetic block mappings (FMD_XCD), the general and
-the table-driven prologue (FMD_FAST=0: general prologue, 1: closed-form geometry; the default prefers the per-tile table),
-the generic fallback kernel (FMD_FORCE_GENERIC).  The register-streaming and persistent kernels of round 1
-(measured slower) were removed in round 2."""
+"""GPU parity of the non-default kernel variants (same results by construction): 64/128-thread tile blocks (FMD_NT),
+the plain and index-arithmetic block mappings (FMD_XCD), the general and the closed-form prologue (FMD_FAST=0 / 1; the
+default prefers the per-tile table), the generic fallback kernel (FMD_FORCE_GENERIC).  These knobs exist in the
+-DFMD_EXPERIMENT build only -- the shipped library reads no environment variable -- so every case re-runs itself in a
+child process on libfmd_hip_exp.so (conftest.run_in_exp_child).  What the shipped library selects by itself (general
+prologue for several phase classes, generic kernel beyond 16 of them) is covered in tests/test_gpu_parity.py."""
 import numpy as np
 import pytest
 
+from conftest import run_in_exp_child
 from test_gpu_parity import CFG_24, CFG_REF, check_stream
 
 pytestmark = pytest.mark.gpu
@@ -25,9 +27,21 @@ def blocks_for(fmd, nch, ncalls, seed, n=None):
 
 @pytest.mark.parametrize("env", [{"FMD_NT": "128"}, {"FMD_NT": "64"}, {"FMD_XCD": "0"}, {"FMD_XCD": "1"}, {"FMD_FAST": "0"}, {"FMD_FAST": "1"},
                                  {"FMD_FORCE_GENERIC": "1"}])
-@pytest.mark.parametrize("cfg", [CFG_24, CFG_REF, (4, 300000, 50000), (16, 62500, 31250)])
-def test_kernel_variants_bit_exact(fmd, oracle, monkeypatch, env, cfg):
-    for k, v in env.items():
+def test_kernel_variants_bit_exact(fmd, oracle, request, env):
+    if run_in_exp_child(request, env):
+        return
+    for cfg in [CFG_24, CFG_REF, (4, 300000, 50000), (16, 62500, 31250)]:
+        check_stream(fmd, oracle, *cfg, blocks_for(fmd, 7, 3, seed=cfg[0]), n_channels=7)
+        check_stream(fmd, oracle, *cfg, blocks_for(fmd, 3, 3, seed=cfg[0] + 1, n=8 * 517), n_channels=3)   # ragged small calls
+
+
+def test_shipped_library_ignores_the_knobs(fmd, monkeypatch):
+    """The release build must not let a stray variable swap the kernel or the tiling."""
+    import os
+    if os.environ.get("FMD_LIB"):
+        pytest.skip("a tuning build is loaded")
+    from test_gpu_parity import mkcfg
+    ref = fmd.DemodBank(mkcfg(fmd, *CFG_24), 16).tiling()
+    for k, v in {"FMD_NT": "64", "FMD_KT": "7", "FMD_FORCE_GENERIC": "1", "FMD_F64_GUARD_LOG2": "-1"}.items():
         monkeypatch.setenv(k, v)
-    check_stream(fmd, oracle, *cfg, blocks_for(fmd, 7, 3, seed=cfg[0]), n_channels=7)
-    check_stream(fmd, oracle, *cfg, blocks_for(fmd, 3, 3, seed=cfg[0] + 1, n=8 * 517), n_channels=3)   # ragged small calls
+    assert fmd.DemodBank(mkcfg(fmd, *CFG_24), 16).tiling() == ref

@@ -77,6 +77,24 @@ def test_missing_library_is_an_error_not_a_fallback():
     assert p.returncode == 0 and b"IMPORTERROR" in p.stdout and b"no CPU fallback" in p.stdout.replace(b"There is ", b"")
 
 
+def test_shipped_library_reads_no_environment():
+    """Tuning / test knobs (kernel variants, the f64 guard band, ablation bits) live in the -DFMD_EXPERIMENT build
+    only: the shipped library must not even import getenv, and the sources may call it in one guarded place."""
+    so = os.path.join(ROOT, "rtl-sdr-rs_amd", "libfmd_hip.so")
+    syms = subprocess.run(["nm", "-D", "--undefined-only", so], capture_output=True, check=True).stdout.decode()
+    assert "getenv" not in syms
+    csrc = os.path.join(ROOT, "rtl-sdr-rs_amd", "csrc")
+    hits = []
+    for f in sorted(os.listdir(csrc)):
+        if f.endswith((".hip", ".cpp", ".h", ".hpp")):
+            for i, line in enumerate(open(os.path.join(csrc, f)), 1):
+                if "getenv(" in line and not line.lstrip().startswith("//"):
+                    hits.append((f, i))
+    assert [h[0] for h in hits] == ["fmd_host.h"], hits          # fmd_knob(), inside #ifdef FMD_EXPERIMENT
+    host = open(os.path.join(csrc, "fmd_host.h")).read()
+    assert host.index("#ifdef FMD_EXPERIMENT") < host.index("getenv(") < host.index("#else")
+
+
 def test_synth_is_deterministic_and_channel_offsettable(fmd):
     a = fmd.synth.synth_iq(3, 2048, sample_offset=1000)
     b = fmd.synth.synth_iq(3, 2048, sample_offset=1000)
