@@ -18,6 +18,7 @@
 #include <utility>
 #include <vector>
 
+#include "fmd_boxcar_mfma.h"
 #include "fmd_host.h"
 #include "fmd_index.h"
 #include "fmd_internal.h"
@@ -86,6 +87,7 @@ struct fmd_demod {
     FmdStreamOrder order;                 // cross-stream ordering of consecutive launches (fmd_host.h)
     std::vector<PhaseClass> classes;      // host mirror of the phases
     std::vector<uint32_t> chan_class;     // [C] index into classes
+    uint32_t* d_bx_amat = nullptr;        // matrix-core boxcar: A fragments (fmd_boxcar_mfma.h), even downsample <= 14
     uint8_t* d_chan_class = nullptr;      // device copy, valid while 1 < classes <= FMD_MAX_CLASSES
     bool d_chan_class_dirty = true;
     hipStream_t stream = nullptr;         // used by the host-buffer entry points
@@ -284,6 +286,7 @@ int enqueue(fmd_demod* d, const void* d_iq, size_t nbytes, void* d_out, size_t o
             L.chan_class = d->d_chan_class;
         }
         L.block_threads = d->block_threads;
+        L.bx_amat = d->d_bx_amat;
         L.fast = d->allow_fast;               // fmd_launch_tile decides (fmd_fast_geometry)
         HIP_TRY(fmd_launch_tile(L, stream));
     } else {
@@ -523,6 +526,11 @@ int fmd_demod_new(const fmd_demod_config* config, const fmd_device_config* dev, 
         if ((e = hipMalloc(&d->d_state[i], sbytes)) != hipSuccess) return fail(e, "hipMalloc(state)");
         if ((e = hipMemset(d->d_state[i], 0, sbytes)) != hipSuccess) return fail(e, "hipMemset(state)");
     }
+    if ((config->downsample & 1u) == 0u && config->downsample / 2u <= FMD_BX_MAX_DH && fmd_knob_u32("FMD_BX_MFMA", 0) != 0u) {   // experiment build only: measured slower than the v_dot4 form
+        const std::vector<uint32_t> amat = fmd_bx_build_amat(config->downsample / 2u);
+        if ((e = hipMalloc(&d->d_bx_amat, amat.size() * 4)) != hipSuccess) return fail(e, "hipMalloc(boxcar matrix)");
+        if ((e = hipMemcpy(d->d_bx_amat, amat.data(), amat.size() * 4, hipMemcpyHostToDevice)) != hipSuccess) return fail(e, "hipMemcpy(boxcar matrix)");
+    }
     if ((e = hipMalloc(&d->d_exc, sizeof(FmdExcBuf))) != hipSuccess) return fail(e, "hipMalloc(reports)");
     if ((e = hipMemset(d->d_exc, 0, sizeof(FmdExcBuf))) != hipSuccess) return fail(e, "hipMemset(reports)");
     if ((e = hipStreamCreateWithFlags(&d->stream, hipStreamNonBlocking)) != hipSuccess) return fail(e, "hipStreamCreate");
@@ -540,6 +548,7 @@ void fmd_demod_free(fmd_demod* d)
     if (d->d_exc) (void)hipFree(d->d_exc);
     d->order.destroy();
     if (d->d_chan_class) (void)hipFree(d->d_chan_class);
+    if (d->d_bx_amat) (void)hipFree(d->d_bx_amat);
     if (d->d_iq) (void)hipFree(d->d_iq);
     if (d->d_out) (void)hipFree(d->d_out);
     if (d->stream) (void)hipStreamDestroy(d->stream);

@@ -195,12 +195,18 @@ __device__ __forceinline__ int disc_nosel(uint32_t a, uint32_t b)
 // 1-ulp band against fast_atan2 itself, for boxcar sums up to 128 * 16 and at 128 * 18 to show the limit; the GPU
 // parity and fuzz tests run it on the hardware.
 #define FMD_DISC_F32_MAX_D 16
+// f32 -> i32 with the hardware's own rule for NaN (v_cvt_i32_f32: NaN -> 0).  `(int)x` is what hipcc selects that
+// instruction for; the wrapper names the property the callers rely on (and the tests pin: (0, 0) inputs).
+__device__ __forceinline__ int fmd_cvt_i32_nan0(float v) { return (int)v; }
 __device__ __forceinline__ float clamp01(float v) { return __builtin_amdgcn_fmed3f(v, 0.0f, 1.0f); }   // folds into a clamp modifier
 __device__ __forceinline__ float u2f(uint32_t u) { return __builtin_bit_cast(float, u); }
 __device__ __forceinline__ uint32_t f2u(float f) { return __builtin_bit_cast(uint32_t, f); }
 
 // fast_atan2 (:383-405) of the exact f32 product (xf, yf) = a * conj(b); see above.
 // NOWRAP: the caller guarantees |s| < 2^19 (downsample <= 3: 2 (128 * 3)^2 = 294 912), where `(4096 * s) as i32` cannot wrap.
+#ifndef FMD_DISC_TRIM
+#define FMD_DISC_TRIM 1              /* 0: the round-2 form (den + 2^-30 under the reciprocal, result * clamp(den + den)); A/B builds */
+#endif
 template <bool NOWRAP = false>
 __device__ __forceinline__ int disc_f32_xy(float xf, float yf)
 {
@@ -210,14 +216,26 @@ __device__ __forceinline__ int disc_f32_xy(float xf, float yf)
     const float s = u2f(f2u(t) ^ sx);
     const float big = 13194139533312.0f;                                 // 1.5 * 2^43
     const float sp = NOWRAP ? s : s - (((s + 0.5f) + big) - big);        // s mod 2^20, signed
+#if FMD_DISC_TRIM
+    // (0, 0): den = 0 -> rcp = inf, |sp| * inf = 0 * inf = NaN, and NaN runs through floor / fma / the clamped subtract /
+    // the sign xors to the final conversion, where v_cvt_i32_f32 turns it into 0 -- exactly fast_atan2's `(0, 0) -> 0`
+    // (:388).  Three instructions fewer than guarding the reciprocal and multiplying by a 0 / 1 factor
+    // (tests: test_near_silence, test_gpu_fuzz silence cases, tests/test_disc_f32_model.py for den >= 1).
+    const float c = __builtin_amdgcn_rcpf(den) * 4095.998046875f;
+#else
     const float c = __builtin_amdgcn_rcpf(den + 0x1p-30f) * 4095.998046875f;   // + 2^-30: finite for den == 0, no change otherwise
+#endif
     const float qf = __builtin_floorf(__builtin_fabsf(sp) * c);
     const float r = __builtin_fmaf(-qf, den, __builtin_fabsf(sp) * 4096.0f);
     const float q = qf + clamp01(r - (den - 1.0f));
     const float qs = u2f(f2u(q) ^ (f2u(sp) & 0x80000000u));
     const float base = 8192.0f - u2f(0x45800000u ^ sx);                  // 4096 or 12288 (:395,400)
     const float res = u2f(f2u(base - qs) ^ (f2u(yf) & 0x80000000u));
+#if FMD_DISC_TRIM
+    return fmd_cvt_i32_nan0(res);
+#else
     return (int)(res * clamp01(den + den));
+#endif
 }
 
 __device__ __forceinline__ int disc_f32(uint32_t a, uint32_t b)
@@ -238,6 +256,9 @@ __device__ __forceinline__ int disc_f32_c(float ar, float ai, float br, float bi
 {
     // + 0.0f: a product such as 0 * -5 is -0, and (-0) + (-0) stays -0; fast_atan2 takes its signs from x < 0 / y < 0,
     // where zero is not negative, and disc_f32_xy reads sign BITS (tests/test_gpu_parity.py::test_near_silence)
+    // (x too: with x = -0 the sign-bit form takes fast_atan2's "x < 0" branch, which agrees with the "x >= 0" one at x = 0 only
+    //  while `(4096 * s) as i32` does not wrap: (x, y) = (-0, 2^19) -- a = (0, -768), b = (-768, 0) at downsample 6 -- would
+    //  come out as 16384 instead of 8192.)
     const float xf = __builtin_fmaf(ai, bi, ar * br) + FMD_ZERO_FIX;        // ar*br + ai*bi
     const float yf = __builtin_fmaf(ai, br, -(ar * bi)) + FMD_ZERO_FIX;     // ai*br - ar*bi
     return disc_f32_xy<NOWRAP>(xf, yf);

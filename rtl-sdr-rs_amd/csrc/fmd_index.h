@@ -28,6 +28,7 @@
 #include <stdint.h>
 
 #if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
 #define FMD_HD __host__ __device__ __forceinline__
 #else
 #define FMD_HD inline

@@ -114,6 +114,7 @@ struct FmdLaunch {
     float    inv_sr, inv_R;
     uint32_t sr_shift;        // log2(sr) when sr is a power of two, else 32
     FmdMagic magic_R;         // fmd_sdiv_magic(sum, magic_R) == sum / R for |sum| < 2^24
+    const uint32_t* bx_amat;  // matrix-core boxcar (fmd_boxcar_mfma.h): A fragments [2][ceil(DH/2)][64 lanes][4 dwords], or nullptr
     const uint8_t* chan_class;// [n_channels] class id, or nullptr when every channel is class 0
     FmdClassPlan cls[FMD_MAX_CLASSES];
 };

@@ -23,6 +23,7 @@
 //       fast_atan2 with an exact f32-reciprocal divide;
 //     * resampler: one audio sample per lane from the tile's discriminator samples in LDS.
 //   fmd_demod_tile_kernel: one block per tile, LDS-DMA staging (global_load_lds_dwordx4).
+#include "fmd_boxcar_mfma.h"
 #include "fmd_device.h"
 #include "fmd_kernels.h"
 
@@ -53,6 +54,16 @@ using namespace fmd_dev;
 #ifndef FMD_ODD_KERNELS
 #define FMD_ODD_KERNELS 1
 #endif
+// The boxcar of the adjacent-window rounds on the matrix cores (fmd_boxcar_mfma.h, mfma_pair_rounds below): bit-exact, and
+// measured 1 ... 4 % SLOWER than the v_dot4 form at every downsample it covers (profiles/r03_boxcar_mfma.md),
+// so it is compiled into the -DFMD_EXPERIMENT build only (FMD_BX_MFMA=1 selects it there at run time).
+#ifndef FMD_BX_MFMA
+#ifdef FMD_EXPERIMENT
+#define FMD_BX_MFMA 1
+#else
+#define FMD_BX_MFMA 0
+#endif
+#endif
 #ifndef FMD_PAIR
 #define FMD_PAIR 1                   /* 0: windows i and i + 64 per lane, packed samples (A/B builds) */
 #endif
@@ -67,9 +78,11 @@ using namespace fmd_dev;
 #if defined(__HIP_DEVICE_COMPILE__)
 #define FMD_AS_GLOBAL __attribute__((address_space(1)))
 #define FMD_AS_CONSTANT __attribute__((address_space(4)))
+#define FMD_AS_LDS __attribute__((address_space(3)))
 #else
 #define FMD_AS_GLOBAL
 #define FMD_AS_CONSTANT
+#define FMD_AS_LDS
 #endif
 
 // Cache policy of the staging loads (aux of global_load_lds): 0 = default, 2 = nt (read once, do not keep).
@@ -256,9 +269,118 @@ __device__ __forceinline__ void masked_rounds(const uint32_t* __restrict__ raw_w
     }
 }
 
+// Boxcar on the matrix cores (fmd_boxcar_mfma.h) for the adjacent-window ("pair") rounds of an even downsample 2 DH:
+// lane l = 16 g + c of the wave-round owns windows base + 2 l and base + 2 l + 1, 8 DH contiguous bytes of the staged
+// tile; ceil(DH / 2) chained v_mfma_i32_16x16x64_i8 over the raw bytes (u8 ^ 0x80) against the banded +-1 weight matrix
+// leave (re1, im1, re2, im2) -- the four boxcar sums of the lane's two windows, constants included through the C operand --
+// in the lane's four result registers.  The discriminator stage behind it is the VALU form's, unchanged.
+typedef int fmd_i4 __attribute__((ext_vector_type(4)));
+
+// The tap-weight fragments of the matrix-core boxcar, fetched in the kernel PROLOGUE -- while the tile's LDS-DMAs are in
+// flight -- so that their global-memory latency hides under the tile's own (fetched after the barrier they cost every
+// wave a full memory round trip in front of its first matrix instruction: +9 % launch time, measured).
+template <int DH>
+struct BxFrag {
+    static constexpr int NM = DH > 0 && DH <= (int)FMD_BX_MAX_DH ? (DH + 1) / 2 : 1;
+    fmd_i4 A[NM];
+    bool use;                 // block-uniform: this tile's pair rounds run on the matrix cores
+    bool o1;                  // rotation parity of a wave's first window (wave-uniform)
+    int e;                    // 0 / -1: the rounds start one window early (odd DH, first window at an odd dword)
+};
+
+template <int DH, int NT>
+__device__ __forceinline__ BxFrag<DH> bx_prefetch(const FmdLaunch& L, const TileCtx& X, uint32_t tid)
+{
+    BxFrag<DH> F;
+    F.use = false; F.o1 = false; F.e = 0;
+#pragma unroll
+    for (int m = 0; m < BxFrag<DH>::NM; ++m) F.A[m] = fmd_i4{0, 0, 0, 0};
+    if constexpr (FMD_BX_MFMA && FMD_USE_F32 && FMD_PAIR && DH > 0 && DH <= (int)FMD_BX_MAX_DH) {
+        constexpr int NW = NT / 64, RS = NW == 1 ? 124 : 126, NM = BxFrag<DH>::NM;
+        const uint32_t p0 = L.cls[X.cls].p0, hp = p0 >> 1;
+        const int wbase = X.wofs - (int)hp + DH * X.jfirst;
+        // whole-dword windows (even boxcar phase); for an even DH they must also start at even dwords (8-byte aligned reads)
+        F.use = L.bx_amat != nullptr && (p0 & 1u) == 0u && ((DH & 1) != 0 || (wbase & 1) == 0) && !FMD_ABLATE(6);
+        if (F.use) {
+            const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid >> 6));
+            F.e = (DH & 1) ? -(wbase & 1) : 0;
+            const int jw = X.jfirst + F.e + (int)wave * RS;
+            F.o1 = ((((DH & 1) ? ((uint32_t)jw ^ hp) : hp)) & 1u) != 0u;
+            typedef const FMD_AS_GLOBAL fmd_i4* gq;
+            const gq amat = (gq)(uintptr_t)L.bx_amat + (F.o1 ? NM * 64 : 0) + (tid & 63u);
+#pragma unroll
+            for (int m = 0; m < NM; ++m) F.A[m] = amat[m * 64];
+        }
+    }
+    return F;
+}
+
+template <int DH, int NT>
+__device__ __forceinline__ void mfma_pair_rounds(const BxFrag<DH>& F, const unsigned char* __restrict__ smem, int16_t* __restrict__ d16,
+                                                 int wbase, int cnt, uint32_t lane, uint32_t wave)
+{
+    // A round is 128 windows (two per lane); RS of them are new.  RS is EVEN here (126, against 127 in the dot-product
+    // form): every round of every wave then starts at a window of the same parity, so the operand reads are 8-byte
+    // aligned in LDS for all of them -- a misaligned ds_read_b64 costs far more than the 0.8 % of extra rounds
+    // (measured: odd downsample halves with 127, where every other wave was misaligned, ran 20 % SLOWER than the
+    // dot-product form).  For an odd DH a tile whose first window sits at an odd dword starts one window early (e = -1:
+    // the extra window only ever serves as a predecessor); for an even DH the caller checks wbase.  The last window of a
+    // round (lane 63's second) is the next round's first new one: both store the same value to the same slot.
+    constexpr int NW = NT / 64, RS = NW == 1 ? 124 : 126;
+    constexpr int NM = (DH + 1) / 2;
+    constexpr uint32_t STRIDE = 4u * DH * NW * RS;           // bytes from one round of a wave to its next
+    wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)wave);   // scalar: the round loop's control flow becomes s_cbranch
+    const int last = cnt - 1;
+    const int e = F.e;
+    const bool o1 = F.o1, o2 = o1 != ((DH & 1) != 0);        // rotation parity of the lane's two windows (wave-uniform)
+    const int c1 = 2 * (o1 ? DH / 2 : (DH + 1) / 2), c2 = 2 * (o2 ? DH / 2 : (DH + 1) / 2);
+    int base = e + (int)wave * RS;
+    if (base >= last) return;
+    // Explicit LDS pointers: 32-bit addresses that wrap, and a read outside the allocation returns 0 (windows before the
+    // tile's first byte / beyond its last only feed results that are not stored) -- through a generic pointer the same
+    // read would be a flat access outside the aperture, which faults.
+    typedef const FMD_AS_LDS unsigned char* lds_bp;
+    typedef const FMD_AS_LDS uint2* lds_u2p;
+    // the lane's own span of the wave's first round: windows base + 2 lane and base + 2 lane + 1, 8 DH contiguous bytes
+    lds_bp p = (lds_bp)smem + (4u * (uint32_t)(wbase + DH * base) + 8u * DH * lane);
+    const fmd_i4 cinit = {DH, c1, DH, c2};                   // the additive constants of the two windows (re gets +1 per dword)
+    uint32_t dead1 = 0, dead2 = 0;                           // operand registers that are dead after the matrix instruction (DPP `old`)
+    auto boxcar = [&](lds_bp pr) {
+        fmd_i4 acc = cinit;
+#pragma unroll
+        for (int m = 0; m < NM; ++m) {
+            const uint2 lo = *(lds_u2p)(pr + 16 * m);
+            const uint2 hi = *(lds_u2p)(pr + 16 * m + 8);
+            const fmd_i4 B = {(int)(lo.x ^ 0x80808080u), (int)(lo.y ^ 0x80808080u), (int)(hi.x ^ 0x80808080u), (int)(hi.y ^ 0x80808080u)};
+            acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(F.A[m], B, acc, 0, 0, 0);
+            dead1 = (uint32_t)B.x; dead2 = (uint32_t)B.y;
+        }
+        return acc;
+    };
+    // software pipeline: the next round's reads and matrix instructions are issued before the current round's
+    // discriminators, which then run in their shadow (no wait states in front of the conversions)
+    fmd_i4 cur = boxcar(p);
+    for (;;) {
+        const int nb = base + NW * RS;
+        const bool more = nb < last;                         // wave-uniform
+        fmd_i4 nxt = cur;
+        if (more) { p += STRIDE; nxt = boxcar(p); }
+        __builtin_amdgcn_sched_barrier(0);
+        const int i1 = base + 2 * (int)lane, i2 = i1 + 1;
+        const float ar1 = (float)cur.x, ai1 = (float)cur.y, ar2 = (float)cur.z, ai2 = (float)cur.w;
+        const float br1 = u2f(wave_shr1_dead(dead1, f2u(ar2))), bi1 = u2f(wave_shr1_dead(dead2, f2u(ai2)));   // second window of lane l - 1
+        const int d1 = disc_f32_c<DH == 1>(ar1, ai1, br1, bi1);
+        const int d2 = disc_f32_c<DH == 1>(ar2, ai2, ar1, ai1);
+        if (lane > 0 && i1 < cnt) d16[i1] = (int16_t)d1;
+        if (i2 < cnt) d16[i2] = (int16_t)d2;
+        if (!more) break;
+        cur = nxt; base = nb;
+    }
+}
+
 // Everything after the tile's bytes are visible in LDS.  Contains one __syncthreads().
 template <int DH, int NT>
-__device__ __forceinline__ void tile_body(const FmdLaunch& L, const TileCtx& X, unsigned char* smem)
+__device__ __forceinline__ void tile_body(const FmdLaunch& L, const TileCtx& X, unsigned char* smem, const BxFrag<DH>& F)
 {
     const FmdRates& r = L.r;
     const FmdClassPlan& P = L.cls[X.cls];
@@ -305,7 +427,10 @@ __device__ __forceinline__ void tile_body(const FmdLaunch& L, const TileCtx& X, 
     // form saves -- unless the windows are 16-byte aligned in LDS (channel buffers aligned, boxcar phase 0: the usual
     // case), where one ds_read_b128 fetches a whole window: then the pair form is taken with two such reads per lane.
     const bool dh4_aligned = DH == 4 && FMD_DH4_B128 && (((wofs - (int)hp) & 3) == 0);     // block-uniform
-    if (fastwin && FMD_USE_F32 && FMD_PAIR && (DH != 4 || dh4_aligned)) {
+    if (F.use) {
+        // the boxcar of the adjacent-window rounds on the matrix cores (see mfma_pair_rounds); F.use implies fastwin
+        if constexpr (DH > 0 && DH <= (int)FMD_BX_MAX_DH) mfma_pair_rounds<DH, NT>(F, smem, d16, wofs - (int)hp + DH * jfirst, cnt, lane, wave);
+    } else if (fastwin && FMD_USE_F32 && FMD_PAIR && (DH != 4 || dh4_aligned)) {
         // Whole-dword windows, f32 discriminator (downsample 2 ... 10).  Lane l takes the ADJACENT windows i = base + 2l
         // and i + 1: the second window's predecessor is the lane's own first one, and only the first one's comes from
         // the neighbour (the second window of lane l - 1; lane 0's first window is the round's overlap and is not
@@ -725,6 +850,7 @@ __global__ void __launch_bounds__(NT) fmd_demod_tile_kernel(const FmdLaunch L)
             issue_dma<NT>(A.a0, A.nchunks, smem, tid);
         }
         const TileCtx X = fast_ctx<FAST>(L, A);              // scalar work under the load latency
+        const BxFrag<DH> F = bx_prefetch<DH, NT>(L, X, tid);  // ... and the matrix-core boxcar's weight fragments
         if (!A.whole && !FMD_ABLATE(4)) stage_slow<NT>(L, X, smem, tid);
         if (FMD_ABLATE(3)) {                                 // ablation: staging skeleton only
             __syncthreads();
@@ -734,7 +860,7 @@ __global__ void __launch_bounds__(NT) fmd_demod_tile_kernel(const FmdLaunch L)
         __builtin_amdgcn_s_waitcnt(0x0F70);
         __syncthreads();
         __builtin_amdgcn_s_setprio(0);
-        tile_body<DH, NT>(L, X, smem);
+        tile_body<DH, NT>(L, X, smem, F);
         return;
     }
     uint32_t c = blockIdx.z * 65535u + blockIdx.y, tix = blockIdx.x;
@@ -760,6 +886,7 @@ __global__ void __launch_bounds__(NT) fmd_demod_tile_kernel(const FmdLaunch L)
     } else {
         stage_slow<NT>(L, X, smem, tid);
     }
+    const BxFrag<DH> F = bx_prefetch<DH, NT>(L, X, tid);      // in flight with the tile's bytes
     if (FMD_ABLATE(3)) {                                     // ablation: staging skeleton only
         __syncthreads();
         if (tid == 0) L.out[(uint64_t)c * L.out_stride + X.T.k0] = (int16_t)reinterpret_cast<uint32_t*>(smem)[blockIdx.x & 63u];
@@ -772,7 +899,7 @@ __global__ void __launch_bounds__(NT) fmd_demod_tile_kernel(const FmdLaunch L)
     // (Measured and rejected: touching the lines of a tile 512..3584 dispatch slots ahead to pre-warm
     //  L2 / Infinity Cache made the launch 4..40 % SLOWER -- the stream is bandwidth-, not latency-bound.)
     __builtin_amdgcn_s_setprio(0);
-    tile_body<DH, NT>(L, X, smem);
+    tile_body<DH, NT>(L, X, smem, F);
 }
 
 template <int DH>
@@ -780,7 +907,11 @@ void launch_one(const FmdLaunch& L, dim3 g, size_t lds, hipStream_t stream)
 {
     switch (L.block_threads) {
 #ifdef FMD_EXPERIMENT                                        // 64- / 128-thread blocks (FMD_NT): measured equal or slower, kept for A/B only
-        case 128: hipLaunchKernelGGL((fmd_demod_tile_kernel<DH, 128, 0>), g, dim3(128), lds, stream, L); break;
+        case 128:
+            if (L.fast == 1u) hipLaunchKernelGGL((fmd_demod_tile_kernel<DH, 128, 1>), g, dim3(128), lds, stream, L);
+            else if (L.fast == 2u) hipLaunchKernelGGL((fmd_demod_tile_kernel<DH, 128, 2>), g, dim3(128), lds, stream, L);
+            else hipLaunchKernelGGL((fmd_demod_tile_kernel<DH, 128, 0>), g, dim3(128), lds, stream, L);
+            break;
         case 64: hipLaunchKernelGGL((fmd_demod_tile_kernel<DH, 64, 0>), g, dim3(64), lds, stream, L); break;
 #endif
         default:
@@ -815,7 +946,7 @@ bool fmd_tile_kernel_supports(const FmdRates& r, uint32_t raw_cap)
 // form (tiles repeat exactly: kt * fr % sr == 0), 2 = per-tile table (any rates, at most FMD_FAST_ROWS tiles), 0 = none.
 static uint32_t fmd_fast_geometry(FmdLaunch& L, uint32_t per)
 {
-    if (!L.fast || L.chan_class || L.block_threads != 256u) return 0u;   // L.fast on entry: allowed (FMD_FAST != 0)
+    if (!L.fast || L.chan_class || (L.block_threads != 256u && L.block_threads != 128u)) return 0u;   // L.fast on entry: allowed (FMD_FAST != 0)
     const FmdRates& r = L.r;
     const FmdClassPlan& P = L.cls[0];
     if (P.nt != L.tiles || P.nt == 0u) return 0u;

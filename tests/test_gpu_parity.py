@@ -135,6 +135,36 @@ def test_near_silence(fmd, oracle, D, fast, slow):
     check_stream(fmd, oracle, D, fast, slow, blocks, n_channels=nch)
 
 
+def axis_pattern(re, im):
+    """8 raw bytes whose rotated (rotate_90, :284-296) and centred (`- 127`, :258) samples are all (re, im), for re, im
+    in {-127, 0, 128}: sample n of each 4 is (b0-127, b1-127), (128-b3, b2-127), (128-b4, 128-b5), (b7-127, 128-b6)."""
+    p = lambda v: v + 127          # plain byte
+    n = lambda v: 128 - v          # byte behind a `255 - x`
+    return np.array([p(re), p(im), p(im), n(re), n(re), n(im), n(im), p(re)], np.uint8)
+
+
+@pytest.mark.parametrize("D,fast,slow", [(4, 256000, 48000), CFG_REF, (7, 166666, 32000), CFG_24, (12, 192000, 32000),
+                                         (16, 150000, 32000), (18, 180000, 30000)])
+def test_axis_aligned_full_scale(fmd, oracle, D, fast, slow):
+    """Decimated samples that sit exactly on an axis at full scale, (+-F, 0) and (0, +-F) in random order: the products are
+    x = +-0 with |y| = F^2 >= 2^19 and y = +-0 with |x| = F^2 -- both signs of zero together with the i32 wrap of
+    `(4096 * s) as i32` (:397,399).  An f32 discriminator that reads sign bits must canonicalise BOTH components: with
+    x = -0 and y = 2^19 the two branches of fast_atan2 differ (16384 vs 8192) -- a = (0, -762), b = (-762, 0) at downsample 6."""
+    rng = np.random.default_rng(3000 + D)
+    nch = 5
+    seg = 8 * D                                               # bytes: 4 whole windows, a multiple of the 8-byte rotation period
+    vals = [(128, 0), (-127, 0), (0, 128), (0, -127), (0, 0)]
+    blocks = []
+    for i in range(3):
+        nseg = int(rng.integers(20, 60))
+        blk = np.empty((nch, nseg * seg), np.uint8)
+        for c in range(nch):
+            picks = rng.integers(0, len(vals) - (0 if c == 0 else 1), nseg)       # channel 0 also passes through (0, 0)
+            blk[c] = np.concatenate([np.tile(axis_pattern(*vals[k]), seg // 8) for k in picks])
+        blocks.append(blk)
+    check_stream(fmd, oracle, D, fast, slow, blocks, n_channels=nch)
+
+
 @pytest.mark.parametrize("kt", [1, 2, 7, 64, 300])
 def test_tiling_invariance(fmd, oracle, kt):
     rng = np.random.default_rng(kt)
