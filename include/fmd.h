@@ -27,7 +27,7 @@ extern "C" {
 #endif
 
 #define FMD_VERSION_MAJOR 0
-#define FMD_VERSION_MINOR 2
+#define FMD_VERSION_MINOR 3
 
 /* DEFAULT_BUF_LENGTH, src/lib.rs:25 -- the buffer size RtlSdr::read_sync callers use. */
 #define FMD_DEFAULT_BUF_LENGTH (16 * 16384)
@@ -43,7 +43,8 @@ typedef enum fmd_status {
     FMD_ERR_BAD_STATE     = -7,  /* fmd_demod_set_state with a state no Demod can reach             */
     FMD_ERR_NO_DEVICE     = -8,  /* no gfx950 device / bad device_id                                */
     FMD_ERR_HIP           = -9,  /* a HIP runtime call failed; see fmd_last_error()                 */
-    FMD_ERR_NOMEM         = -10
+    FMD_ERR_NOMEM         = -10,
+    FMD_ERR_IO            = -11  /* rtl_tcp source: connect / handshake / socket error, see fmd_last_error()  */
 } fmd_status;
 
 /* struct RadioConfig, simple_fm.rs:173-176 */
@@ -278,6 +279,38 @@ int fmd_sink_release(fmd_sink *s);
 int fmd_sink_poll(fmd_sink *s);     /* deliver what has finished; returns the number of buffers delivered or < 0 */
 int fmd_sink_drain(fmd_sink *s);    /* wait for and deliver everything in flight */
 int fmd_sink_info(const fmd_sink *s, size_t *out_cap, uint32_t *n_devices, uint32_t *in_flight);
+
+/* ---- rtl_tcp client-side IQ source ---------------------------------------------------- */
+/* The reference ships the rtl_tcp SERVER (examples/rtl_tcp.rs); this is the matching client, so that a dongle on another
+ * host feeds the sinks above without USB code here.  Wire format: a 12-byte handshake "RTL0" + tuner type + tuner gain
+ * count, both u32 big-endian (send_handshake, examples/rtl_tcp.rs:691-697); then raw interleaved u8 IQ exactly as
+ * RtlSdr::read_sync delivered it (sender_loop, :609-631); commands are 5 bytes, opcode + big-endian 32-bit parameter
+ * (command_loop, :639-678).  Host code only (no GPU needed).
+ *   fmd_rtltcp_open     : connect (timeout_ms, 0 = 10 s) and read the handshake; FMD_ERR_IO when it is not "RTL0";
+ *   fmd_rtltcp_read_sync: RtlSdr::read_sync (src/lib.rs:153) -- fill buf, *n_read = bytes written; FEWER than nbytes
+ *                         means the stream ended, which the reference's callers treat as "samples lost"
+ *                         (examples/simple_fm.rs:122); a socket error or a timeout returns FMD_ERR_IO;
+ *   fmd_rtltcp_command  : one command; a negative (i32) parameter travels as its two's complement. */
+typedef struct fmd_rtltcp fmd_rtltcp;
+#define FMD_RTLTCP_SET_FREQUENCY       0x01   /* opcodes of command_loop, examples/rtl_tcp.rs:659-675 */
+#define FMD_RTLTCP_SET_SAMPLE_RATE     0x02
+#define FMD_RTLTCP_SET_GAIN_MODE       0x03
+#define FMD_RTLTCP_SET_GAIN            0x04
+#define FMD_RTLTCP_SET_FREQ_CORRECTION 0x05
+#define FMD_RTLTCP_SET_IF_GAIN         0x06
+#define FMD_RTLTCP_SET_TEST_MODE       0x07
+#define FMD_RTLTCP_SET_AGC_MODE        0x08
+#define FMD_RTLTCP_SET_DIRECT_SAMPLING 0x09
+#define FMD_RTLTCP_SET_OFFSET_TUNING   0x0a
+#define FMD_RTLTCP_SET_RTL_XTAL        0x0b
+#define FMD_RTLTCP_SET_TUNER_XTAL      0x0c
+#define FMD_RTLTCP_SET_GAIN_BY_INDEX   0x0d
+#define FMD_RTLTCP_SET_BIAS_TEE        0x0e
+int fmd_rtltcp_open(const char *host, uint16_t port, uint32_t timeout_ms, fmd_rtltcp **out);
+void fmd_rtltcp_close(fmd_rtltcp *s);
+int fmd_rtltcp_info(const fmd_rtltcp *s, uint32_t *tuner_type, uint32_t *gain_count);
+int fmd_rtltcp_read_sync(fmd_rtltcp *s, uint8_t *buf, size_t nbytes, size_t *n_read);
+int fmd_rtltcp_command(fmd_rtltcp *s, uint8_t opcode, uint32_t param);
 
 /* ---- diagnostics ---------------------------------------------------------------------- */
 const char *fmd_strerror(int status);

@@ -19,6 +19,7 @@ FMD_ERR_BAD_STATE = -7
 FMD_ERR_NO_DEVICE = -8
 FMD_ERR_HIP = -9
 FMD_ERR_NOMEM = -10
+FMD_ERR_IO = -11
 
 DEFAULT_BUF_LENGTH = 16 * 16384      # src/lib.rs:25
 
@@ -109,6 +110,11 @@ PROTOTYPES = {
     "fmd_sink_poll": (C.c_int, [_vp]),
     "fmd_sink_drain": (C.c_int, [_vp]),
     "fmd_sink_info": (C.c_int, [_vp, _szp, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
+    "fmd_rtltcp_open": (C.c_int, [C.c_char_p, C.c_uint16, C.c_uint32, C.POINTER(_vp)]),
+    "fmd_rtltcp_close": (None, [_vp]),
+    "fmd_rtltcp_info": (C.c_int, [_vp, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
+    "fmd_rtltcp_read_sync": (C.c_int, [_vp, _vp, _sz, _szp]),
+    "fmd_rtltcp_command": (C.c_int, [_vp, C.c_uint8, C.c_uint32]),
 }
 
 SINK_CALLBACK = C.CFUNCTYPE(None, C.c_void_p, C.c_uint64, C.POINTER(C.c_int16), C.POINTER(C.c_size_t), C.c_size_t, C.c_int)

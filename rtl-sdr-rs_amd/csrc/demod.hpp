@@ -157,6 +157,35 @@ private:
     fmd_sink* h_ = nullptr;
 };
 
+// An rtl_tcp server (the reference's examples/rtl_tcp.rs) as the producer: `read_sync` has the shape of
+// RtlSdr::read_sync (src/lib.rs:153) -- bytes written, fewer than asked = the stream ended ("samples lost",
+// simple_fm.rs:122).  Wire format and opcodes: include/fmd.h, fmd_rtltcp_*.
+class RtlTcpSource {
+public:
+    RtlTcpSource(const std::string& host, uint16_t port, uint32_t timeout_ms = 10000)
+    {
+        check(fmd_rtltcp_open(host.c_str(), port, timeout_ms, &h_));
+        check(fmd_rtltcp_info(h_, &tuner_type_, &gain_count_));
+    }
+    ~RtlTcpSource() { fmd_rtltcp_close(h_); }
+    RtlTcpSource(const RtlTcpSource&) = delete;
+    RtlTcpSource& operator=(const RtlTcpSource&) = delete;
+
+    size_t read_sync(uint8_t* buf, size_t nbytes) { size_t n = 0; check(fmd_rtltcp_read_sync(h_, buf, nbytes, &n)); return n; }
+    void command(uint8_t opcode, uint32_t param) { check(fmd_rtltcp_command(h_, opcode, param)); }
+    // config_sdr of the example (simple_fm.rs:217-229), by name
+    void set_tuner_gain_auto() { command(FMD_RTLTCP_SET_GAIN_MODE, 0); }
+    void set_bias_tee(bool on) { command(FMD_RTLTCP_SET_BIAS_TEE, on ? 1u : 0u); }
+    void set_center_freq(uint32_t hz) { command(FMD_RTLTCP_SET_FREQUENCY, hz); }
+    void set_sample_rate(uint32_t hz) { command(FMD_RTLTCP_SET_SAMPLE_RATE, hz); }
+    uint32_t tuner_type() const { return tuner_type_; }
+    uint32_t gain_count() const { return gain_count_; }
+
+private:
+    fmd_rtltcp* h_ = nullptr;
+    uint32_t tuner_type_ = 0, gain_count_ = 0;
+};
+
 // output(buf: Vec<i16>), simple_fm.rs:430-438: raw native-endian s16 to stdout, flushed.
 inline void output(const std::vector<int16_t>& buf, FILE* f = stdout)
 {

@@ -413,6 +413,7 @@ const char* fmd_strerror(int status)
         case FMD_ERR_NO_DEVICE: return "no usable gfx950 device";
         case FMD_ERR_HIP: return "HIP runtime error";
         case FMD_ERR_NOMEM: return "out of memory";
+        case FMD_ERR_IO: return "rtl_tcp source: socket error";
         default: return "unknown status";
     }
 }

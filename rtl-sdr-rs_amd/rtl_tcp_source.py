@@ -100,6 +100,50 @@ class RtlTcpSource:
         self.close()
 
 
+class RtlTcpSourceC:
+    """The same source through the C ABI (fmd_rtltcp_*, include/fmd.h) -- what a non-Python host (the C++ mirror
+    fm::RtlTcpSource, the Rust shim's RtlTcpSource) uses; same interface as RtlTcpSource above."""
+
+    def __init__(self, host="127.0.0.1", port=1234, timeout=10.0):
+        import ctypes as C
+        from ._ffi import check, lib
+        self._C, self._lib, self._check = C, lib(), check
+        self._h = C.c_void_p()
+        check(self._lib.fmd_rtltcp_open(host.encode(), port, int(timeout * 1000), C.byref(self._h)))
+        t, g = C.c_uint32(), C.c_uint32()
+        check(self._lib.fmd_rtltcp_info(self._h, C.byref(t), C.byref(g)))
+        self.tuner_type, self.gain_count = t.value, g.value
+
+    def read_sync(self, buf):
+        view = memoryview(buf).cast("B")
+        C = self._C
+        n = C.c_size_t(0)
+        addr = C.addressof((C.c_uint8 * len(view)).from_buffer(view))
+        self._check(self._lib.fmd_rtltcp_read_sync(self._h, addr, len(view), C.byref(n)))
+        return n.value
+
+    def command(self, opcode, param):
+        self._check(self._lib.fmd_rtltcp_command(self._h, opcode & 0xFF, param & 0xFFFFFFFF))
+
+    set_center_freq = RtlTcpSource.set_center_freq
+    set_sample_rate = RtlTcpSource.set_sample_rate
+    set_tuner_gain_auto = RtlTcpSource.set_tuner_gain_auto
+    set_bias_tee = RtlTcpSource.set_bias_tee
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h:
+            self._lib.fmd_rtltcp_close(self._h)
+            self._h = self._C.c_void_p()
+
+    __del__ = close
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+
 def stream_fm(host, port, freq=94_900_000, rate=170_000, rate_resample=32_000, out=None, max_blocks=None):
     """simple_fm's receive()+process() (:89-170) with the dongle replaced by an rtl_tcp server and the Demod by
     the GPU one: tune with offset (optimal_settings :189-214), read DEFAULT_BUF_LENGTH blocks, write raw s16."""

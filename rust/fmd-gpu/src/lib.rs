@@ -80,6 +80,11 @@ pub struct fmd_sink {
     _private: [u8; 0],
 }
 
+#[repr(C)]
+pub struct fmd_rtltcp {
+    _private: [u8; 0],
+}
+
 /// `fmd_sink_callback`: (user, seq, audio [n_channels][out_cap], out_len [n_channels], out_cap, status).
 pub type fmd_sink_callback = Option<unsafe extern "C" fn(*mut c_void, u64, *const i16, *const usize, usize, c_int)>;
 
@@ -131,6 +136,11 @@ extern "C" {
     pub fn fmd_sink_poll(s: *mut fmd_sink) -> c_int;
     pub fn fmd_sink_drain(s: *mut fmd_sink) -> c_int;
     pub fn fmd_sink_info(s: *const fmd_sink, out_cap: *mut usize, n_devices: *mut u32, in_flight: *mut u32) -> c_int;
+    pub fn fmd_rtltcp_open(host: *const c_char, port: u16, timeout_ms: u32, out: *mut *mut fmd_rtltcp) -> c_int;
+    pub fn fmd_rtltcp_close(s: *mut fmd_rtltcp);
+    pub fn fmd_rtltcp_info(s: *const fmd_rtltcp, tuner_type: *mut u32, gain_count: *mut u32) -> c_int;
+    pub fn fmd_rtltcp_read_sync(s: *mut fmd_rtltcp, buf: *mut u8, nbytes: usize, n_read: *mut usize) -> c_int;
+    pub fn fmd_rtltcp_command(s: *mut fmd_rtltcp, opcode: u8, param: u32) -> c_int;
 }
 
 /// Error in the crate's convention (`src/error.rs:8,40-44`: a Result, never a panic).
@@ -271,6 +281,48 @@ impl<R: std::io::Read> IqSource for R {
             got += n;
         }
         Ok(got)
+    }
+}
+
+/// An rtl_tcp server (the reference's own examples/rtl_tcp.rs, or osmocom's) as an `IqSource`: a dongle on another host
+/// feeding the GPU `Demod`.  Handshake "RTL0" + tuner type + gain count (examples/rtl_tcp.rs:691-697), raw u8 IQ
+/// (:609-631), 5-byte big-endian commands (:639-678) -- all behind `fmd_rtltcp_*` of the C ABI.
+pub struct RtlTcpSource {
+    handle: *mut fmd_rtltcp,
+    pub tuner_type: u32,
+    pub gain_count: u32,
+}
+
+unsafe impl Send for RtlTcpSource {}
+
+impl RtlTcpSource {
+    pub fn connect(host: &str, port: u16, timeout_ms: u32) -> Result<Self> {
+        let chost = std::ffi::CString::new(host).map_err(|_| FmdError { status: -1, message: "host contains NUL".into() })?;
+        let mut handle: *mut fmd_rtltcp = std::ptr::null_mut();
+        check(unsafe { fmd_rtltcp_open(chost.as_ptr(), port, timeout_ms, &mut handle) })?;
+        let (mut t, mut g) = (0u32, 0u32);
+        check(unsafe { fmd_rtltcp_info(handle, &mut t, &mut g) })?;
+        Ok(RtlTcpSource { handle, tuner_type: t, gain_count: g })
+    }
+
+    /// One 5-byte command (opcode + big-endian parameter); `config_sdr` of the example (examples/simple_fm.rs:217-229)
+    /// maps to 0x03 (gain mode), 0x0e (bias tee), 0x01 (frequency), 0x02 (sample rate).
+    pub fn command(&mut self, opcode: u8, param: u32) -> Result<()> {
+        check(unsafe { fmd_rtltcp_command(self.handle, opcode, param) })
+    }
+}
+
+impl IqSource for RtlTcpSource {
+    fn read_sync(&mut self, buf: &mut [u8]) -> std::result::Result<usize, Box<dyn std::error::Error>> {
+        let mut n: usize = 0;
+        check(unsafe { fmd_rtltcp_read_sync(self.handle, buf.as_mut_ptr(), buf.len(), &mut n) })?;
+        Ok(n)
+    }
+}
+
+impl Drop for RtlTcpSource {
+    fn drop(&mut self) {
+        unsafe { fmd_rtltcp_close(self.handle) }
     }
 }
 

@@ -40,7 +40,7 @@ def test_header_is_plain_c11_and_links(tmp_path, fmd):
 
 
 # ---- Rust shim vs header ------------------------------------------------------------------------------------------
-C2R = {"uint8_t": "u8", "int16_t": "i16", "int32_t": "i32", "uint32_t": "u32", "uint64_t": "u64", "size_t": "usize",
+C2R = {"uint8_t": "u8", "uint16_t": "u16", "int16_t": "i16", "int32_t": "i32", "uint32_t": "u32", "uint64_t": "u64", "size_t": "usize",
        "int": "c_int", "char": "c_char", "void": "c_void", "double": "f64"}
 STRUCTS = {"fmd_radio_config": "RadioConfig", "fmd_demod_config": "DemodConfig", "fmd_demod_state": "DemodState",
            "fmd_device_config": "DeviceConfig", "fmd_synth_params": "SynthParams"}
@@ -136,3 +136,23 @@ def test_c_consumer_matches_oracle(tmp_path, fmd, oracle):
     st = [int(x) for x in (tmp_path / "state.txt").read_text().split()]
     want = oracle.state_of(od)
     assert st == [want["prev_index"], want["now_lpr"], want["prev_lpr_index"]] + want["lp_now"] + want["demod_pre"]
+
+
+@pytest.mark.gpu
+def test_c_consumer_reads_its_iq_from_an_rtl_tcp_server(tmp_path, fmd, oracle):
+    """The same plain-C program with the producer side of the boundary behind the C ABI too: fmd_rtltcp_* against the
+    fake server of tests/test_rtl_tcp_source.py (handshake :691-697, commands :639-678, raw u8 IQ :609-631)."""
+    from test_rtl_tcp_source import FakeServer
+    from rtl_sdr_rs_amd import rtl_tcp_source as rts
+    exe = build_consumer(tmp_path)
+    n = fmd.DEFAULT_BUF_LENGTH
+    iq = fmd.synth.synth_iq(1, 2 * n + 40, seed=0xC12, amplitude=90)[0]
+    srv = FakeServer(iq.tobytes())
+    p = subprocess.run([exe, "-", str(tmp_path / "audio.s16"), str(tmp_path / "state.txt"), str(srv.port)],
+                       capture_output=True, timeout=300)
+    assert p.returncode == 0, p.stderr.decode()
+    srv.thread.join(timeout=5)
+    _, ocfg = oracle.optimal_settings(94_900_000, 170_000)
+    exp, _ = oracle.demodulate_stream(ocfg, iq[:2 * n], n)
+    assert np.array_equal(np.fromfile(str(tmp_path / "audio.s16"), dtype=np.int16), exp)
+    assert (rts.CMD_SET_FREQUENCY, 95_155_000) in srv.commands and (rts.CMD_SET_SAMPLE_RATE, 1_020_000) in srv.commands

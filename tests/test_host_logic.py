@@ -53,7 +53,7 @@ def test_optimal_settings_and_out_cap_without_gpu(fmd):
     cap = fmd.out_cap(d, fmd.DEFAULT_BUF_LENGTH)
     assert 4113 <= cap <= 4120                                  # 4112/4113 samples per reference block
     assert fmd.lib().fmd_strerror(-2).decode().startswith("buffer length")
-    assert fmd.lib().fmd_version() == 2
+    assert fmd.lib().fmd_version() == 3                      # FMD_VERSION_MAJOR * 1000 + FMD_VERSION_MINOR
 
 
 def test_fails_loudly_without_device(fmd):

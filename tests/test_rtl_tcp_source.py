@@ -70,6 +70,43 @@ def test_handshake_commands_and_read_sync():
     assert (rts.CMD_SET_FREQ_CORRECTION, 0xFFFFFFFD) in srv.commands   # i32 -3, big-endian two's complement
 
 
+def test_c_abi_source_handshake_commands_and_read_sync(fmd):
+    """The same through fmd_rtltcp_* (include/fmd.h): what the C++ mirror and the Rust shim's IqSource use.  Host code
+    only -- it runs without a GPU."""
+    rng = np.random.default_rng(2)
+    payload = rng.integers(0, 256, 300000, dtype=np.uint8).tobytes()
+    srv = FakeServer(payload, tuner_type=6, gain_count=28)
+    with rts.RtlTcpSourceC("127.0.0.1", srv.port) as src:
+        assert (src.tuner_type, src.gain_count) == (6, 28)
+        src.set_center_freq(95_155_000)
+        src.set_sample_rate(1_020_000)
+        src.command(rts.CMD_SET_FREQ_CORRECTION, -3)
+        buf = np.empty(262144, dtype=np.uint8)
+        assert src.read_sync(buf) == 262144
+        assert buf.tobytes() == payload[:262144]
+        assert src.read_sync(buf) == 300000 - 262144              # short read at end of stream: not an error
+        assert src.read_sync(buf) == 0
+    srv.thread.join(timeout=5)
+    assert (rts.CMD_SET_FREQUENCY, 95_155_000) in srv.commands
+    assert (rts.CMD_SET_SAMPLE_RATE, 1_020_000) in srv.commands
+    assert (rts.CMD_SET_FREQ_CORRECTION, 0xFFFFFFFD) in srv.commands
+
+
+def test_c_abi_source_errors(fmd):
+    import socket as so
+    with so.socket() as s:                                       # a port nobody listens on
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    with pytest.raises(fmd.FmdError) as ei:
+        rts.RtlTcpSourceC("127.0.0.1", port, timeout=2.0)
+    assert ei.value.status == -11                                 # FMD_ERR_IO
+    srv = FakeServer(b"", tuner_type=0)
+    srv.hs = b"HTTP/1.1 200"                                      # 12 bytes that are not a handshake
+    with pytest.raises(fmd.FmdError) as ei:
+        rts.RtlTcpSourceC("127.0.0.1", srv.port, timeout=2.0)
+    assert ei.value.status == -11 and "RTL0" in str(ei.value)
+
+
 def test_bad_handshake_rejected():
     with pytest.raises(ValueError):
         rts.parse_handshake(b"RTL1" + bytes(8))
@@ -110,7 +147,7 @@ def test_three_rtl_tcp_streams_through_the_sink(fmd, oracle):
             audio[c].append(rows[c])
 
     sink = fmd.Sink(cfg, 3, N, device_ids=[0, 1 % fmd.device_count()], depth=3, on_audio=on_audio)
-    srcs = [rts.RtlTcpSource("127.0.0.1", s.port) for s in servers]
+    srcs = [rts.RtlTcpSource("127.0.0.1", servers[0].port)] + [rts.RtlTcpSourceC("127.0.0.1", s.port) for s in servers[1:]]   # both clients
     n = fmd.pump(srcs, sink)
     assert n == 4                                               # the 5th read is short on every stream
     for s in srcs:
