@@ -83,6 +83,9 @@ int32_t fmo_polar_discriminant(fmo_cplx a, fmo_cplx b);
 int32_t fmo_polar_discriminant_fast(fmo_cplx a, fmo_cplx b);
 /* Demod::fast_atan2 simple_fm.rs:383-405 */
 int32_t fmo_fast_atan2(int32_t y, int32_t x);
+/* Number of samples so far at which the reference's `/` would have panicked (zero divisor after the i32 products of
+ * `a * b.conj()` wrapped: downsample >= 305 with full-scale input only); the oracle returns 0 for them. */
+long fmo_would_panic(void);
 
 /* Demod::fm_demod simple_fm.rs:355-367; returns count, or -1 where the reference
  * asserts (len <= 1, :356). */

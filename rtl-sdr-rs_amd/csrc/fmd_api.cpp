@@ -136,7 +136,7 @@ int choose_tiling(fmd_demod* d, uint32_t kt_req)
     r.kt = kt;
     d->lp_cap = fmd_tile_lp_cap(r);
     d->raw_cap = fmd_tile_raw_cap(r);
-    const size_t lds = (size_t)d->raw_cap + 6u * (size_t)d->lp_cap + 32;
+    const size_t lds = (size_t)d->raw_cap + (r.D > FMD_MAX_DOWNSAMPLE ? 10u : 6u) * (size_t)d->lp_cap + 32;   // i32 pairs beyond downsample 128
     if (lds > 64 * 1024) {
         set_err("tile needs %zu bytes of LDS (kt=%u): rate_out/rate_resample x downsample too large", lds, kt);
         return FMD_ERR_UNSUPPORTED;
@@ -466,8 +466,8 @@ int fmd_demod_new(const fmd_demod_config* config, const fmd_device_config* dev, 
         set_err("need downsample >= 1 and rate_out >= rate_resample >= 1 (simple_fm.rs:421 divides by rate_out/rate_resample)");
         return FMD_ERR_BAD_RATES;
     }
-    if (config->downsample > FMD_MAX_DOWNSAMPLE) {
-        set_err("downsample %u > %u unsupported", config->downsample, FMD_MAX_DOWNSAMPLE);
+    if (config->downsample > FMD_MAX_DOWNSAMPLE_WIDE) {
+        set_err("downsample %u > %u unsupported", config->downsample, FMD_MAX_DOWNSAMPLE_WIDE);
         return FMD_ERR_UNSUPPORTED;
     }
     fmd_demod* d = new (std::nothrow) fmd_demod();

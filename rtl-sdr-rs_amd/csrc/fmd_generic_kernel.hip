@@ -3,9 +3,13 @@
 //
 // The generic kernel fuses every pass of Demod::demodulate (examples/simple_fm.rs:256-269) exactly
 // like the production tile kernel (fmd_tile_kernel.hip) but makes no assumption beyond
-// fmd_ranges_fit32(): any downsample <= 128, any phase per channel, any tiling.  It is what runs
+// fmd_ranges_fit32(): any downsample, any phase per channel, any tiling.  It is what runs
 // when the phase-class plans do not apply (> FMD_MAX_CLASSES distinct phases in one bank, or reduced
-// rates beyond the exact-small-divide range of the tile kernel) and under FMD_FORCE_GENERIC=1.
+// rates beyond the exact-small-divide range of the tile kernel), under FMD_FORCE_GENERIC=1 (experiment build), and for
+// downsample 129 ... 512 (WIDE): there |lp| <= 128 * D no longer fits 16 bits, so the decimated samples stay i32 pairs,
+// and the reference's own arithmetic starts to wrap -- `a * b.conj()` on Complex<i32> (:371,378) beyond downsample 255,
+// `x + yabs` / `yabs - x` in fast_atan2 (:397,399) beyond 128 -- which fmd_mul_conj / fmd_fast_atan2 reproduce as the
+// wrapping 32-bit operations a release build of the reference performs.
 #include "fmd_device.h"
 #include "fmd_kernels.h"
 
@@ -13,12 +17,27 @@ namespace {
 
 using namespace fmd_dev;
 
+// Decimated samples in LDS: packed re | im << 16 (downsample <= 128) or an i32 pair (WIDE).
+template <bool WIDE> struct LpStore;
+template <> struct LpStore<false> {
+    uint32_t* p;
+    __device__ __forceinline__ void put(int i, int re, int im) const { p[i] = pack_lp(re, im); }
+    __device__ __forceinline__ void get(int i, int& re, int& im) const { const uint32_t v = p[i]; re = lp_re(v); im = lp_im(v); }
+};
+template <> struct LpStore<true> {
+    int2* p;
+    __device__ __forceinline__ void put(int i, int re, int im) const { p[i] = make_int2(re, im); }
+    __device__ __forceinline__ void get(int i, int& re, int& im) const { const int2 v = p[i]; re = v.x; im = v.y; }
+};
+
+template <bool WIDE>
 __global__ void __launch_bounds__(FMD_BLOCK_THREADS) fmd_demod_generic_kernel(const FmdLaunch L)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint32_t* const raw_w = reinterpret_cast<uint32_t*>(smem);
-    uint32_t* const lp_pk = reinterpret_cast<uint32_t*>(smem + L.raw_cap);
-    int16_t* const d16 = reinterpret_cast<int16_t*>(smem + L.raw_cap + 4u * L.lp_cap);
+    LpStore<WIDE> lp;
+    lp.p = reinterpret_cast<decltype(lp.p)>(smem + L.raw_cap);
+    int16_t* const d16 = reinterpret_cast<int16_t*>(smem + L.raw_cap + (WIDE ? 8u : 4u) * L.lp_cap);
 
     const uint32_t tid = threadIdx.x;
     const uint32_t c = blockIdx.x / L.tiles;
@@ -71,15 +90,15 @@ __global__ void __launch_bounds__(FMD_BLOCK_THREADS) fmd_demod_generic_kernel(co
             lds_window_sum(raw_w, wofs, fmd_win_begin(r.D, p0, j), fmd_win_end(r.D, p0, j), re, im);
             if (j == 0) { re += st.lp_now_re; im += st.lp_now_im; }
         }
-        lp_pk[i] = pack_lp(re, im);
+        lp.put(i, re, im);
     }
     __syncthreads();
 
     // ---- fm_demod (:355-367): polar discriminator against the predecessor --------------------
     for (int i = tid + 1; i < cnt; i += FMD_BLOCK_THREADS) {
-        const uint32_t a = lp_pk[i], b = lp_pk[i - 1];
-        int cr, ci;
-        fmd_mul_conj(lp_re(a), lp_im(a), lp_re(b), lp_im(b), cr, ci);
+        int ar, ai, br, bi, cr, ci;
+        lp.get(i, ar, ai); lp.get(i - 1, br, bi);
+        fmd_mul_conj(ar, ai, br, bi, cr, ci);
         int pcm;
         if (jfirst + i == 0) {                               // first sample of the call (:359)
             bool g;
@@ -105,9 +124,9 @@ __global__ void __launch_bounds__(FMD_BLOCK_THREADS) fmd_demod_generic_kernel(co
 
     // guarded f64 sample (FmdF64Exc, fmd_kernels.h): the record needs the finished group sums
     if (jfirst < 0 && tid == 0) {
-        const uint32_t a = lp_pk[1], b = lp_pk[0];
-        int cr, ci;
-        fmd_mul_conj(lp_re(a), lp_im(a), lp_re(b), lp_im(b), cr, ci);
+        int ar, ai, br, bi, cr, ci;
+        lp.get(1, ar, ai); lp.get(0, br, bi);
+        fmd_mul_conj(ar, ai, br, bi, cr, ci);
         bool g;
         (void)polar_f64(cr, ci, L.f64_guard, &g);
         if (g) exc_emit(exc_args(L, c, i0r, K, st.now_lpr, d16, jfirst), 0, cr, ci);
@@ -127,7 +146,7 @@ __global__ void __launch_bounds__(FMD_BLOCK_THREADS) fmd_demod_generic_kernel(co
         if (M == 0) { tr += st.lp_now_re; ti += st.lp_now_im; }
         ns_.lp_now_re = tr; ns_.lp_now_im = ti;
         if (M == 0) { ns_.demod_pre_re = st.demod_pre_re; ns_.demod_pre_im = st.demod_pre_im; }
-        else { const uint32_t l = lp_pk[cnt - 1]; ns_.demod_pre_re = lp_re(l); ns_.demod_pre_im = lp_im(l); }
+        else { int lr, li; lp.get(cnt - 1, lr, li); ns_.demod_pre_re = lr; ns_.demod_pre_im = li; }
         ns_.reserved = 0;
         L.st_out[c] = ns_;
         if (L.out_len) L.out_len[c] = K;
@@ -194,7 +213,8 @@ __global__ void __launch_bounds__(256) fmd_synth_kernel(const FmdSynthLaunch S)
 
 size_t fmd_generic_lds_bytes(const FmdLaunch& L)
 {
-    return ((size_t)L.raw_cap + 4u * (size_t)L.lp_cap + 2u * (size_t)L.lp_cap + 15u) & ~(size_t)15u;
+    const size_t per = L.r.D > FMD_MAX_DOWNSAMPLE ? 8u : 4u;          // i32 pairs beyond downsample 128
+    return ((size_t)L.raw_cap + per * (size_t)L.lp_cap + 2u * (size_t)L.lp_cap + 15u) & ~(size_t)15u;
 }
 
 hipError_t fmd_launch_generic(const FmdLaunch& L, hipStream_t stream)
@@ -202,7 +222,8 @@ hipError_t fmd_launch_generic(const FmdLaunch& L, hipStream_t stream)
     const size_t lds = fmd_generic_lds_bytes(L);
     const uint64_t blocks = (uint64_t)L.n_channels * L.tiles;
     if (blocks == 0 || blocks > 0x7FFFFFFFull) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(fmd_demod_generic_kernel, dim3((uint32_t)blocks), dim3(FMD_BLOCK_THREADS), lds, stream, L);
+    if (L.r.D > FMD_MAX_DOWNSAMPLE) hipLaunchKernelGGL(fmd_demod_generic_kernel<true>, dim3((uint32_t)blocks), dim3(FMD_BLOCK_THREADS), lds, stream, L);
+    else hipLaunchKernelGGL(fmd_demod_generic_kernel<false>, dim3((uint32_t)blocks), dim3(FMD_BLOCK_THREADS), lds, stream, L);
     return hipGetLastError();
 }
 

@@ -34,7 +34,8 @@
 #define FMD_HD inline
 #endif
 
-#define FMD_MAX_DOWNSAMPLE 128u        /* |lp| <= 128*D <= 16384 fits i16; no i32 overflow in fm_demod */
+#define FMD_MAX_DOWNSAMPLE 128u        /* |lp| <= 128*D <= 16384 fits i16; no i32 overflow in fm_demod: the tile kernel's domain */
+#define FMD_MAX_DOWNSAMPLE_WIDE 512u   /* 129 ... 512 (optimal_settings for rates down to 1957 Hz, simple_fm.rs:190): generic kernel, i32 samples */
 #define FMD_MAX_RATE_REDUCED (1u << 24)
 
 // Constants derived once per handle from DemodConfig (simple_fm.rs:179-185).

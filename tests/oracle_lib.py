@@ -63,6 +63,8 @@ class Oracle:
         lib.fmo_low_pass_complex.restype = C.c_size_t
         lib.fmo_fast_atan2.argtypes = [C.c_int32, C.c_int32]
         lib.fmo_fast_atan2.restype = C.c_int32
+        lib.fmo_would_panic.argtypes = []
+        lib.fmo_would_panic.restype = C.c_long
         lib.fmo_polar_discriminant.argtypes = [Cplx, Cplx]
         lib.fmo_polar_discriminant.restype = C.c_int32
         lib.fmo_polar_discriminant_fast.argtypes = [Cplx, Cplx]

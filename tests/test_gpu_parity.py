@@ -212,7 +212,7 @@ def test_error_behaviour(fmd):
     buf = np.zeros(8192, np.uint8)
     rc = fmd.lib().fmd_demod_demodulate(d._h, buf.ctypes.data, buf.size, out.ctypes.data, 1, C.byref(n))
     assert rc == -5
-    for bad in [(6, 32000, 170000), (0, 170000, 32000), (6, 170000, 0), (129, 8000, 8000)]:
+    for bad in [(6, 32000, 170000), (0, 170000, 32000), (6, 170000, 0), (513, 1950, 1950)]:                      # 129 ... 512: the generic kernel (test_downsample_129_to_512)
         with pytest.raises(fmd.FmdError):
             fmd.Demod(mkcfg(fmd, *bad) if bad[0] else fmd.DemodConfig(bad[1], bad[1], bad[2], 0, 1))
     with pytest.raises(fmd.FmdError):
@@ -510,6 +510,43 @@ def test_large_downsample_full_scale(fmd, oracle, D, fast, slow):
             blk[c] = np.concatenate(segs)
         blocks.append(blk)
     check_stream(fmd, oracle, D, fast, slow, blocks, n_channels=nch)
+
+
+@pytest.mark.parametrize("D,fast,slow,kind", [(129, 7752, 3876, "full"), (200, 5000, 5000, "full"), (255, 3922, 1000, "full"),
+                                              (304, 3290, 3290, "full"), (400, 2500, 1250, "full"), (512, 1957, 1957, "random"), (512, 1957, 1957, "full"),
+                                              (512, 1957, 600, "dc")])
+def test_downsample_129_to_512(fmd, oracle, D, fast, slow, kind):
+    """optimal_settings(f, rate) gives downsample 1_000_000 / rate + 1 (simple_fm.rs:190): 129 ... 512 for rates from 7812
+    down to 1957 Hz.  Those run the generic kernel with i32 decimated samples, and the reference's own i32 arithmetic
+    starts to wrap there -- `x + yabs` in fast_atan2 beyond 128, the complex product beyond 255 -- which must be
+    reproduced as the wrapping operations of a release build (the oracle: -fwrapv).  "full": rotated full-scale DC of
+    either sign with abrupt flips plus random data (the largest products); "random" / "dc": the same ingredients one at a
+    time at the factors where some full-scale mixtures make the REFERENCE panic (zero divisor after the wrap, downsample
+    >= 305): the oracle counts such samples and the test asserts there were none."""
+    rng = np.random.default_rng(D)
+    pos = np.array([255, 255, 0, 255, 0, 0, 255, 0], np.uint8)        # rotate_90 + centre -> (+128, +128) every sample
+    neg = 255 - pos                                                   # -> (-127, -127)
+    nch = 3
+    panics0 = oracle.lib.fmo_would_panic()
+    blocks = []
+    for i in range(3):
+        n = 8 * int(rng.integers(5 * D, 9 * D))
+        blk = np.empty((nch, n), np.uint8)
+        for c in range(nch):
+            segs, left = [], n
+            while left > 0:
+                m = min(left, 8 * int(rng.integers(1, 2 * D)))
+                k = int(rng.integers(0, 3)) if kind == "full" else (2 if kind == "random" else int(rng.integers(0, 2)))
+                segs.append(np.tile(pos if k == 0 else neg, m // 8) if k < 2 else rng.integers(0, 256, m, dtype=np.uint8))
+                left -= m
+            blk[c] = np.concatenate(segs)
+        blocks.append(blk)
+    check_stream(fmd, oracle, D, fast, slow, blocks, n_channels=nch)
+    assert oracle.lib.fmo_would_panic() == panics0                    # the reference itself is defined on these inputs
+    if D == 512:
+        with pytest.raises(fmd.FmdError) as ei:
+            fmd.DemodBank(mkcfg(fmd, 513, fast, slow), 1)
+        assert ei.value.status == -6                                   # FMD_ERR_UNSUPPORTED beyond 512
 
 
 @pytest.mark.parametrize("D,fast,slow,block", [(6, 170000, 32000, 262144), (10, 240000, 32000, 262144), (10, 240000, 32000, 4096),
