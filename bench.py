@@ -46,7 +46,7 @@ PMC_SUMMARY = os.path.join("profiles", "r03_pmc_summary.json")
 
 # what the headline kernel is built from (the FIR kernels, the sink and the CLI do not enter it)
 HEADLINE_SOURCES = ("fmd_tile_kernel.hip", "fmd_kernels.h", "fmd_device.h", "fmd_index.h", "fmd_host.h", "fmd_internal.h",
-                    "fmd_api.cpp")
+                    "fmd_boxcar_mfma.h", "fmd_api.cpp")
 
 
 def kernel_source_hash():
