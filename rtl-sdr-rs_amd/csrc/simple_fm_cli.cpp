@@ -11,6 +11,11 @@
 // file k goes to <prefix>.<k>.s16 (-o prefix, default "audio") and the run ends with the shortest file.  With -g N the
 // same goes through the pipelined multi-GPU sink (fmd_sink_*): channels split over N devices, byte-identical output.
 //
+// Live mode, -t host:port: the example with READ_FROM_FILE = false (:51-64, receive() :89-132, process() :135-170) with
+// the dongle behind an rtl_tcp server (the reference's own examples/rtl_tcp.rs): config_sdr's settings (:217-229) go out
+// as rtl_tcp commands, DEFAULT_BUF_LENGTH blocks come back through fm::RtlTcpSource::read_sync, a short read ends the run
+// with the example's "samples lost" message (:122-125).
+//
 // EOF policy (the reference ignores the read count and never terminates at EOF): only COMPLETE
 // blocks are demodulated; a trailing partial block is dropped with a note on stderr.  Logging goes to stderr
 // because stdout carries audio (:37-38).
@@ -18,6 +23,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <string>
 #include <vector>
 
 #include "demod.hpp"
@@ -50,7 +56,7 @@ static int run_sink(const std::vector<const char*>& paths, const char* prefix, u
             uint8_t* slot = sink.acquire();
             bool full = true;
             for (size_t c = 0; c < C && full; ++c) full = fread(slot + c * N, 1, N, in[c]) == N;
-            if (!full) break;                                   // the shortest file ends the run; partial blocks dropped
+            if (!full) { sink.release(); break; }               // the shortest file ends the run; partial blocks dropped
             sink.submit();
         }
         sink.drain();
@@ -100,6 +106,48 @@ static int run_bank(const std::vector<const char*>& paths, const char* prefix, u
     return rc;
 }
 
+// receive() + process() of the example over rtl_tcp (-t host:port)
+static int run_rtl_tcp(const char* hostport, uint32_t freq, uint32_t rate, uint32_t resample, size_t max_blocks)
+{
+    std::string host(hostport);
+    uint16_t port = 1234;
+    const size_t colon = host.rfind(':');
+    if (colon != std::string::npos) { port = (uint16_t)atoi(host.c_str() + colon + 1); host.resize(colon); }
+    try {
+        const auto settings = fm::optimal_settings(freq, rate, resample);           // :48
+        const fm::DemodConfig& dc = settings.second;
+        fm::RtlTcpSource sdr(host, port);
+        fprintf(stderr, "rtl_tcp %s:%u tuner type %u, %u gains\n", host.c_str(), (unsigned)port, sdr.tuner_type(), sdr.gain_count());
+        sdr.set_tuner_gain_auto();                                                   // config_sdr, :217-229
+        sdr.set_bias_tee(false);
+        sdr.set_center_freq(settings.first.capture_freq);
+        sdr.set_sample_rate(settings.first.capture_rate);
+        fprintf(stderr, "Oversampling input by: %ux\n", dc.downsample);            // :138
+        fprintf(stderr, "Output at %u Hz\n", dc.rate_in);                          // :139
+        fm::Demod demod(dc);                                                         // :137
+        std::vector<uint8_t> buf(fm::DEFAULT_BUF_LENGTH);
+        size_t loops = 0;
+        std::chrono::duration<double> total(0);
+        while (max_blocks == 0 || loops < max_blocks) {
+            const size_t n = sdr.read_sync(buf.data(), buf.size());                  // :116
+            if (n < buf.size()) {                                                    // :122-125
+                fprintf(stderr, "Short read (%zu bytes), samples lost, exiting!\n", n);
+                break;
+            }
+            const auto t0 = std::chrono::steady_clock::now();
+            const std::vector<int16_t> audio = demod.demodulate(buf);               // :153
+            total += std::chrono::steady_clock::now() - t0;
+            fm::output(audio);                                                       // :156
+            ++loops;
+        }
+        if (loops) fprintf(stderr, "Average processing time: %.2fms (%zu loops)\n", 1e3 * total.count() / (double)loops, loops);   // :162-168
+    } catch (const fm::Error& e) {
+        fprintf(stderr, "error: %s\n", e.what());
+        return 1;
+    }
+    return 0;
+}
+
 int main(int argc, char** argv)
 {
     uint32_t rate = 170000, resample = 32000, freq = 94900000;
@@ -107,6 +155,8 @@ int main(int argc, char** argv)
     int gpus = 0;                                            // -g N: several files through the pipelined sink on N GPUs
     const char* path = nullptr;
     const char* prefix = "audio";
+    const char* rtl_tcp = nullptr;                           // -t host:port: live mode over rtl_tcp
+    size_t max_blocks = 0;                                   // -n: stop after this many blocks (live mode; 0 = until the stream ends)
     std::vector<const char*> paths;
     for (int i = 1; i < argc; ++i) {
         if (!strcmp(argv[i], "-s") && i + 1 < argc) rate = (uint32_t)strtoul(argv[++i], nullptr, 10);
@@ -114,13 +164,17 @@ int main(int argc, char** argv)
         else if (!strcmp(argv[i], "-f") && i + 1 < argc) freq = (uint32_t)strtoul(argv[++i], nullptr, 10);
         else if (!strcmp(argv[i], "-o") && i + 1 < argc) prefix = argv[++i];
         else if (!strcmp(argv[i], "-g") && i + 1 < argc) gpus = atoi(argv[++i]);
+        else if (!strcmp(argv[i], "-t") && i + 1 < argc) rtl_tcp = argv[++i];
+        else if (!strcmp(argv[i], "-n") && i + 1 < argc) max_blocks = strtoul(argv[++i], nullptr, 10);
         else if (!strcmp(argv[i], "-b") && i + 1 < argc) { per_launch = strtoul(argv[++i], nullptr, 10); if (!per_launch) per_launch = 1; }
         else if (!strcmp(argv[i], "-h") || !strcmp(argv[i], "--help")) {
             fprintf(stderr, "usage: %s [-f freq_hz] [-s sample_rate_hz] [-r resample_hz] [-b blocks_per_launch] <capture.bin | ->\n"
-                            "       %s [-s ...] [-r ...] [-o prefix] [-g n_gpus] <a.bin> <b.bin> ...   (one channel per file)\n", argv[0], argv[0]);
+                            "       %s [-s ...] [-r ...] [-o prefix] [-g n_gpus] <a.bin> <b.bin> ...   (one channel per file)\n"
+                            "       %s [-f freq_hz] [-s ...] [-r ...] [-n blocks] -t host:port            (live: IQ from an rtl_tcp server)\n", argv[0], argv[0], argv[0]);
             return 0;
         } else paths.push_back(argv[i]);
     }
+    if (rtl_tcp) return run_rtl_tcp(rtl_tcp, freq, rate, resample, max_blocks);
     if (paths.empty()) { fprintf(stderr, "missing input file (use - for stdin)\n"); return 2; }
     if (paths.size() > 1 && gpus > 0) return run_sink(paths, prefix, freq, rate, resample, gpus);
     if (paths.size() > 1) return run_bank(paths, prefix, freq, rate, resample);

@@ -80,3 +80,23 @@ def test_cli_bank_mode_one_channel_per_file(fmd, oracle, tmp_path):
             a = np.fromfile("%s.%d.s16" % (prefix2, k), dtype=np.int16)
             b = np.fromfile("%s.%d.s16" % (prefix, k), dtype=np.int16)
             assert np.array_equal(a, b), (g, k)
+
+
+def test_cli_live_mode_over_rtl_tcp(fmd, oracle):
+    """-t host:port: the example's live path (receive + process, simple_fm.rs:89-170) with the dongle behind an rtl_tcp
+    server: config_sdr's four settings arrive as commands, the audio equals the oracle's over the complete blocks, and
+    the short read at the end of the stream ends the run with the example's message (:122-125)."""
+    from test_rtl_tcp_source import FakeServer
+    from rtl_sdr_rs_amd import rtl_tcp_source as rts
+    N = fmd.DEFAULT_BUF_LENGTH
+    data = fmd.synth.synth_iq(1, 3 * N + 5000, seed=77, amplitude=70, dev_q32=int(75000 / 1020000 * 2**32), mod_period=1020)[0]
+    srv = FakeServer(data.tobytes())
+    p = subprocess.run([CLI, "-t", "127.0.0.1:%d" % srv.port], capture_output=True, timeout=120)
+    srv.thread.join(timeout=5)
+    assert p.returncode == 0, p.stderr.decode()
+    _, cfg = oracle.optimal_settings(94_900_000, 170_000)
+    exp = oracle_file_mode(oracle, cfg, data[:3 * N], N)
+    assert np.array_equal(np.frombuffer(p.stdout, dtype=np.int16), exp)
+    assert b"Short read (5000 bytes), samples lost" in p.stderr and b"(3 loops)" in p.stderr
+    for cmd in ((rts.CMD_SET_GAIN_MODE, 0), (rts.CMD_SET_BIAS_TEE, 0), (rts.CMD_SET_FREQUENCY, 95_155_000), (rts.CMD_SET_SAMPLE_RATE, 1_020_000)):
+        assert cmd in srv.commands, cmd
