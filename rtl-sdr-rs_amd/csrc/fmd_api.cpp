@@ -69,6 +69,10 @@ struct fmd_demod {
     uint32_t C = 0;
     int device = 0;
     uint32_t lp_cap = 0, raw_cap = 0;
+    // register-streaming kernel (fmd_demod_stream_kernel: even downsample <= 16, whole-dword windows): its own, larger tiling
+    bool stream_ok = false;
+    FmdRates rs{};                        // r with the streaming kernel's audio samples per tile
+    uint32_t lp_cap_s = 0;
     uint32_t block_ns = 0;                // fmd_demod_set_block_len: samples per reference call inside one launch
     bool force_generic = false;
     uint32_t xcd_swizzle = 2;             // block -> (channel, tile) mapping (FMD_XCD, experiment build)
@@ -181,7 +185,7 @@ bool tile_kernel_ok(const fmd_demod* d)
 }
 
 // Validates a call; fills one plan per class and the grid's tiles-per-channel.
-int plan_call(const fmd_demod* d, size_t nbytes, size_t out_cap, std::vector<FmdClassPlan>& plans, uint32_t* tiles)
+int plan_call(const fmd_demod* d, const FmdRates& r, size_t nbytes, size_t out_cap, std::vector<FmdClassPlan>& plans, uint32_t* tiles)
 {
     if (nbytes % 8 != 0) { set_err("nbytes %% 8 != 0 (simple_fm.rs:286 would panic)"); return FMD_ERR_BAD_LENGTH; }
     const uint64_t ns = nbytes / 2;
@@ -195,14 +199,14 @@ int plan_call(const fmd_demod* d, size_t nbytes, size_t out_cap, std::vector<Fmd
             return FMD_ERR_UNSUPPORTED;
         }
     }
-    if (!fmd_ranges_fit32(d->r, ns)) {
+    if (!fmd_ranges_fit32(r, ns)) {
         set_err("call of %zu bytes exceeds the 32-bit index range for these rates", nbytes);
         return FMD_ERR_UNSUPPORTED;
     }
     uint32_t tmax = 1;
     plans.resize(d->classes.size());
     for (size_t k = 0; k < d->classes.size(); ++k) {
-        const FmdClassPlan P = fmd_make_plan(d->r, d->classes[k].p0, d->classes[k].i0r, (uint32_t)ns);
+        const FmdClassPlan P = fmd_make_plan(r, d->classes[k].p0, d->classes[k].i0r, (uint32_t)ns);
         if (P.M < 2) { set_err("%u decimated samples (simple_fm.rs:356 asserts > 1)", P.M); return FMD_ERR_TOO_SHORT; }
         if (P.K > out_cap) { set_err("a channel produces %u samples, out_cap %zu", P.K, out_cap); return FMD_ERR_CAPACITY; }
         plans[k] = P;
@@ -227,24 +231,29 @@ void advance_classes(fmd_demod* d, size_t nbytes, const std::vector<FmdClassPlan
 }
 
 int enqueue(fmd_demod* d, const void* d_iq, size_t nbytes, void* d_out, size_t out_cap, void* d_out_len,
-            hipStream_t stream)
+            hipStream_t stream, bool allow_stream = true)
 {
     std::vector<FmdClassPlan> plans;
     uint32_t tiles = 1;
-    int rc = plan_call(d, nbytes, out_cap, plans, &tiles);
+    // the register-streaming kernel: one phase class at an even boxcar phase (whole-dword windows), one reference call per launch
+    const bool stream_now = allow_stream && d->stream_ok && d->C >= 8u && d->block_ns == 0u && d->classes.size() == 1 && (d->classes[0].p0 & 1u) == 0u &&
+                            nbytes >= 64u * d->r.D && !d->force_generic;
+    const FmdRates& rr = stream_now ? d->rs : d->r;
+    int rc = plan_call(d, rr, nbytes, out_cap, plans, &tiles);
     if (rc) return rc;
     if (((uintptr_t)d_iq & 15u) != 0) { set_err("d_iq must be 16-byte aligned"); return FMD_ERR_INVALID_ARG; }
     FmdLaunch L{};
     L.iq = static_cast<const uint8_t*>(d_iq);
     L.chan_stride = nbytes;
     L.total_bytes = (uint64_t)nbytes * d->C;
-    L.r = d->r;
+    L.r = rr;
+    L.stream = stream_now ? 1u : 0u;
     L.ns = (uint32_t)(nbytes / 2);
     L.block_ns = d->block_ns;
     L.xcd_swizzle = d->xcd_swizzle;               // 2 (default): contiguous eighth of the channels per XCD; 0: plain
     L.n_channels = d->C;
     L.tiles = tiles;
-    L.lp_cap = d->lp_cap;
+    L.lp_cap = stream_now ? d->lp_cap_s : d->lp_cap;
     L.raw_cap = d->raw_cap;
     L.st_in = d->d_state[d->cur];
     L.st_out = d->d_state[d->cur ^ 1];
@@ -264,7 +273,7 @@ int enqueue(fmd_demod* d, const void* d_iq, size_t nbytes, void* d_out, size_t o
         if (eo != hipSuccess) { set_err("stream ordering failed: %s", hipGetErrorString(eo)); return FMD_ERR_HIP; }
     }
     if (tile_kernel_ok(d)) {
-        const FmdRates& r = d->r;
+        const FmdRates& r = rr;
         L.tl = fmd_make_tiling(r);
         L.Qt = L.tl.Qt;
         L.fa = r.fr / r.sr; L.fb = r.fr % r.sr;
@@ -288,7 +297,10 @@ int enqueue(fmd_demod* d, const void* d_iq, size_t nbytes, void* d_out, size_t o
         L.block_threads = d->block_threads;
         L.bx_amat = d->d_bx_amat;
         L.fast = d->allow_fast;               // fmd_launch_tile decides (fmd_fast_geometry)
-        HIP_TRY(fmd_launch_tile(L, stream));
+        const hipError_t le = fmd_launch_tile(L, stream);
+        if (le == hipErrorNotSupported && stream_now)        // no table / closed-form geometry for this call: the LDS kernel with its own tiling
+            return enqueue(d, d_iq, nbytes, d_out, out_cap, d_out_len, stream, false);
+        HIP_TRY(le);
     } else {
         HIP_TRY(fmd_launch_generic(L, stream));
     }
@@ -494,6 +506,37 @@ int fmd_demod_new(const fmd_demod_config* config, const fmd_device_config* dev, 
     d->allow_fast = fmd_knob_u32("FMD_FAST", 2);
     int rc = choose_tiling(d, kt_env);
     if (rc) { delete d; return rc; }
+    // Register-streaming kernel (fmd_demod_stream_kernel): downsample 2 and 4, where a lane's two adjacent windows are ONE
+    // 8- / 16-byte load and the 64 lanes of a wave read 512 / 1024 contiguous bytes per round (at 6, 10, 12 a lane's span
+    // is 24 / 40 / 48 bytes: strided 16-byte loads touch 1.5 - 3 x the cache lines and measured 25 - 70 % SLOWER than the
+    // LDS-DMA kernel).  LDS only holds the discriminator samples there, so the tile is sized for the work per block: the
+    // least wave-instructions per audio sample under the kernel's quantisation -- whole rounds of 127 decimated samples
+    // per wave (at most FMD_STREAM_MAX_ROUNDS, straight-line code), the busiest of the 4 waves sets the pace, one
+    // resampler pass per 256 audio samples, a fixed cost per tile.
+    d->stream_ok = false;
+    if ((r.D == 2u || r.D == 4u) && d->block_threads == 256u && fmd_knob_u32("FMD_STREAM", 1) != 0u) {
+        FmdRates rs = r;
+        uint32_t kts = fmd_knob_u32("FMD_KT_STREAM", 0);
+        const uint32_t cap_cnt = 4u * 127u * FMD_STREAM_MAX_ROUNDS - 8u;
+        if (kts == 0u) {
+            double best = 0.0;
+            for (uint32_t k = 64; k <= 4096u; k += 32u) {
+                rs.kt = k;
+                if (fmd_tile_lp_cap(rs) > cap_cnt || (uint64_t)rs.sr * (k + 2) >= (1u << 24)) break;
+                const uint64_t cnt = ((uint64_t)k * r.fr + r.sr - 1) / r.sr + 1;
+                const uint64_t rounds = (cnt + 126) / 127, per_wave = (rounds + 3) / 4, passes = (k + 255) / 256;
+                const double work = (double)per_wave * 4.0 * 100.0 + (double)passes * 4.0 * (70.0 + 6.0 * (double)(r.fr / r.sr)) + 4.0 * 150.0;
+                const double per_audio = work / (double)k;
+                if (kts == 0u || per_audio < best) { best = per_audio; kts = k; }
+            }
+            if (kts == 0u) kts = r.kt;
+        }
+        rs.kt = kts;
+        while (rs.kt > 1u && fmd_tile_lp_cap(rs) > cap_cnt) rs.kt -= 1u;
+        const uint32_t lp = fmd_tile_lp_cap(rs);
+        const bool fits = (uint64_t)rs.sr * (rs.kt + 2) < (1u << 24) && 2ull * (lp + r.fr / r.sr + 3) + 48 <= 60u * 1024u;
+        if (fits && fmd_tile_kernel_supports(rs, 0u)) { d->rs = rs; d->lp_cap_s = lp; d->stream_ok = true; }
+    }
 
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) {
@@ -588,7 +631,7 @@ int fmd_demod_demodulate_batch(fmd_demod* d, const uint8_t* iq, size_t nbytes, i
     int rc;
     {   // validate before touching the staging buffers
         std::vector<FmdClassPlan> plans; uint32_t tiles;
-        rc = plan_call(d, nbytes, out_cap, plans, &tiles);
+        rc = plan_call(d, d->r, nbytes, out_cap, plans, &tiles);
         if (rc) return rc;
     }
     const size_t in_bytes = nbytes * (size_t)d->C;
@@ -741,9 +784,11 @@ int fmd_demod_set_state(fmd_demod* d, uint32_t channel, const fmd_demod_state* s
 int fmd_demod_tiling(const fmd_demod* d, uint32_t* audio_per_tile, uint32_t* lds_bytes, uint32_t* block_threads)
 {
     if (!d) return FMD_ERR_INVALID_ARG;
-    if (audio_per_tile) *audio_per_tile = d->r.kt;
+    const bool streaming = d->stream_ok && d->C >= 8u && d->block_ns == 0u && tile_kernel_ok(d);   // what a bank in one phase class runs
+    if (audio_per_tile) *audio_per_tile = streaming ? d->rs.kt : d->r.kt;
     if (lds_bytes) {
-        FmdLaunch L{}; L.raw_cap = d->raw_cap; L.lp_cap = d->lp_cap; L.fa = d->r.fr / d->r.sr;
+        FmdLaunch L{}; L.raw_cap = d->raw_cap; L.lp_cap = streaming ? d->lp_cap_s : d->lp_cap; L.fa = d->r.fr / d->r.sr; L.r = d->r;
+        L.stream = streaming ? 1u : 0u;
         *lds_bytes = (uint32_t)(tile_kernel_ok(d) ? fmd_tile_lds_bytes(L) : fmd_generic_lds_bytes(L));
     }
     if (block_threads) *block_threads = tile_kernel_ok(d) ? d->block_threads : FMD_BLOCK_THREADS;
@@ -756,6 +801,7 @@ int fmd_demod_set_tiling(fmd_demod* d, uint32_t audio_per_tile)
     const FmdRates saved = d->r; const uint32_t lc = d->lp_cap, rc_ = d->raw_cap;
     int rc = choose_tiling(d, audio_per_tile);
     if (rc) { d->r = saved; d->lp_cap = lc; d->raw_cap = rc_; }
+    else if (audio_per_tile) d->stream_ok = false;           // an explicit tile size means the LDS kernel with exactly that tile
     return rc;
 }
 

@@ -11,6 +11,7 @@
 #ifndef FMD_MAX_CLASSES
 #define FMD_MAX_CLASSES 16       /* phase classes one launch can carry (32-byte plans in the kernel arguments) */
 #endif
+#define FMD_STREAM_MAX_ROUNDS 12  /* register-streaming kernel: wave-rounds of 127 decimated samples per wave and tile (straight-line code) */
 #define FMD_TILE_MAX_LOADS 8      /* 16-byte chunks per thread the tile kernel can stage */
 
 // Device-side error bits (FmdLaunch::err), all "cannot happen" conditions.
@@ -107,6 +108,7 @@ struct FmdLaunch {
     int32_t   f64_skew;       // -DFMD_EXPERIMENT builds only: added to the kernel's value of guarded samples (patch-path test)
     uint32_t dbg;             // ablation bits, honoured only by -DFMD_EXPERIMENT builds (tuning; never shipped)
     uint32_t block_threads;   // one-block-per-tile kernel: 64, 128 or 256 (default) threads
+    uint32_t stream;          // 1: register-streaming kernel (fmd_demod_stream_kernel): no LDS staging, raw_cap unused
     // ---- tile kernel only (phase-class plans; see fmd_index.h) ----
     uint32_t Qt;              // decimated samples per full tile = kt * fr / sr (== tl.Qt)
     FmdTiling tl;             // tiling constants of fmd_tile_fast

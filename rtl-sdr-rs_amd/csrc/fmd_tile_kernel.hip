@@ -142,6 +142,7 @@ __device__ __forceinline__ void lds_dma16(const unsigned char* g, unsigned char*
 // Where a tile's bytes are and where they land in LDS (all wave-uniform).
 struct TileCtx {
     FmdTile T;
+    uint64_t gbase;     // global address of the channel-call's first byte
     uint64_t a0;        // 16-byte aligned global address of the first staged chunk
     uint32_t nchunks;   // 16-byte chunks staged
     int wofs;           // LDS dword index of the call's dword 0 (may be negative)
@@ -162,6 +163,7 @@ __device__ __forceinline__ TileCtx tile_setup(const FmdLaunch& L, uint32_t c, ui
     X.jfirst = X.T.jA - 1;
     X.cnt = X.T.jB - X.jfirst + 1;
     const uint64_t gbase = (uint64_t)(uintptr_t)L.iq + (uint64_t)c * L.chan_stride;
+    X.gbase = gbase;
     const uint64_t gLo = gbase + 2ull * (uint32_t)X.T.nLo;
     const uint64_t gHi = gbase + 2ull * (uint32_t)X.T.nHi;
     X.a0 = gLo & ~15ull;
@@ -378,20 +380,121 @@ __device__ __forceinline__ void mfma_pair_rounds(const BxFrag<DH>& F, const unsi
     }
 }
 
-// Everything after the tile's bytes are visible in LDS.  Contains one __syncthreads().
+// ---- register-streaming rounds (fmd_demod_stream_kernel) ------------------------------------------------------------
+// The adjacent-window rounds with the raw bytes going global memory -> registers, never through LDS: lane l of a round
+// owns windows base + 2 l and base + 2 l + 1, 8 DH CONTIGUOUS bytes of the channel, and the 64 lanes of a wave read
+// 512 DH contiguous bytes per round with one or two 16-byte loads per lane.  A wave keeps P rounds of loads in flight in
+// a ring of register sets (the loop body appears P times, so the ring is indexed at compile time) and computes round k
+// while rounds k + 1 ... k + P - 1 are on their way: load and compute overlap per ROUND inside every wave, instead of
+// per TILE across the 8 blocks a CU can hold.  Bytes in flight per CU: 32 waves x P x 512 DH (196 KB at downsample 6, P =
+// 4) against ~86 KB for 8 LDS tiles of which some are always computing.  LDS only holds the discriminator samples, so a
+// tile can be several times larger (fewer prologues / resampler passes / halos per byte).  Loads beyond the wave's last
+// round are issued against the channel's first bytes (one cache line for the whole wave): the count of outstanding
+// loads stays a compile-time constant, which is what lets hipcc wait with vmcnt(N > 0).
+template <int NDW>
+__device__ __forceinline__ void stream_load(const unsigned char* __restrict__ p, uint32_t (&w)[NDW])
+{
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+    typedef const FMD_AS_GLOBAL u32x4* g4;
+    typedef const FMD_AS_GLOBAL u32x2* g2;
+    typedef const FMD_AS_GLOBAL uint32_t* g1;
+    int u = 0;
+#pragma unroll
+    for (; u + 4 <= NDW; u += 4) {
+        const u32x4 v = __builtin_nontemporal_load((g4)(uintptr_t)(p + 4 * u));
+        w[u] = v.x; w[u + 1] = v.y; w[u + 2] = v.z; w[u + 3] = v.w;
+    }
+    if constexpr (NDW % 4 >= 2) {
+        const u32x2 v = __builtin_nontemporal_load((g2)(uintptr_t)(p + 4 * (NDW & ~3)));
+        w[NDW & ~3] = v.x; w[(NDW & ~3) + 1] = v.y;
+    }
+    if constexpr (NDW % 2 == 1) w[NDW - 1] = __builtin_nontemporal_load((g1)(uintptr_t)(p + 4 * (NDW - 1)));
+}
+
 template <int DH, int NT>
+__device__ __forceinline__ void stream_pair_rounds(const unsigned char* __restrict__ chan, uint32_t nbytes, int16_t* __restrict__ d16,
+                                                   int jfirst, uint32_t hp, int cnt, uint32_t lane, uint32_t wave)
+{
+    constexpr int NW = NT / 64, RS = NW == 1 ? 124 : 127, NDW = 2 * DH;
+    constexpr int P = NDW <= 6 ? 4 : (NDW <= 10 ? 3 : 2);   // rounds in flight per wave (register budget: 64 VGPRs)
+    constexpr int32_t STRIDE = 4 * DH * NW * RS;             // bytes from one round of a wave to its next
+    wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)wave);
+    const int last = cnt - 1;
+    int base = (int)wave * RS;
+    if (base >= last) return;
+    const int jw = jfirst + base;
+    const bool o1 = ((((DH & 1) ? ((uint32_t)jw ^ hp) : hp)) & 1u) != 0u, o2 = o1 != ((DH & 1) != 0);   // wave-uniform (see tile_body)
+    const uint32_t r1A = o1 ? FMD_W_RE_ODD : FMD_W_RE_EVEN, r1B = o1 ? FMD_W_RE_EVEN : FMD_W_RE_ODD;
+    const uint32_t m1A = o1 ? FMD_W_IM_ODD : FMD_W_IM_EVEN, m1B = o1 ? FMD_W_IM_EVEN : FMD_W_IM_ODD;
+    const uint32_t r2A = o2 ? FMD_W_RE_ODD : FMD_W_RE_EVEN, r2B = o2 ? FMD_W_RE_EVEN : FMD_W_RE_ODD;
+    const uint32_t m2A = o2 ? FMD_W_IM_ODD : FMD_W_IM_EVEN, m2B = o2 ? FMD_W_IM_EVEN : FMD_W_IM_ODD;
+    const int c1 = 2 * (o1 ? DH / 2 : (DH + 1) / 2), c2 = 2 * (o2 ? DH / 2 : (DH + 1) / 2);
+    // byte offset of the lane's span within the channel-call, round by round; spans outside the call (the window before
+    // the call's first sample in tile 0, surplus lanes of the last round) are clamped into it: their results are patched
+    // (call start) or never stored
+    int32_t off = 4 * (DH * (jfirst + base + 2 * (int)lane) - (int)hp);
+    const int32_t maxoff = (int32_t)nbytes - 4 * NDW;
+    int fbase = base;                                        // round the next fetch belongs to
+    auto fetch = [&](uint32_t (&w)[NDW]) {
+        const int32_t lim = fbase < last ? maxoff : 0;       // wave-uniform: beyond the last round -> the channel's first bytes
+        const int32_t o = off < 0 ? 0 : (off > lim ? lim : off);   // (v_med3_i32)
+        stream_load<NDW>(chan + (uint32_t)o, w);
+        off += STRIDE; fbase += NW * RS;
+    };
+    auto round = [&](const uint32_t (&w)[NDW], int b) {
+        const int i1 = b + 2 * (int)lane, i2 = i1 + 1;
+        int re1 = DH, im1 = c1, re2 = DH, im2 = c2;
+        uint32_t dead1 = 0, dead2 = 0;
+#pragma unroll
+        for (int u = 0; u < DH; ++u) {
+            const uint32_t wa = w[u] ^ 0x80808080u, wb = w[u + DH] ^ 0x80808080u;    // u8 -> s8 (b - 128)
+            re1 = sdot4(wa, (u & 1) ? r1B : r1A, re1);
+            im1 = sdot4(wa, (u & 1) ? m1B : m1A, im1);
+            re2 = sdot4(wb, (u & 1) ? r2B : r2A, re2);
+            im2 = sdot4(wb, (u & 1) ? m2B : m2A, im2);
+            dead1 = wa; dead2 = wb;
+        }
+        const float ar1 = (float)re1, ai1 = (float)im1, ar2 = (float)re2, ai2 = (float)im2;
+        const float br1 = u2f(wave_shr1_dead(dead1, f2u(ar2))), bi1 = u2f(wave_shr1_dead(dead2, f2u(ai2)));   // second window of lane l - 1
+        const int d1 = disc_f32_c<DH == 1>(ar1, ai1, br1, bi1);
+        const int d2 = disc_f32_c<DH == 1>(ar2, ai2, ar1, ai1);
+        if (lane > 0 && i1 < cnt) d16[i1] = (int16_t)d1;
+        if (i2 < cnt) d16[i2] = (int16_t)d2;
+    };
+    // Straight-line code for up to FMD_STREAM_MAX_ROUNDS rounds per wave (the host sizes the tiles accordingly): in a
+    // loop hipcc's wait-count pass gives up at the back edge and waits for EVERY outstanding load (vmcnt(0)) once per trip,
+    // which stalls the whole ring; unrolled, every round waits for exactly its own register set.
+    uint32_t w[P][NDW];
+#pragma unroll
+    for (int p = 0; p < P; ++p) fetch(w[p]);
+#pragma unroll
+    for (int k = 0; k < FMD_STREAM_MAX_ROUNDS; ++k) {
+        round(w[k % P], base);
+        base += NW * RS;
+        if (base >= last) break;                             // wave-uniform
+        fetch(w[k % P]);
+    }
+}
+
+// Everything after the tile's bytes are visible in LDS.  Contains one __syncthreads().
+// STREAM (fmd_demod_stream_kernel): the raw bytes are not staged -- the rounds read them from global memory straight into
+// registers (stream_pair_rounds), LDS holds the discriminator samples only, and the few one-lane window sums of the
+// call-start patch / the guard record / the state update read the channel in global memory through the same helper
+// (raw_w = the channel-call's first dword, wofs = 0).
+template <int DH, int NT, bool STREAM = false>
 __device__ __forceinline__ void tile_body(const FmdLaunch& L, const TileCtx& X, unsigned char* smem, const BxFrag<DH>& F)
 {
     const FmdRates& r = L.r;
     const FmdClassPlan& P = L.cls[X.cls];
     const FmdTile& T = X.T;
-    const uint32_t* const raw_w = reinterpret_cast<const uint32_t*>(smem);
-    int16_t* const d16 = reinterpret_cast<int16_t*>(smem + L.raw_cap);
+    const uint32_t* const raw_w = STREAM ? reinterpret_cast<const uint32_t*>((uintptr_t)X.gbase) : reinterpret_cast<const uint32_t*>(smem);
+    int16_t* const d16 = reinterpret_cast<int16_t*>(smem + (STREAM ? 0u : L.raw_cap));
 
     const uint32_t tid = threadIdx.x;
     const uint32_t lane = tid & 63u, wave = tid >> 6;
     const uint32_t p0 = P.p0, c = X.c;
-    const int jfirst = X.jfirst, cnt = X.cnt, wofs = X.wofs;
+    const int jfirst = X.jfirst, cnt = X.cnt, wofs = STREAM ? 0 : X.wofs;
     // DH >= 8 (downsample 16, 32, 64 with kernels of their own): whole-dword windows too, but a multiple of 4 dwords long --
     // those take the wrap-around walk below, with the window length a compile-time constant
     const bool fastwin = DH > 0 && DH < 8 && (p0 & 1u) == 0u;   // windows are DH whole dwords
@@ -427,7 +530,11 @@ __device__ __forceinline__ void tile_body(const FmdLaunch& L, const TileCtx& X, 
     // form saves -- unless the windows are 16-byte aligned in LDS (channel buffers aligned, boxcar phase 0: the usual
     // case), where one ds_read_b128 fetches a whole window: then the pair form is taken with two such reads per lane.
     const bool dh4_aligned = DH == 4 && FMD_DH4_B128 && (((wofs - (int)hp) & 3) == 0);     // block-uniform
-    if (F.use) {
+    if constexpr (STREAM) {
+        // (the host only selects this kernel for an even downsample at an even boxcar phase: whole-dword windows)
+        if constexpr (DH == 1 || DH == 2)
+            stream_pair_rounds<DH, NT>(reinterpret_cast<const unsigned char*>((uintptr_t)X.gbase), 2u * L.ns, d16, jfirst, hp, cnt, lane, wave);
+    } else if (F.use) {
         // the boxcar of the adjacent-window rounds on the matrix cores (see mfma_pair_rounds); F.use implies fastwin
         if constexpr (DH > 0 && DH <= (int)FMD_BX_MAX_DH) mfma_pair_rounds<DH, NT>(F, smem, d16, wofs - (int)hp + DH * jfirst, cnt, lane, wave);
     } else if (fastwin && FMD_USE_F32 && FMD_PAIR && (DH != 4 || dh4_aligned)) {
@@ -646,6 +753,24 @@ __device__ __forceinline__ void tile_body(const FmdLaunch& L, const TileCtx& X, 
         d16[1 - jfirst] = (int16_t)fmd_fast_atan2(ci, cr);
     }
     __syncthreads();
+    if constexpr (STREAM) {
+        // The call's LAST decimated sample: a lane's span is two windows, and when the call ends after a lane's FIRST
+        // window the span runs past the channel-call -- stream_pair_rounds clamps its load into the call, which shifts the
+        // lane's bytes.  At most that one sample per channel-call can be affected; one lane redoes it from global memory
+        // (after the barrier: another wave may have stored it) and a second barrier orders the resampler behind it.
+        if (T.last) {                                        // block-uniform
+            if (tid == 0) {
+                const int j = (int)P.M - 1;                  // >= 1: the host guarantees M >= 2
+                int ar, ai, br, bi, cr, ci;
+                lds_window_sum(raw_w, wofs, fmd_win_begin(r.D, p0, j), fmd_win_end(r.D, p0, j), ar, ai);
+                lds_window_sum(raw_w, wofs, fmd_win_begin(r.D, p0, j - 1), fmd_win_end(r.D, p0, j - 1), br, bi);
+                if (j - 1 == 0) { br += st.lp_now_re; bi += st.lp_now_im; }
+                fmd_mul_conj(ar, ai, br, bi, cr, ci);
+                if (j >= 2 || jfirst > 0) d16[j - jfirst] = (int16_t)fmd_fast_atan2(ci, cr);   // (j == 1 in tile 0 is the call-start patch's)
+            }
+            __syncthreads();
+        }
+    }
     // Several reference calls in one launch (fmd_demod_set_block_len): reference call b >= 1 starts at sample
     // b * block_ns, and its first decimated sample -- index (p0 + b * block_ns) / D of this launch -- takes the
     // f64 path against its predecessor (:359).  A tile owns discriminator samples jA .. jB; at most a few
@@ -796,7 +921,7 @@ __device__ __forceinline__ TileCtx fast_ctx(const FmdLaunch& L, const FastAddr& 
     const FmdClassPlan& P = L.cls[0];
     TileCtx X;
     X.c = A.c; X.cls = 0u; X.valid = true; X.whole = A.whole;
-    X.a0 = A.a0; X.nchunks = A.nchunks;
+    X.a0 = A.a0; X.nchunks = A.nchunks; X.gbase = A.gbase;
     X.wofs = (int)((int64_t)(A.gbase - A.a0) >> 2);
     FmdTile& T = X.T;
     const uint32_t t = A.t;
@@ -902,6 +1027,19 @@ __global__ void __launch_bounds__(NT) fmd_demod_tile_kernel(const FmdLaunch L)
     tile_body<DH, NT>(L, X, smem, F);
 }
 
+// ---- register-streaming form: no staging, no staging barrier (see stream_pair_rounds) -------------------------------
+template <int DH, int FAST>
+__global__ void __launch_bounds__(256, 8) fmd_demod_stream_kernel(const FmdLaunch L)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const FastAddr A = fast_addr<FAST>(L);
+    if (A.c >= L.fg.n_channels) return;
+    const TileCtx X = fast_ctx<FAST>(L, A);
+    BxFrag<DH> F;
+    F.use = false; F.o1 = false; F.e = 0;
+    tile_body<DH, 256, true>(L, X, smem, F);
+}
+
 template <int DH>
 void launch_one(const FmdLaunch& L, dim3 g, size_t lds, hipStream_t stream)
 {
@@ -915,6 +1053,10 @@ void launch_one(const FmdLaunch& L, dim3 g, size_t lds, hipStream_t stream)
         case 64: hipLaunchKernelGGL((fmd_demod_tile_kernel<DH, 64, 0>), g, dim3(64), lds, stream, L); break;
 #endif
         default:
+            if constexpr (DH == 1 || DH == 2) {
+                if (L.stream && L.fast == 2u) { hipLaunchKernelGGL((fmd_demod_stream_kernel<DH, 2>), g, dim3(256), lds, stream, L); break; }
+                if (L.stream && L.fast == 1u) { hipLaunchKernelGGL((fmd_demod_stream_kernel<DH, 1>), g, dim3(256), lds, stream, L); break; }
+            }
             if (L.fast == 1u) hipLaunchKernelGGL((fmd_demod_tile_kernel<DH, 256, 1>), g, dim3(256), lds, stream, L);
             else if (L.fast == 2u) hipLaunchKernelGGL((fmd_demod_tile_kernel<DH, 256, 2>), g, dim3(256), lds, stream, L);
             else hipLaunchKernelGGL((fmd_demod_tile_kernel<DH, 256, 0>), g, dim3(256), lds, stream, L);
@@ -927,7 +1069,7 @@ void launch_one(const FmdLaunch& L, dim3 g, size_t lds, hipStream_t stream)
 size_t fmd_tile_lds_bytes(const FmdLaunch& L)
 {
     const size_t glen = (size_t)L.fa + 1u;
-    return (size_t)L.raw_cap + ((2u * ((size_t)L.lp_cap + glen + 1u) + 15u) & ~(size_t)15u) + 16u;
+    return (L.stream ? 0u : (size_t)L.raw_cap) + ((2u * ((size_t)L.lp_cap + glen + 1u) + 15u) & ~(size_t)15u) + 16u;
 }
 
 bool fmd_tile_kernel_supports(const FmdRates& r, uint32_t raw_cap)
@@ -961,7 +1103,7 @@ static uint32_t fmd_fast_geometry(FmdLaunch& L, uint32_t per)
     if (P.nt <= FMD_FAST_ROWS && (tl.Rt != 0u || L.fast != 1u) ) {
         for (uint32_t t = 0; t < P.nt; ++t) {
             const FmdTile T = fmd_tile_fast(r, P, tl, L.ns, t);
-            if ((uint64_t)(T.jB - T.jA + 2) > L.lp_cap || 2ull * (uint64_t)(T.nHi - T.nLo) + 30u > L.raw_cap) return 0u;
+            if ((uint64_t)(T.jB - T.jA + 2) > L.lp_cap || (!L.stream && 2ull * (uint64_t)(T.nHi - T.nLo) + 30u > L.raw_cap)) return 0u;
             L.rows[t] = FmdTileRow{2u * (uint32_t)T.nLo, 2u * (uint32_t)T.nHi, T.jA, T.jB, T.eq, T.er};
         }
         return 2u;
@@ -979,7 +1121,7 @@ static uint32_t fmd_fast_geometry(FmdLaunch& L, uint32_t per)
         const int64_t jA = ja > 0 ? ja : 0, jB = T.last ? (int64_t)P.M - 1 : (int64_t)t * tl.Qt + jB_off;
         const int64_t nLo2 = lo > 0 ? lo : 0, nHi2 = T.last ? (int64_t)ns2 : (int64_t)t * step2 + hi_off2;
         if (jA != T.jA || jB != T.jB || nLo2 != 2ll * T.nLo || nHi2 != 2ll * T.nHi) return 0u;
-        if ((uint64_t)(jB - jA + 2) > L.lp_cap || (uint64_t)(nHi2 - nLo2) + 30u > L.raw_cap) return 0u;
+        if ((uint64_t)(jB - jA + 2) > L.lp_cap || (!L.stream && (uint64_t)(nHi2 - nLo2) + 30u > L.raw_cap)) return 0u;
     }
     g.step2 = (uint32_t)step2; g.lo_off2 = (int32_t)lo_off2; g.hi_off2 = (int32_t)hi_off2;
     g.jA_off = (int32_t)jA_off; g.jB_off = (int32_t)jB_off;
@@ -988,7 +1130,6 @@ static uint32_t fmd_fast_geometry(FmdLaunch& L, uint32_t per)
 
 hipError_t fmd_launch_tile(const FmdLaunch& L, hipStream_t stream)
 {
-    const size_t lds = fmd_tile_lds_bytes(L);
     if (L.n_channels == 0 || L.tiles == 0) return hipErrorInvalidValue;
     const int dh = (L.r.D % 2 == 0) ? (int)(L.r.D / 2) : -(int)L.r.D;
     uint32_t gy = L.n_channels < 65535u ? L.n_channels : 65535u;
@@ -1003,6 +1144,10 @@ hipError_t fmd_launch_tile(const FmdLaunch& L, hipStream_t stream)
         K.xcd_swizzle = 3u;
         K.fast = fmd_fast_geometry(K, per);
     } else K.fast = 0u;
+    // the streaming kernel has the table / closed-form prologue only, and its tiles do not fit the LDS kernel: the caller
+    // plans the call again with the LDS tiling
+    if (K.stream && !K.fast) return hipErrorNotSupported;
+    const size_t lds = fmd_tile_lds_bytes(K);                // (after K.stream is final: the streaming form stages nothing)
     switch (dh) {
         case 1: launch_one<1>(K, g, lds, stream); break;
         case 2: launch_one<2>(K, g, lds, stream); break;
