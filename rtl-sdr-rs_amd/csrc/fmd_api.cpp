@@ -514,7 +514,7 @@ int fmd_demod_new(const fmd_demod_config* config, const fmd_device_config* dev, 
     // per wave (at most FMD_STREAM_MAX_ROUNDS, straight-line code), the busiest of the 4 waves sets the pace, one
     // resampler pass per 256 audio samples, a fixed cost per tile.
     d->stream_ok = false;
-    if ((r.D == 2u || r.D == 4u) && d->block_threads == 256u && fmd_knob_u32("FMD_STREAM", 1) != 0u) {
+    if ((r.D == 2u || r.D == 4u) && d->block_threads == 256u && fmd_knob_u32("FMD_STREAM", 1) != 0u) {   // (knob: A/B in the experiment build)
         FmdRates rs = r;
         uint32_t kts = fmd_knob_u32("FMD_KT_STREAM", 0);
         const uint32_t cap_cnt = 4u * 127u * FMD_STREAM_MAX_ROUNDS - 8u;

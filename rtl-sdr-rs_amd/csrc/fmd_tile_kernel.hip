@@ -391,6 +391,11 @@ __device__ __forceinline__ void mfma_pair_rounds(const BxFrag<DH>& F, const unsi
 // tile can be several times larger (fewer prologues / resampler passes / halos per byte).  Loads beyond the wave's last
 // round are issued against the channel's first bytes (one cache line for the whole wave): the count of outstanding
 // loads stays a compile-time constant, which is what lets hipcc wait with vmcnt(N > 0).
+// Used for downsample 2 and 4 ONLY, where a lane's span is one 8- / 16-byte load and a wave's load instruction reads
+// 512 / 1024 contiguous bytes: +4 ... 11 % over the LDS-DMA kernel (D=4: 65 -> 73 % of the HBM spec).  At 6, 10, 12 the
+// span is 24 / 40 / 48 bytes -- 16-byte loads at that stride touch 1.5 - 3 x the cache lines -- and the kernel measured
+// 25 - 70 % SLOWER; a variant with one window per load and lanes 64 windows apart (perfectly coalesced dwordx3 / dwordx4
+// loads at downsample 6 / 8) measured 2 / 6 % slower than LDS-DMA (profiles/r03_experiments.md).
 template <int NDW>
 __device__ __forceinline__ void stream_load(const unsigned char* __restrict__ p, uint32_t (&w)[NDW])
 {
@@ -753,7 +758,7 @@ __device__ __forceinline__ void tile_body(const FmdLaunch& L, const TileCtx& X, 
         d16[1 - jfirst] = (int16_t)fmd_fast_atan2(ci, cr);
     }
     __syncthreads();
-    if constexpr (STREAM) {
+    if constexpr (STREAM && (DH == 1 || DH == 2)) {
         // The call's LAST decimated sample: a lane's span is two windows, and when the call ends after a lane's FIRST
         // window the span runs past the channel-call -- stream_pair_rounds clamps its load into the call, which shifts the
         // lane's bytes.  At most that one sample per channel-call can be affected; one lane redoes it from global memory
