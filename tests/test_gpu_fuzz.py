@@ -132,3 +132,44 @@ def test_fuzz_several_reference_calls_per_launch(fmd, oracle):
                 assert gpu_state(bank, c) == oracle.state_of(obank[c]), (D, fast, slow, block, B, c)
         bank.close()
         done += ok
+
+
+def test_fuzz_streaming_kernel(fmd, oracle):
+    """Downsample 2 and 4 with >= 8 channels run the register-streaming kernel (fmd_demod_stream_kernel: global memory ->
+    registers, no LDS staging, tiles of ~1000 audio samples): random rates, 8 ... 40 channels, calls from a fraction of a
+    tile to several tiles (and one reference-sized buffer), random / full-scale / near-silent / synthetic data, boxcar
+    phases 0 and 2, the clamped spans at both ends of a call, state after every call."""
+    n_cases = max(6, int(os.environ.get("FMD_FUZZ_CASES", "40")) // 3)
+    rng = np.random.default_rng(int(os.environ.get("FMD_FUZZ_SEED", "20260101")) + 11)
+    if not os.environ.get("FMD_LIB"):
+        # the kernel under test is the one that runs: a bank of >= 8 channels reports the streaming kernel's tiling (larger
+        # tiles, LDS for the discriminator samples only), a small bank the LDS-DMA kernel's
+        small, large = fmd.DemodBank(mkcfg(fmd, 4, 256000, 48000), 2).tiling(), fmd.DemodBank(mkcfg(fmd, 4, 256000, 48000), 8).tiling()
+        assert large["audio_per_tile"] > 2 * small["audio_per_tile"] and large["lds_bytes"] < small["lds_bytes"], (small, large)
+    for case in range(n_cases):
+        D = int(rng.choice([2, 4]))
+        slow = int(rng.choice(RATES))
+        fast = max(slow, int(slow * rng.uniform(1.0, 9.0)) if rng.random() < 0.7 else int(rng.choice([256000, 500000, 300000, 64000, 250000])))
+        nch = int(rng.integers(8, 41))
+        blocks = []
+        for k in range(int(rng.integers(2, 5))):
+            big = rng.random() < 0.35
+            n = 8 * int(rng.integers(4000, 40000)) if big else 8 * int(rng.integers(max(1, D // 2), 900))
+            if case == 0 and k == 0:
+                n = fmd.DEFAULT_BUF_LENGTH
+            mode = rng.random()
+            if mode < 0.5:
+                blk = rng.integers(0, 256, (nch, n), dtype=np.uint8)
+            elif mode < 0.7:
+                blk = np.where(rng.integers(0, 2, (nch, n)) > 0, 255, 0).astype(np.uint8)
+            elif mode < 0.85:
+                blk = rng.integers(126, 131, (nch, n)).astype(np.uint8)
+            else:
+                blk = fmd.synth.synth_iq(nch, n, seed=int(rng.integers(1, 1 << 30)), amplitude=int(rng.integers(1, 121)))
+            blocks.append(blk)
+        try:
+            check_stream(fmd, oracle, D, fast, slow, blocks, n_channels=nch)
+        except fmd.FmdError as e:
+            assert e.status in (-3, -5, -6), (D, fast, slow, nch, e)
+        except AssertionError as e:
+            raise AssertionError("case D=%d fast=%d slow=%d nch=%d sizes=%s: %s" % (D, fast, slow, nch, [b.shape[1] for b in blocks], e))
