@@ -62,22 +62,12 @@ def test_oracle_fir_equals_numpy_convolution(oracle, T, M):
     assert got.shape == exp.shape and np.array_equal(got, exp)
 
 
-@pytest.mark.gpu
-@pytest.mark.parametrize("form", ["mfma", "mfma_swz", "valu"])
-@pytest.mark.parametrize("T,M", [(127, 8), (6, 6), (10, 10), (5, 2), (16, 16), (33, 4), (1, 2), (64, 6), (255, 32),
-                                 (300, 8), (1024, 2), (129, 64), (77, 66), (31, 128)])
-def test_gpu_fir_matches_oracle(fmd, oracle, request, form, T, M):
-    """Both kernel forms (matrix-core form = default for decim <= 64, VALU form beyond), streaming over ragged calls;
-    shapes cover one and several K passes, both window parities, decim > 64.  Forcing the VALU form for small decim
-    (FMD_FIR_MFMA=0) and the conflict-free LDS layout (FMD_FIR_SWZ=1) are knobs of the -DFMD_EXPERIMENT build: those
-    cases re-run themselves in a child process on that library."""
-    if form == "valu" and M <= 64 and run_in_exp_child(request, {"FMD_FIR_MFMA": "0"}):
-        return
-    if form == "mfma_swz":                                        # conflict-free LDS layout (decim 8 only; off by default)
-        if M != 8:
-            pytest.skip("the swizzled layout exists for decim 8 only")
-        if run_in_exp_child(request, {"FMD_FIR_SWZ": "1"}):
-            return
+FIR_SHAPES = [(127, 8), (6, 6), (10, 10), (5, 2), (16, 16), (33, 4), (1, 2), (64, 6), (255, 32),
+              (300, 8), (1024, 2), (129, 64), (77, 66), (31, 128)]
+
+
+def fir_stream_case(fmd, oracle, T, M):
+    """One FIR shape streamed over ragged calls against the oracle FIR."""
     rng = np.random.default_rng(T * 7 + M)
     taps = np.ones(T, np.int16) if T == M else rng.integers(-2047, 2048, T).astype(np.int16)
     nch = 5
@@ -93,12 +83,34 @@ def test_gpu_fir_matches_oracle(fmd, oracle, request, form, T, M):
         got = bank.filter_batch(iq)
         for c in range(nch):
             exp = oracle.fir_filter(hs[c], iq[c])
-            assert got[c].shape == exp.shape, (call, c, got[c].shape, exp.shape)
-            assert np.array_equal(got[c], exp), (call, c)
+            assert got[c].shape == exp.shape, (T, M, call, c, got[c].shape, exp.shape)
+            assert np.array_equal(got[c], exp), (T, M, call, c)
     for h in hs:
         oracle.lib.fmo_fir_free(h)
     bank.reset()
     assert bank.filter_batch(np.zeros((nch, 8), np.uint8)).shape[1] == ((4 - T) // M + 1 if T <= 4 else 0)   # after reset
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("T,M", FIR_SHAPES)
+def test_gpu_fir_matches_oracle(fmd, oracle, T, M):
+    """What the shipped library selects by itself: the matrix-core form for decim <= 64, the VALU form beyond; shapes cover
+    one and several K passes, both window parities, decim > 64."""
+    fir_stream_case(fmd, oracle, T, M)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("form", ["valu", "mfma_swz"])
+def test_gpu_fir_forced_forms(fmd, oracle, request, form):
+    """The VALU form forced for small decim (FMD_FIR_MFMA=0) and the conflict-free LDS layout of the matrix-core form
+    (FMD_FIR_SWZ=1, decim 8 only) are knobs of the -DFMD_EXPERIMENT build: each form re-runs itself ONCE in a child process
+    on that library and walks through all its shapes there."""
+    if run_in_exp_child(request, {"FMD_FIR_MFMA": "0"} if form == "valu" else {"FMD_FIR_SWZ": "1"}):
+        return
+    for T, M in FIR_SHAPES:
+        if form == "mfma_swz" and M != 8:
+            continue
+        fir_stream_case(fmd, oracle, T, M)
 
 
 @pytest.mark.gpu
