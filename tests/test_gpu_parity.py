@@ -379,6 +379,20 @@ def test_config5_shape_on_one_gpu(fmd, oracle):
         assert not np.array_equal(first_audio[r], first_audio[0]), r
 
 
+@pytest.mark.parametrize("D,fast,slow", [(4, 256000, 48000), (4, 192000, 48000), (2, 500000, 32000)])
+def test_streaming_kernel_long_calls(fmd, oracle, D, fast, slow):
+    """Downsample 2 / 4 with >= 8 channels (the register-streaming kernel) and calls of several MiB per channel: more tiles
+    than the per-tile table holds.  192 k -> 48 k has tiles that repeat exactly (closed-form geometry: the streaming kernel
+    keeps running), 256 k -> 48 k and 500 k -> 32 k do not (the library plans the call again for the LDS-DMA kernel) -- same
+    audio and state either way, then a reference-sized call continues the stream on the streaming kernel again."""
+    rng = np.random.default_rng(D + fast)
+    nch = 9
+    blocks = [rng.integers(0, 256, (nch, 3 << 20), dtype=np.uint8),
+              fmd.synth.synth_iq(nch, fmd.DEFAULT_BUF_LENGTH, seed=7, amplitude=110),
+              np.where(rng.integers(0, 2, (nch, 1 << 20)) > 0, 255, 0).astype(np.uint8)]
+    check_stream(fmd, oracle, D, fast, slow, blocks, n_channels=nch)
+
+
 def test_large_single_channel_call(fmd, oracle):
     """Config 2 throughput shape: one channel, 16 MiB in one call (time-tiled inside the channel)."""
     N = 16 << 20
