@@ -289,7 +289,8 @@ int fmd_sink_info(const fmd_sink *s, size_t *out_cap, uint32_t *n_devices, uint3
  *   fmd_rtltcp_open     : connect (timeout_ms, 0 = 10 s) and read the handshake; FMD_ERR_IO when it is not "RTL0";
  *   fmd_rtltcp_read_sync: RtlSdr::read_sync (src/lib.rs:153) -- fill buf, *n_read = bytes written; FEWER than nbytes
  *                         means the stream ended, which the reference's callers treat as "samples lost"
- *                         (examples/simple_fm.rs:122); a socket error or a timeout returns FMD_ERR_IO;
+ *                         (examples/simple_fm.rs:122); a socket error or a timeout returns FMD_ERR_IO with
+ *                         *n_read = the bytes that did arrive (the stream keeps its I/Q byte alignment);
  *   fmd_rtltcp_command  : one command; a negative (i32) parameter travels as its two's complement. */
 typedef struct fmd_rtltcp fmd_rtltcp;
 #define FMD_RTLTCP_SET_FREQUENCY       0x01   /* opcodes of command_loop, examples/rtl_tcp.rs:659-675 */

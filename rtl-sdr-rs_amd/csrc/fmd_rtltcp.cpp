@@ -54,10 +54,12 @@ int wait_fd(int fd, short events, int timeout_ms)
     }
 }
 
-// Up to n bytes; stops early at end of stream.  Returns bytes read, or -1 on error / timeout.
-long read_upto(fmd_rtltcp* s, uint8_t* buf, size_t n)
+// Up to n bytes; stops early at end of stream.  Returns bytes read, or -1 on error / timeout (then *partial, when
+// given, holds the bytes that did arrive, so a caller can keep the I/Q byte alignment of the stream).
+long read_upto(fmd_rtltcp* s, uint8_t* buf, size_t n, size_t* partial = nullptr)
 {
     size_t got = 0;
+    struct Keep { size_t* p; const size_t& g; ~Keep() { if (p) *p = g; } } keep{partial, got};
     while (got < n) {
         const int w = wait_fd(s->fd, POLLIN, s->timeout_ms);
         if (w == 0) { errno = ETIMEDOUT; return -1; }
@@ -148,7 +150,7 @@ int fmd_rtltcp_read_sync(fmd_rtltcp* s, uint8_t* buf, size_t nbytes, size_t* n_r
 {
     if (!s || !buf || !n_read) { fmd_internal_set_err("null argument"); return FMD_ERR_INVALID_ARG; }
     *n_read = 0;
-    const long n = read_upto(s, buf, nbytes);
+    const long n = read_upto(s, buf, nbytes, n_read);       // on error *n_read = the bytes that did arrive
     if (n < 0) { err("read"); return FMD_ERR_IO; }
     *n_read = (size_t)n;                                     // < nbytes: the stream ended ("samples lost", simple_fm.rs:122)
     return FMD_OK;

@@ -119,7 +119,9 @@ class RtlTcpSourceC:
         C = self._C
         n = C.c_size_t(0)
         addr = C.addressof((C.c_uint8 * len(view)).from_buffer(view))
-        self._check(self._lib.fmd_rtltcp_read_sync(self._h, addr, len(view), C.byref(n)))
+        rc = self._lib.fmd_rtltcp_read_sync(self._h, addr, len(view), C.byref(n))
+        self.partial = n.value                      # on FMD_ERR_IO (timeout / socket error): the bytes that did arrive
+        self._check(rc)
         return n.value
 
     def command(self, opcode, param):

@@ -3,10 +3,34 @@
 committed summaries under profiles/.  Usage: summarize_profiles.py <tag> [round-prefix, default r01]"""
 import collections, csv, glob, json, os, shutil, sys
 
+def summarize_firdemod(g, tag, rnd, out):
+    """Fused FIR -> discriminator -> resampler kernel (config 4): bench line + PMC passes (scripts/gpu_pmc_firdemod.sh)."""
+    fd = os.path.join(g, tag + "_firdemod.json")
+    if os.path.exists(fd):
+        shutil.copy(fd, os.path.join(out, rnd + "_config4_firdemod.json"))
+    fdp = os.path.join(g, tag + "_pmc_fd", "summary.json")
+    if os.path.exists(fdp):
+        c = json.load(open(fdp))
+        w = c["SQ_WAVES"]["mean_per_launch"]
+        line = json.loads(open(fd).read().strip().splitlines()[-1]) if os.path.exists(fd) else {}
+        alg = line.get("GBps", 0) * line.get("ms", 0) * 1e6
+        fetch, wr = c["FETCH_SIZE"]["mean_per_launch"] * 2048, c["WRITE_SIZE"]["mean_per_launch"] * 1024
+        pf = {"command": "rocprofv3 --kernel-trace --pmc <set> -- python3 tools/bench_firdemod.py (scripts/gpu_pmc_firdemod.sh; one pass per counter set)",
+              "bench_line_same_session": line, "counters": c,
+              "per_wave": {k: round(c[k]["mean_per_launch"] / w, 2) for k in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_INSTS_VMEM_RD", "SQ_INSTS_MFMA",
+                                                                            "SQ_WAVE_CYCLES", "SQ_ACTIVE_INST_VALU", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_LDS_BANK_CONFLICT", "SQ_LDS_IDX_ACTIVE") if k in c},
+              "hbm_traffic": {"bytes_per_launch(2 x FETCH_SIZE + WRITE_SIZE, KiB units)": fetch + wr, "algorithmic_bytes_per_launch": round(alg),
+                              "ratio": round((fetch + wr) / alg, 4) if alg else None}}
+        json.dump(pf, open(os.path.join(out, rnd + "_config4_firdemod_pmc.json"), "w"), indent=1)
+
+
 tag = sys.argv[1]
 rnd = sys.argv[2] if len(sys.argv) > 2 else "r03"
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src, pmc, out = os.path.join(root, "gpurun_out", tag), os.path.join(root, "gpurun_out", tag + "_pmc"), os.path.join(root, "profiles")
+if "--firdemod-only" in sys.argv:      # a session that re-measured only the fused FIR kernel (its source is not one of the headline's)
+    summarize_firdemod(os.path.join(root, "gpurun_out"), tag, rnd, out)
+    sys.exit(0)
 KERNEL = "fmd_demod_tile_kernel<5, 256, 2>"
 sys.path.insert(0, root)
 import bench as _bench   # kernel_source_hash(): ties the PMC summary to the sources it was measured on
@@ -98,21 +122,4 @@ if os.path.exists(cfgs):
 pc = os.path.join(g, tag + "_pmc_configs.jsonl")
 if os.path.exists(pc):
     shutil.copy(pc, os.path.join(out, rnd + "_pmc_configs.jsonl"))
-# fused FIR -> discriminator -> resampler kernel (config 4): bench line + PMC passes (scripts/gpu_pmc_firdemod.sh)
-fd = os.path.join(g, tag + "_firdemod.json")
-if os.path.exists(fd):
-    shutil.copy(fd, os.path.join(out, rnd + "_config4_firdemod.json"))
-fdp = os.path.join(g, tag + "_pmc_fd", "summary.json")
-if os.path.exists(fdp):
-    c = json.load(open(fdp))
-    w = c["SQ_WAVES"]["mean_per_launch"]
-    line = json.loads(open(fd).read().strip().splitlines()[-1]) if os.path.exists(fd) else {}
-    alg = line.get("GBps", 0) * line.get("ms", 0) * 1e6
-    fetch, wr = c["FETCH_SIZE"]["mean_per_launch"] * 2048, c["WRITE_SIZE"]["mean_per_launch"] * 1024
-    pf = {"command": "rocprofv3 --kernel-trace --pmc <set> -- python3 tools/bench_firdemod.py (scripts/gpu_pmc_firdemod.sh; one pass per counter set)",
-          "bench_line_same_session": line, "counters": c,
-          "per_wave": {k: round(c[k]["mean_per_launch"] / w, 2) for k in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_INSTS_VMEM_RD", "SQ_INSTS_MFMA",
-                                                                        "SQ_WAVE_CYCLES", "SQ_ACTIVE_INST_VALU", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_LDS_BANK_CONFLICT", "SQ_LDS_IDX_ACTIVE") if k in c},
-          "hbm_traffic": {"bytes_per_launch(2 x FETCH_SIZE + WRITE_SIZE, KiB units)": fetch + wr, "algorithmic_bytes_per_launch": round(alg),
-                          "ratio": round((fetch + wr) / alg, 4) if alg else None}}
-    json.dump(pf, open(os.path.join(out, rnd + "_config4_firdemod_pmc.json"), "w"), indent=1)
+summarize_firdemod(g, tag, rnd, out)

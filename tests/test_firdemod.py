@@ -56,8 +56,37 @@ def test_gpu_all_ones_is_the_boxcar_kernel_and_the_reference(fmd, oracle, D, fas
 @pytest.mark.gpu
 @pytest.mark.parametrize("T,M,fast,slow", [(127, 8, 2500000, 48000), (33, 4, 250000, 48000), (5, 2, 96000, 48000),
                                            (64, 6, 170000, 32000), (255, 32, 625000, 8000), (300, 8, 100000, 44100),
-                                           (16, 16, 48000, 48000), (129, 64, 37500, 8000), (1, 2, 500000, 32000)])
+                                           (16, 16, 48000, 48000), (129, 64, 37500, 8000), (1, 2, 500000, 32000),
+                                           (127, 16, 1250000, 48000), (200, 16, 625000, 44100), (255, 16, 625000, 48000)])
 def test_gpu_fused_matches_composition(fmd, oracle, T, M, fast, slow):
+    """Decimate 8 with all k-steps in one pass runs the operand-fragment-reuse mapping; every other shape the plain one."""
+    fused_case(fmd, oracle, T, M, fast, slow)
+
+
+@pytest.mark.gpu
+def test_gpu_fused_plain_mapping_forced(fmd, oracle, request):
+    """The plain matrix-core mapping where the shipped library picks fragment reuse (FMD_FD_NOREUSE, a knob of the
+    -DFMD_EXPERIMENT build: the test re-runs itself once in a child process on that library)."""
+    from conftest import run_in_exp_child
+    if run_in_exp_child(request, {"FMD_FD_NOREUSE": "1"}):
+        return
+    for T, M, fast, slow in [(127, 8, 2500000, 48000), (127, 16, 1250000, 48000), (200, 16, 625000, 44100)]:
+        fused_case(fmd, oracle, T, M, fast, slow)
+
+
+@pytest.mark.gpu
+def test_gpu_fused_reuse_at_decim_16(fmd, oracle, request):
+    """Fragment reuse with two k-steps between a column's output groups (decim 16; FMD_FD_REUSE16, experiment build --
+    bit-exact, measured 4-6 % slower than the plain mapping, so the shipped library does not select it) and the
+    even-column-pitch form of the decim-8 mapping (FMD_DBG bit 8)."""
+    from conftest import run_in_exp_child
+    if run_in_exp_child(request, {"FMD_FD_REUSE16": "1", "FMD_DBG": "256"}):
+        return
+    for T, M, fast, slow in [(127, 16, 1250000, 48000), (200, 16, 625000, 44100), (33, 16, 312500, 48000), (127, 8, 2500000, 48000)]:
+        fused_case(fmd, oracle, T, M, fast, slow)
+
+
+def fused_case(fmd, oracle, T, M, fast, slow):
     rng = np.random.default_rng(T * 11 + M)
     taps = rng.integers(-2047, 2048, T).astype(np.int16)
     shift = fmd.auto_shift(taps, 16384) + int(rng.integers(0, 6))     # both discriminator forms (|lp| <= 2048: f32)

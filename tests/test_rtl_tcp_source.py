@@ -107,6 +107,31 @@ def test_c_abi_source_errors(fmd):
     assert ei.value.status == -11 and "RTL0" in str(ei.value)
 
 
+def test_c_abi_source_timeout_reports_the_partial_count(fmd):
+    """A server that stalls mid-block: read_sync fails with FMD_ERR_IO after the timeout and says how many bytes did
+    arrive, so a caller that retries keeps the I/Q byte alignment of the stream."""
+    stall = threading.Event()
+
+    class Stalling(FakeServer):
+        def run(self):
+            conn, _ = self.lsock.accept()
+            conn.sendall(self.hs + self.payload)
+            stall.wait(10)
+            conn.close()
+            self.lsock.close()
+
+    payload = bytes(range(256)) * 4 + b"xyz"                      # 1027 bytes, an odd count
+    srv = Stalling(payload)
+    with rts.RtlTcpSourceC("127.0.0.1", srv.port, timeout=0.4) as src:
+        buf = np.zeros(4096, dtype=np.uint8)
+        with pytest.raises(fmd.FmdError) as ei:
+            src.read_sync(buf)
+        assert ei.value.status == -11 and "timed out" in str(ei.value).lower()
+        assert src.partial == len(payload) and buf[:len(payload)].tobytes() == payload
+    stall.set()
+    srv.thread.join(timeout=5)
+
+
 def test_bad_handshake_rejected():
     with pytest.raises(ValueError):
         rts.parse_handshake(b"RTL1" + bytes(8))

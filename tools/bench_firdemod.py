@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """BASELINE configs[3] with the demodulator fused behind the FIR (fmd_firdemod_*): 127 taps, decimate 8, 256 channels x
-2 MiB per call, 2.5 Msps -> 48 kHz.  One JSON line.  FMD_FD_KT / FMD_DBG (exp build) are tuning knobs."""
+2 MiB per call, 2.5 Msps -> 48 kHz.  One JSON line.  FMD_FD_KT / FMD_DBG / FMD_FD_NOREUSE (exp build) are tuning knobs;
+BENCH_FD_DECIM=16 times the decimate-16 shape (1.25 Msps -> 48 kHz) instead."""
 import json, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -8,6 +9,8 @@ import torch
 import rtl_sdr_rs_amd as fmd
 
 nch, n, T, M, fast, slow = 256, 2 << 20, 127, 8, 2500000, 48000
+if os.environ.get("BENCH_FD_DECIM"):
+    M = int(os.environ["BENCH_FD_DECIM"]); fast = 20_000_000 // M
 taps = np.random.default_rng(1).integers(-2047, 2048, T).astype(np.int16)
 bank = fmd.FirDemodBank(taps, M, fast, slow, nch)
 stream = torch.cuda.current_stream().cuda_stream
@@ -31,5 +34,5 @@ for r in range(3):
     ts.append(e0.elapsed_time(e1) / 100)
 ms = sorted(ts)[1]
 alg = nch * n + 2 * nch * k
-print(json.dumps({"dbg": os.environ.get("FMD_DBG"), "kt": os.environ.get("FMD_FD_KT"), "tpb": os.environ.get("FMD_FD_TPB"), "ms": round(ms, 4), "GBps": round(alg / ms / 1e6, 1),
+print(json.dumps({"decim": M, "noreuse": os.environ.get("FMD_FD_NOREUSE"), "reuse16": os.environ.get("FMD_FD_REUSE16"), "dbg": os.environ.get("FMD_DBG"), "kt": os.environ.get("FMD_FD_KT"), "tpb": os.environ.get("FMD_FD_TPB"), "ms": round(ms, 4), "GBps": round(alg / ms / 1e6, 1),
                   "frac": round(alg / ms / 1e6 / 8000, 4), "tiling": bank.tiling(), "audio": k}))
