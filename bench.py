@@ -403,7 +403,7 @@ def extra_power_clock(torch, dev_index, step, seconds=2.0):
     idle reading.  Why it is in the line: on the boxes measured so far the full kernel sits AT the board's power cap
     and the firmware lowers the shader clock by 10-15 % (the staging skeleton and the compute side alone each run at
     the full clock, profiles/r03_experiments.md section 11), which is what separates the kernel from its own
-    loads-only time and explains the box-to-box spread of the headline figure."""
+    loads-only time."""
     sens = GpuSensors(torch, dev_index)
     if sens.dir is None:
         return {"error": "no amdgpu sysfs sensors for this device"}
