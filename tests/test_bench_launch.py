@@ -103,6 +103,36 @@ def test_two_ranks_on_one_box():
         assert 0.05 < r["roofline"]["frac"] < 1.0 and r["roofline"]["bound"] == "hbm"
 
 
+def torchrun_cmd(n, port, extra):
+    """The driver's own launch line for N > 1 (one rank per GPU, rendezvous on 127.0.0.1)."""
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+            "--master-port", str(port), BENCH, "--gpus", str(n)] + extra
+
+
+def test_driver_launch_line_fails_loudly_without_gpu(fmd):
+    """`python -m torch.distributed.run ... bench.py --gpus 2` on a box without a GPU: both ranks read RANK / LOCAL_RANK /
+    WORLD_SIZE from the environment, refuse (no CPU path) and the job exits non-zero without printing a line."""
+    if fmd.device_count() > 0:
+        pytest.skip("a GPU is present: covered by the gpu test below")
+    p = subprocess.run(torchrun_cmd(2, 29541, ["--backend", "gloo", "--steps", "2", "--no-cpu"]), capture_output=True, env=clean_env(), timeout=600)
+    assert p.returncode != 0
+    assert b"no gfx950 device" in p.stderr and not [l for l in p.stdout.decode().splitlines() if l.startswith("{")]
+
+
+@pytest.mark.gpu
+def test_driver_launch_line_two_ranks_on_one_box():
+    """The same launch line with a GPU: ranks started by torch.distributed.run (not by bench.py's own launcher), gloo
+    because both ranks share the box's one GPU; rank 0 prints ONE line with n_gpus == 2 and both per-GPU rates."""
+    p = subprocess.run(torchrun_cmd(2, 29543, ["--backend", "gloo", "--steps", "5", "--warmup", "2", "--settle", "10", "--no-cpu", "--no-extra",
+                                               "--channels", "1024", "--min-timed-s", "0.05"]), capture_output=True, env=clean_env(), timeout=900)
+    assert p.returncode == 0, p.stderr.decode()[-3000:]
+    lines = [l for l in p.stdout.decode().splitlines() if l.startswith("{")]
+    assert len(lines) == 1, lines
+    r = json.loads(lines[0])
+    assert r["n_gpus"] == 2 and len(r["per_gpu_msamples_per_s"]) == 2 and r["scaling"] == "weak"
+    assert r["config"]["torch_distributed"]["world_size"] == 2 and r["value"] > 0
+
+
 def shape_of(x):
     """Keys and value types of a JSON line, recursively (numbers are one type): what "unchanged" means for a line."""
     if isinstance(x, dict):
