@@ -383,11 +383,13 @@ class GpuSensors:
 
         th = threading.Thread(target=loop, daemon=True)
         th.start()
-        t_end = time.time() + seconds
-        while time.time() < t_end:
-            work()
-        stop.append(1)
-        th.join()
+        try:
+            t_end = time.time() + seconds
+            while time.time() < t_end:
+                work()
+        finally:                                             # the sampler ends with the work, also when the work raises
+            stop.append(1)
+            th.join()
         return sclk, power
 
 
