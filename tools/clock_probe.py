@@ -76,8 +76,11 @@ def main():
             ms.append(e0.elapsed_time(e1) / 500)
 
         sclk, power = sens.sample_while(work, a.seconds)
+        n6 = max(1, len(ms) // 6)                            # drift over the interval: medians of six consecutive slices
+        slices = [round(sorted(ms[i:i + n6])[len(ms[i:i + n6]) // 2], 4) for i in range(0, n6 * 6, n6) if ms[i:i + n6]]
+        sc6 = [sorted(sclk[i:i + max(1, len(sclk) // 6)])[len(sclk[i:i + max(1, len(sclk) // 6)]) // 2] for i in range(0, max(1, len(sclk) // 6) * 6, max(1, len(sclk) // 6)) if sclk[i:i + max(1, len(sclk) // 6)]]
         ms.sort()
-        print(json.dumps({"variant": name, "FMD_DBG": dbg, "kernel": what, "launches": 500 * len(ms), "ms_per_call_median": round(ms[len(ms) // 2], 4),
+        print(json.dumps({"variant": name, "ms_per_call_over_time": slices, "sclk_mhz_over_time": sc6, "FMD_DBG": dbg, "kernel": what, "launches": 500 * len(ms), "ms_per_call_median": round(ms[len(ms) // 2], 4),
                           "sclk_mhz": bench.sensor_stats(sclk), "power_w": bench.sensor_stats(power)}), flush=True)
         del bank, out
         time.sleep(1.0)
