@@ -15,9 +15,12 @@ torch.distributed code path with world size 1 (so the RCCL branch runs on a one-
 
 Timing: exactly K steps per timed region, each region bracketed by barrier + synchronize, MAX over ranks;
 the region is repeated until >= 1 s has been timed and the MEDIAN region is reported (min / max beside it).
-After the timing: a parity bit (a fresh bank, two steps from the zero state, >= 64 channels against the oracle),
-side lines for the other BASELINE configurations (`extra.*`, each outside the headline's timed region) and the CPU
-baseline (the oracle, the only place besides the parity bit where bench.py touches it).
+After the timing, at EVERY world size: a parity bit on every rank (a fresh bank, two steps from the zero state, >= 64
+channels of the rank's own shard against the oracle; the flags are gathered into `parity`), every rank's shader clock
+and socket power while all GPUs run the headline launch together (`extra.power_clock.per_gpu`), the name of the kernel
+the library reports it launched (`roofline.kernel`, checked against the expected one) and, on rank 0, the CPU baseline
+(the oracle, the only place besides the parity bit where bench.py touches it).  With one GPU also the side lines for the
+other BASELINE configurations and the rest of the supported domain (`extra.*`, each outside the headline's timed region).
 """
 import argparse
 import ctypes as C
@@ -38,15 +41,17 @@ BLOCK = 16 * 16384
 D, FAST, SLOW = 10, 240000, 32000
 CFG_REF = (6, 170000, 32000)     # optimal_settings(94.9 MHz, 170 kHz), examples/simple_fm.rs:25-27,48,189-214
 HBM_PEAK_GBS = 8000.0            # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-KERNEL = "fmd_demod_tile_kernel<5, 256, 2>"   # the dominant kernel of this workload (rocprofv3 --kernel-trace name)
+# the kernel this workload is expected to run (rocprofv3 --kernel-trace name); the line quotes what the library REPORTS it
+# launched (fmd_demod_last_kernel) and flags a difference
+KERNEL_EXPECTED = "fmd_tk::fmd_demod_tile_kernel<5, 2>"
 MIN_TIMED_S = 1.0                # repeat the K-step region until this much has been timed
 MAX_REGIONS = 4000
-PMC_SUMMARY = os.path.join("profiles", "r03_pmc_summary.json")
+PMC_SUMMARY = os.path.join("profiles", "r04_pmc_summary.json")
 
 
 # what the headline kernel is built from (the FIR kernels, the sink and the CLI do not enter it)
-HEADLINE_SOURCES = ("fmd_tile_kernel.hip", "fmd_kernels.h", "fmd_device.h", "fmd_index.h", "fmd_host.h", "fmd_internal.h",
-                    "fmd_boxcar_mfma.h", "fmd_api.cpp")
+HEADLINE_SOURCES = ("fmd_tile_body.h", "fmd_tile_lds_even.hip", "fmd_tile_launch.hip", "fmd_kernels.h", "fmd_device.h", "fmd_index.h",
+                    "fmd_host.h", "fmd_internal.h", "fmd_api.cpp")
 
 
 def kernel_source_hash():
@@ -224,11 +229,42 @@ def extra_cfg_ref(fmd, torch, dev, stream, bufs):
     bank.check()
     alg = nch * BLOCK + 2 * int(bank.last_out_len().sum())
     res = {"workload": "cfg-ref: %d channels x %d B/call, downsample %d, %d -> %d Hz (examples/simple_fm.rs:25-27)" % (nch, BLOCK, d, fast, slow),
-           "kernel": "fmd_demod_tile_kernel<%d, 256, 2>" % (d // 2), "ms_per_call": round(ms, 4), "ms_min_max": [round(lo, 4), round(hi, 4)],
+           "kernel": bank.last_kernel(), "ms_per_call": round(ms, 4), "ms_min_max": [round(lo, 4), round(hi, 4)],
            "iq_msamples_per_s": round(nch * (BLOCK // 2) / ms / 1e3, 1), "algorithmic_bytes_per_launch": alg,
            "GBps": round(alg / ms / 1e6, 1), "frac": round(alg / ms / 1e6 / HBM_PEAK_GBS, 4), "tiling": bank.tiling()}
     bank.close()
     return res
+
+
+# (downsample, rate_out, rate_resample): the rest of the supported domain, tools/bench_configs.py's table
+DOMAIN = [(1, 48000, 48000), (2, 500000, 32000), (4, 256000, 48000), (5, 250000, 44100), (7, 166666, 32000), (8, 250000, 44100),
+          (12, 192000, 32000), (16, 150000, 32000), (64, 37500, 8000)]
+
+
+def extra_domain(fmd, torch, dev, stream, bufs):
+    """Every other kernel family of the demod path on the headline's batch shape and input buffers (outside its timed
+    region, <= 0.2 s each): odd factors, the register-streaming kernel (2, 4), the wrap-around walk (16, 64), one
+    discriminator per IQ sample (1).  Each line names the kernel the library reports it launched."""
+    nch = bufs[0].shape[0]
+    rows = []
+    for d, fast, slow in DOMAIN:
+        try:
+            cfg = fmd.DemodConfig(fast, fast, slow, d, max(1, (1 << 15) // (128 * d)))
+            bank = fmd.DemodBank(cfg, nch, device_id=dev.index)
+            cap = bank.out_cap(BLOCK)
+            out = torch.zeros((nch, cap), dtype=torch.int16, device=dev)
+            call = lambda i: bank.demodulate_device(bufs[i % len(bufs)].data_ptr(), BLOCK, out.data_ptr(), cap, None, stream)
+            ms, lo, hi, _ = time_calls(torch, call, settle=60, steps=40, regions=3)
+            bank.check()
+            alg = nch * BLOCK + 2 * int(bank.last_out_len().sum())
+            rows.append({"downsample": d, "rate_out": fast, "rate_resample": slow, "kernel": bank.last_kernel(),
+                         "ms_per_call": round(ms, 4), "ms_min_max": [round(lo, 4), round(hi, 4)], "GBps": round(alg / ms / 1e6, 1),
+                         "frac": round(alg / ms / 1e6 / HBM_PEAK_GBS, 4), "audio_per_tile": bank.tiling()["audio_per_tile"]})
+            bank.close()
+            del out
+        except Exception as e:
+            rows.append({"downsample": d, "rate_out": fast, "rate_resample": slow, "error": repr(e)})
+    return {"workload": "%d channels x %d B/call per configuration, 3 regions of 40 calls after 60 untimed ones" % (nch, BLOCK), "rows": rows}
 
 
 def extra_config2(fmd, torch, dev, stream):
@@ -491,7 +527,9 @@ def main():
     ap.add_argument("--nbuf", type=int, default=3, help="distinct input batches rotated through (defeats the 256 MiB L3)")
     ap.add_argument("--kt", type=int, default=0, help="tiling override (audio samples per tile)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline and the parity bit (both use the oracle)")
-    ap.add_argument("--no-extra", action="store_true", help="skip the side lines (extra.*)")
+    ap.add_argument("--no-extra", action="store_true", help="skip the side lines (extra.*), the per-GPU clock / power sample included")
+    ap.add_argument("--power-only", action="store_true", help="of the side lines keep only extra.power_clock (every rank samples its own GPU)")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="oracle time spent on the CPU baseline (rank 0)")
     ap.add_argument("--min-timed-s", type=float, default=MIN_TIMED_S, help="repeat the K-step region until this much has been timed")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="torch.distributed backend for the barrier / max-over-ranks timing (nccl = RCCL); with gloo "
@@ -646,6 +684,42 @@ def main():
     except (OSError, KeyError, ValueError):
         pass
 
+    # ---- every rank, outside the timed regions: parity bit and clock / power of its own GPU ------------------------------
+    def gather_rows(vals):
+        """one row of floats per rank -> list of rows (rank order)"""
+        if dist is None:
+            return [list(vals)]
+        mine = torch.tensor(list(vals), dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
+        every = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(every, mine)
+        return [[float(x) for x in t.tolist()] for t in every]
+
+    launched = bank.last_kernel()
+    par = None
+    if not args.no_cpu:
+        try:
+            par = parity_bit(fmd, torch, cfg, bufs, dev_index, stream)
+        except Exception as e:
+            par = {"ok": False, "error": repr(e), "channels_checked": 0}
+        rows = gather_rows([1.0 if par.get("ok") else 0.0, float(par.get("channels_checked", 0))])
+        par = dict(par, ok=all(r[0] == 1.0 for r in rows), ranks_checked=len(rows), ranks_ok=[r[0] == 1.0 for r in rows],
+                   channels_checked=int(sum(r[1] for r in rows)),
+                   seeding="rank r checks channels of its own shard [r * %d, (r + 1) * %d): global channel c is seeded with base + c" % (nch, nch))
+    pc = None
+    if not args.no_extra:
+        fence()                                              # all GPUs of the node load up together: that is the point
+        try:
+            pc = extra_power_clock(torch, dev_index, step)
+        except Exception as e:
+            pc = {"error": repr(e)}
+        med = lambda d, k: float((d.get(k) or {}).get("median") or float("nan"))
+        rows = gather_rows([med(pc, "sclk_mhz"), med(pc, "power_w"), float(pc.get("ms_per_call_during_sampling") or float("nan")),
+                            float(pc.get("power_cap_w") or float("nan"))])
+        nn = lambda v, nd: None if v != v else round(v, nd)
+        pc["per_gpu"] = [{"rank": i, "sclk_mhz": nn(r[0], 0), "power_w": nn(r[1], 0), "ms_per_call": nn(r[2], 4), "power_cap_w": nn(r[3], 0)}
+                         for i, r in enumerate(rows)]
+        fence()
+
     if rank == 0:
         res = {
             "metric": "IQ Msamples/s demodulated", "value": round(value, 1), "unit": "Msamples/s",
@@ -671,19 +745,21 @@ def main():
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
                          "traffic_measured_in_this_run": False,
-                         "kernel": KERNEL, "algorithmic_bytes_per_launch": alg_bytes,
+                         "kernel": launched, "kernel_expected": KERNEL_EXPECTED, "kernel_is_expected": launched == KERNEL_EXPECTED,
+                         "algorithmic_bytes_per_launch": alg_bytes,
                          # BASELINE's "% HBM-read roofline" (SURVEY 8d): 2 B per IQ sample only, writes not counted
                          "hbm_read_frac": round(nch * BLOCK / (kern_ms_region * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                          "kernel_ms_events_region": round(kern_ms_region, 4),
                          "kernel_ms_events_per_launch_median": round(kern_ms_pair, 4),
                          "kernel_ms_events_per_launch_min_max": [round(per_launch[0], 4), round(per_launch[-1], 4)]},
         }
-        if world == 1 and not args.no_cpu:
-            try:
-                res["parity"] = parity_bit(fmd, torch, cfg, bufs, dev_index, stream)
-            except Exception as e:
-                res["parity"] = {"ok": False, "error": repr(e)}
-        if world == 1 and not args.no_extra:
+        if launched != KERNEL_EXPECTED:
+            sys.stderr.write("bench.py: the library launched %r, expected %r\n" % (launched, KERNEL_EXPECTED))
+        if par is not None:
+            res["parity"] = par
+        if pc is not None:
+            res["extra"] = {"power_clock": pc}
+        if world == 1 and not args.no_extra and not args.power_only:
             # what this box's HBM does on a plain device-to-device copy of one input batch (SURVEY 8d asks for the
             # measured reference beside the 8 TB/s spec): bytes read + bytes written over the HIP-event time
             try:
@@ -704,22 +780,21 @@ def main():
                 del dst
             except Exception as e:
                 res["roofline"]["box_reference"] = {"error": repr(e)}
-            res["extra"] = {}
             side = [("cfg_ref", lambda: extra_cfg_ref(fmd, torch, dev, stream, bufs)),
                     ("check_per_step", lambda: extra_check_per_step(fmd, torch, bank, bufs, out, cap, stream)),
                     ("config2_1channel", lambda: extra_config2(fmd, torch, dev, stream)),
                     ("config4_fir", lambda: extra_config4(fmd, torch, dev, stream, False)),
                     ("config4_fir_demod_fused", lambda: extra_config4(fmd, torch, dev, stream, True)),
                     ("sink_pcie", lambda: extra_sink_pcie(fmd, dev_index)),
-                    ("power_clock", lambda: extra_power_clock(torch, dev_index, step))]
+                    ("domain", lambda: extra_domain(fmd, torch, dev, stream, bufs))]
             for name, fn in side:
                 try:
                     res["extra"][name] = fn()
                 except Exception as e:          # side lines never break the headline
                     res["extra"][name] = {"error": repr(e)}
-        if world == 1 and not args.no_cpu:
+        if not args.no_cpu:                      # rank 0 only, after the last timed region; the other ranks wait at the final barrier
             try:
-                res["cpu_baseline"] = cpu_baseline(fmd, torch, cfg, bufs[0])
+                res["cpu_baseline"] = cpu_baseline(fmd, torch, cfg, bufs[0], target_s=args.cpu_seconds)
             except Exception as e:              # the baseline is reported, never required for the GPU number
                 res["cpu_baseline"] = {"error": repr(e)}
         print(json.dumps(res), flush=True)

@@ -318,9 +318,14 @@ const char *fmd_strerror(int status);
 const char *fmd_last_error(void);          /* thread-local detail of the last failure          */
 int fmd_device_count(int *count);          /* gfx950 devices visible to HIP                    */
 int fmd_version(void);                     /* FMD_VERSION_MAJOR * 1000 + FMD_VERSION_MINOR     */
-/* Kernel tiling chosen for a configuration (for benchmarks / DESIGN.md bookkeeping). */
+/* Kernel tiling (for benchmarks / DESIGN.md bookkeeping): of the handle's most recent launch,
+ * or, before the first one, what a bank fed whole read_sync buffers will run. */
 int fmd_demod_tiling(const fmd_demod *d, uint32_t *audio_per_tile, uint32_t *lds_bytes,
                      uint32_t *block_threads);
+/* Name of the kernel the handle's most recent launch ran, as `rocprofv3 --kernel-trace` prints
+ * it (e.g. "fmd_tk::fmd_demod_tile_kernel<5, 2>"); "" before the first launch.  bench.py
+ * quotes it in `roofline.kernel` instead of a constant. */
+int fmd_demod_last_kernel(const fmd_demod *d, char *name, size_t cap);
 /* Override the tiling (audio samples per workgroup tile; 0 = automatic).  Results never
  * depend on it; it exists for tuning sweeps. */
 int fmd_demod_set_tiling(fmd_demod *d, uint32_t audio_per_tile);

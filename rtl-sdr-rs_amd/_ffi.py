@@ -85,6 +85,7 @@ PROTOTYPES = {
     "fmd_device_count": (C.c_int, [C.POINTER(C.c_int)]),
     "fmd_version": (C.c_int, []),
     "fmd_demod_tiling": (C.c_int, [_vp, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
+    "fmd_demod_last_kernel": (C.c_int, [_vp, C.c_char_p, C.c_size_t]),
     "fmd_demod_set_tiling": (C.c_int, [_vp, C.c_uint32]),
     "fmd_fir_new": (C.c_int, [_i16p, C.c_uint32, C.c_uint32, C.POINTER(DeviceConfig), C.POINTER(_vp)]),
     "fmd_fir_free": (None, [_vp]),

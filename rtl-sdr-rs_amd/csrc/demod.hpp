@@ -8,8 +8,7 @@
 //   output(Vec<i16>)                          :430-438  -> fm::output(const std::vector<int16_t>&, FILE*)
 // Where the reference panics (len % 8, < 2 decimated samples, rate_out < rate_resample) these throw
 // fm::Error carrying the fmd_status.  Header-only; link with libfmd_hip.so.
-#ifndef FMD_DEMOD_HPP
-#define FMD_DEMOD_HPP
+#pragma once
 
 #include <cstdint>
 #include <cstdio>
@@ -194,5 +193,3 @@ inline void output(const std::vector<int16_t>& buf, FILE* f = stdout)
 }
 
 }  // namespace fm
-
-#endif

@@ -18,7 +18,6 @@
 #include <utility>
 #include <vector>
 
-#include "fmd_boxcar_mfma.h"
 #include "fmd_host.h"
 #include "fmd_index.h"
 #include "fmd_internal.h"
@@ -78,7 +77,6 @@ struct fmd_demod {
     uint32_t xcd_swizzle = 2;             // block -> (channel, tile) mapping (FMD_XCD, experiment build)
     uint32_t dbg = 0;                     // ablation bits (FMD_DBG, experiment build)
     int n_cus = 0;                        // compute units of the device
-    uint32_t block_threads = 256;         // workgroup size of the one-block-per-tile kernel (FMD_NT: 64 / 128 in the experiment build)
     uint32_t allow_fast = 2;              // FMD_FAST: 0 general prologue only, 1 closed form only, 2 (default) table, else closed form (A/B)
     FmdChanState* d_state[2] = {nullptr, nullptr};
     int cur = 0;
@@ -91,7 +89,7 @@ struct fmd_demod {
     FmdStreamOrder order;                 // cross-stream ordering of consecutive launches (fmd_host.h)
     std::vector<PhaseClass> classes;      // host mirror of the phases
     std::vector<uint32_t> chan_class;     // [C] index into classes
-    uint32_t* d_bx_amat = nullptr;        // matrix-core boxcar: A fragments (fmd_boxcar_mfma.h), even downsample <= 14
+    FmdKernelId last_kernel;              // what the most recent launch ran (fmd_demod_last_kernel, fmd_demod_tiling)
     uint8_t* d_chan_class = nullptr;      // device copy, valid while 1 < classes <= FMD_MAX_CLASSES
     bool d_chan_class_dirty = true;
     hipStream_t stream = nullptr;         // used by the host-buffer entry points
@@ -111,8 +109,8 @@ int choose_tiling(fmd_demod* d, uint32_t kt_req)
         // rounds of 127 decimated samples (4 waves share the rounds) and the resampler runs in passes of one
         // audio sample per thread, so e.g. 272 audio samples per tile (a second pass for 16 of them) measured
         // 10 % slower than 256 at the reference's own rates.  Weights are instruction counts of the kernel.
-        const uint32_t nt_threads = d->block_threads, waves = nt_threads / 64u;
-        const double budget = 20480.0 * (double)nt_threads / 256.0;
+        const uint32_t waves = FMD_BLOCK_THREADS / 64u;
+        const double budget = 20480.0;
         const uint32_t dh = (r.D + 1u) / 2u;                                 // dwords per window
         const double c_round = 64.0 + 12.0 * dh, c_audio = 70.0 + 6.0 * (double)(r.fr / r.sr), c_fixed = 90.0;   // per wave: prologue, staging, barriers, epilogue
         double best = 0.0;
@@ -294,15 +292,13 @@ int enqueue(fmd_demod* d, const void* d_iq, size_t nbytes, void* d_out, size_t o
             }
             L.chan_class = d->d_chan_class;
         }
-        L.block_threads = d->block_threads;
-        L.bx_amat = d->d_bx_amat;
         L.fast = d->allow_fast;               // fmd_launch_tile decides (fmd_fast_geometry)
-        const hipError_t le = fmd_launch_tile(L, stream);
+        const hipError_t le = fmd_launch_tile(L, stream, &d->last_kernel);
         if (le == hipErrorNotSupported && stream_now)        // no table / closed-form geometry for this call: the LDS kernel with its own tiling
             return enqueue(d, d_iq, nbytes, d_out, out_cap, d_out_len, stream, false);
         HIP_TRY(le);
     } else {
-        HIP_TRY(fmd_launch_generic(L, stream));
+        HIP_TRY(fmd_launch_generic(L, stream, &d->last_kernel));
     }
     d->order.after(stream);
     d->seq += 1;
@@ -498,10 +494,6 @@ int fmd_demod_new(const fmd_demod_config* config, const fmd_device_config* dev, 
     d->force_generic = fmd_knob_u32("FMD_FORCE_GENERIC", 0) != 0;
     d->xcd_swizzle = fmd_knob_u32("FMD_XCD", 2);
     d->dbg = fmd_knob_u32("FMD_DBG", 0);
-    d->block_threads = fmd_knob_u32("FMD_NT", 256);
-    if (d->block_threads != 128 && d->block_threads != 64) d->block_threads = 256;
-    // two waves per block step 2*127 windows per round: an odd downsample would flip a lane's rotation phase
-    if (d->block_threads == 128 && (config->downsample & 1u)) d->block_threads = 256;
     const uint32_t kt_env = fmd_knob_u32("FMD_KT", 0);
     d->allow_fast = fmd_knob_u32("FMD_FAST", 2);
     int rc = choose_tiling(d, kt_env);
@@ -514,7 +506,7 @@ int fmd_demod_new(const fmd_demod_config* config, const fmd_device_config* dev, 
     // per wave (at most FMD_STREAM_MAX_ROUNDS, straight-line code), the busiest of the 4 waves sets the pace, one
     // resampler pass per 256 audio samples, a fixed cost per tile.
     d->stream_ok = false;
-    if ((r.D == 2u || r.D == 4u) && d->block_threads == 256u && fmd_knob_u32("FMD_STREAM", 1) != 0u) {   // (knob: A/B in the experiment build)
+    if ((r.D == 2u || r.D == 4u) && fmd_knob_u32("FMD_STREAM", 1) != 0u) {   // (knob: A/B in the experiment build)
         FmdRates rs = r;
         uint32_t kts = fmd_knob_u32("FMD_KT_STREAM", 0);
         const uint32_t cap_cnt = 4u * 127u * FMD_STREAM_MAX_ROUNDS - 8u;
@@ -570,11 +562,6 @@ int fmd_demod_new(const fmd_demod_config* config, const fmd_device_config* dev, 
         if ((e = hipMalloc(&d->d_state[i], sbytes)) != hipSuccess) return fail(e, "hipMalloc(state)");
         if ((e = hipMemset(d->d_state[i], 0, sbytes)) != hipSuccess) return fail(e, "hipMemset(state)");
     }
-    if ((config->downsample & 1u) == 0u && config->downsample / 2u <= FMD_BX_MAX_DH && fmd_knob_u32("FMD_BX_MFMA", 0) != 0u) {   // experiment build only: measured slower than the v_dot4 form
-        const std::vector<uint32_t> amat = fmd_bx_build_amat(config->downsample / 2u);
-        if ((e = hipMalloc(&d->d_bx_amat, amat.size() * 4)) != hipSuccess) return fail(e, "hipMalloc(boxcar matrix)");
-        if ((e = hipMemcpy(d->d_bx_amat, amat.data(), amat.size() * 4, hipMemcpyHostToDevice)) != hipSuccess) return fail(e, "hipMemcpy(boxcar matrix)");
-    }
     if ((e = hipMalloc(&d->d_exc, sizeof(FmdExcBuf))) != hipSuccess) return fail(e, "hipMalloc(reports)");
     if ((e = hipMemset(d->d_exc, 0, sizeof(FmdExcBuf))) != hipSuccess) return fail(e, "hipMemset(reports)");
     if ((e = hipStreamCreateWithFlags(&d->stream, hipStreamNonBlocking)) != hipSuccess) return fail(e, "hipStreamCreate");
@@ -592,7 +579,6 @@ void fmd_demod_free(fmd_demod* d)
     if (d->d_exc) (void)hipFree(d->d_exc);
     d->order.destroy();
     if (d->d_chan_class) (void)hipFree(d->d_chan_class);
-    if (d->d_bx_amat) (void)hipFree(d->d_bx_amat);
     if (d->d_iq) (void)hipFree(d->d_iq);
     if (d->d_out) (void)hipFree(d->d_out);
     if (d->stream) (void)hipStreamDestroy(d->stream);
@@ -784,6 +770,13 @@ int fmd_demod_set_state(fmd_demod* d, uint32_t channel, const fmd_demod_state* s
 int fmd_demod_tiling(const fmd_demod* d, uint32_t* audio_per_tile, uint32_t* lds_bytes, uint32_t* block_threads)
 {
     if (!d) return FMD_ERR_INVALID_ARG;
+    if (block_threads) *block_threads = FMD_BLOCK_THREADS;
+    if (d->last_kernel.family != FMD_KERNEL_NONE) {          // what the most recent launch actually ran
+        if (audio_per_tile) *audio_per_tile = d->last_kernel.kt;
+        if (lds_bytes) *lds_bytes = d->last_kernel.lds;
+        return FMD_OK;
+    }
+    // before the first launch: what a bank in one phase class, fed whole read_sync buffers, will run
     const bool streaming = d->stream_ok && d->C >= 8u && d->block_ns == 0u && tile_kernel_ok(d);   // what a bank in one phase class runs
     if (audio_per_tile) *audio_per_tile = streaming ? d->rs.kt : d->r.kt;
     if (lds_bytes) {
@@ -791,8 +784,21 @@ int fmd_demod_tiling(const fmd_demod* d, uint32_t* audio_per_tile, uint32_t* lds
         L.stream = streaming ? 1u : 0u;
         *lds_bytes = (uint32_t)(tile_kernel_ok(d) ? fmd_tile_lds_bytes(L) : fmd_generic_lds_bytes(L));
     }
-    if (block_threads) *block_threads = tile_kernel_ok(d) ? d->block_threads : FMD_BLOCK_THREADS;
     return FMD_OK;
+}
+
+int fmd_demod_last_kernel(const fmd_demod* d, char* name, size_t cap)
+{
+    if (!d || !name || cap == 0) return FMD_ERR_INVALID_ARG;
+    const FmdKernelId& k = d->last_kernel;
+    int n = 0;
+    switch (k.family) {                                      // the names rocprofv3 --kernel-trace prints for these launches
+        case FMD_KERNEL_TILE:    n = snprintf(name, cap, "fmd_tk::fmd_demod_tile_kernel<%d, %d>", (int)k.dh, (int)k.fast); break;
+        case FMD_KERNEL_STREAM:  n = snprintf(name, cap, "fmd_tk::fmd_demod_stream_kernel<%d, %d>", (int)k.dh, (int)k.fast); break;
+        case FMD_KERNEL_GENERIC: n = snprintf(name, cap, "fmd_demod_generic_kernel<%s>", k.dh ? "true" : "false"); break;
+        default:                 n = snprintf(name, cap, "%s", ""); break;
+    }
+    return n < 0 || (size_t)n >= cap ? FMD_ERR_CAPACITY : FMD_OK;
 }
 
 int fmd_demod_set_tiling(fmd_demod* d, uint32_t audio_per_tile)

@@ -1,7 +1,6 @@
 // fmd_device.h -- device-side helpers shared by the gfx950 kernels (fmd_generic_kernel.hip,
-// fmd_tile_kernel.hip).  Reference citations: examples/simple_fm.rs of ccostes/rtl-sdr-rs v0.3.1.
-#ifndef FMD_DEVICE_H
-#define FMD_DEVICE_H
+// fmd_tile_body.h, fmd_firdemod.hip).  Reference citations: examples/simple_fm.rs of ccostes/rtl-sdr-rs v0.3.1.
+#pragma once
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -118,39 +117,12 @@ __device__ __forceinline__ int sdot2(uint32_t a, uint32_t b)
     return __builtin_amdgcn_sdot2(__builtin_bit_cast(fmd_s2, a), __builtin_bit_cast(fmd_s2, b), 0, false);
 }
 
-// Demod::polar_discriminant_fast (:377-380) + fast_atan2 (:383-405), branch-free, for packed operands
-// (re | im << 16, components fit i16).  c = a * conj(b) is returned for the f64 sample.
-// Division: |quotient| <= 4097, so an f32 estimate is within 1 and one exact (wrapping) remainder fixes
-// it; valid while |x| + |y| < 2^30, which holds for every downsample <= 128 (|lp| <= 128 * D).  Same results
-// as fmd_fast_atan2 (tested).
-__device__ __forceinline__ int disc_fast(uint32_t a, uint32_t b)
-{
-    const uint32_t a_sw = __builtin_amdgcn_alignbit(a, a, 16);          // (im, re)
-    const uint32_t b_cj = (b & 0xFFFFu) | ((0u - (b >> 16)) << 16);      // (re, -im)
-    const int cr = sdot2(a, b);                                          // ar*br + ai*bi
-    const int ci = sdot2(a_sw, b_cj);                                    // ai*br - ar*bi
-    const uint32_t ux = (uint32_t)cr;
-    const uint32_t my = (uint32_t)(ci >> 31);                            // sign masks: (v ^ m) - m = m ? -v : v
-    const uint32_t yabs = ((uint32_t)ci ^ my) - my;
-    const uint32_t dif = ux - yabs, sum = ux + yabs;
-    const bool xpos = cr >= 0;
-    const int num = (int)((xpos ? dif : sum) << 12);                     // the i64 product truncated to i32 (:397,399)
-    const uint32_t den = xpos ? sum : yabs - ux;
-    const uint32_t mn = (uint32_t)(num >> 31);
-    const uint32_t unum = ((uint32_t)num ^ mn) - mn;
-    uint32_t q = (uint32_t)((float)unum * __builtin_amdgcn_rcpf((float)den));
-    const int rem = (int)(unum - q * den);
-    q = q + (rem >= (int)den ? 1u : 0u) - (rem < 0 ? 1u : 0u);
-    const uint32_t qs = (q ^ mn) - mn;                                   // truncating signed quotient
-    const uint32_t angle = (xpos ? (1u << 12) : (3u << 12)) - qs;
-    const uint32_t res = (angle ^ my) - my;
-    return den == 0u ? 0 : (int)res;                                     // x == 0 && y == 0 (:388)
-}
-
-// The same function without a single select, used by the masked-window loop: there hipcc turns disc_fast's
-// `?:` into VCC-masked v_cndmask_b32_e32, which issues ~4x slower than the SGPR-masked e64 form it picks in
-// the whole-dword loop (tools/valubench.hip).  Measured: this form -1.5 % at D = 7 in the masked loop, but
-// +1.2 ... 2.5 % in the whole-dword loop, which therefore keeps disc_fast.
+// Demod::polar_discriminant_fast (:377-380) + fast_atan2 (:383-405), branch-free and without a single select, for packed
+// operands (re | im << 16, components fit i16): the integer form, for downsample > 16 (and the fused FIR kernel when its
+// filter gain exceeds the f32 form's range).  hipcc turns `?:` into VCC-masked v_cndmask_b32_e32, which issues ~4x slower
+// than the SGPR-masked e64 form (tools/valubench.hip), hence sign-mask arithmetic throughout.
+// Division: |quotient| <= 4097, so an f32 estimate is within 1 and one exact (wrapping) remainder fixes it; valid while
+// |x| + |y| < 2^30, which holds for every downsample <= 128 (|lp| <= 128 * D).  Same results as fmd_fast_atan2 (tested).
 // With mx / my the sign masks of x / y:  den = |x| + |y| in both branches of :390-400, the numerator is
 // +-(|x| - |y|) with the sign of x, and the base angle is pi/4 + (x < 0 ? pi/2 : 0).
 __device__ __forceinline__ int disc_nosel(uint32_t a, uint32_t b)
@@ -195,18 +167,28 @@ __device__ __forceinline__ int disc_nosel(uint32_t a, uint32_t b)
 // 1-ulp band against fast_atan2 itself, for boxcar sums up to 128 * 16 and at 128 * 18 to show the limit; the GPU
 // parity and fuzz tests run it on the hardware.
 #define FMD_DISC_F32_MAX_D 16
-// f32 -> i32 with the hardware's own rule for NaN (v_cvt_i32_f32: NaN -> 0).  `(int)x` is what hipcc selects that
-// instruction for; the wrapper names the property the callers rely on (and the tests pin: (0, 0) inputs).
-__device__ __forceinline__ int fmd_cvt_i32_nan0(float v) { return (int)v; }
+// f32 -> i32 with the hardware's own rule for NaN: v_cvt_i32_f32 returns 0 for NaN (and saturates), which disc_f32_xy
+// relies on for fast_atan2's `(0, 0) -> 0`.  A C++ `(int)v` of NaN is undefined behaviour (fptosi poison in LLVM: right
+// only while the compiler happens not to fold it) and the saturating intrinsic expands to ten instructions on gfx950, so
+// the instruction is named outright.  It is an ordinary one-cycle-class VALU conversion of a value produced by plain VALU
+// code: none of the gfx950 hazards that made inline asm unsafe around the dot products (see below) applies to it.
+// tests: test_near_silence, the silence cases of tests/test_gpu_fuzz.py, test_axis_aligned_full_scale.
+__device__ __forceinline__ int fmd_cvt_i32_nan0(float v)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    int r;
+    asm("v_cvt_i32_f32 %0, %1" : "=v"(r) : "v"(v));
+    return r;
+#else
+    return v != v ? 0 : (int)v;                           // host pass: never executed, kept well-defined
+#endif
+}
 __device__ __forceinline__ float clamp01(float v) { return __builtin_amdgcn_fmed3f(v, 0.0f, 1.0f); }   // folds into a clamp modifier
 __device__ __forceinline__ float u2f(uint32_t u) { return __builtin_bit_cast(float, u); }
 __device__ __forceinline__ uint32_t f2u(float f) { return __builtin_bit_cast(uint32_t, f); }
 
 // fast_atan2 (:383-405) of the exact f32 product (xf, yf) = a * conj(b); see above.
 // NOWRAP: the caller guarantees |s| < 2^19 (downsample <= 3: 2 (128 * 3)^2 = 294 912), where `(4096 * s) as i32` cannot wrap.
-#ifndef FMD_DISC_TRIM
-#define FMD_DISC_TRIM 1              /* 0: the round-2 form (den + 2^-30 under the reciprocal, result * clamp(den + den)); A/B builds */
-#endif
 template <bool NOWRAP = false>
 __device__ __forceinline__ int disc_f32_xy(float xf, float yf)
 {
@@ -216,26 +198,18 @@ __device__ __forceinline__ int disc_f32_xy(float xf, float yf)
     const float s = u2f(f2u(t) ^ sx);
     const float big = 13194139533312.0f;                                 // 1.5 * 2^43
     const float sp = NOWRAP ? s : s - (((s + 0.5f) + big) - big);        // s mod 2^20, signed
-#if FMD_DISC_TRIM
     // (0, 0): den = 0 -> rcp = inf, |sp| * inf = 0 * inf = NaN, and NaN runs through floor / fma / the clamped subtract /
     // the sign xors to the final conversion, where v_cvt_i32_f32 turns it into 0 -- exactly fast_atan2's `(0, 0) -> 0`
     // (:388).  Three instructions fewer than guarding the reciprocal and multiplying by a 0 / 1 factor
     // (tests: test_near_silence, test_gpu_fuzz silence cases, tests/test_disc_f32_model.py for den >= 1).
     const float c = __builtin_amdgcn_rcpf(den) * 4095.998046875f;
-#else
-    const float c = __builtin_amdgcn_rcpf(den + 0x1p-30f) * 4095.998046875f;   // + 2^-30: finite for den == 0, no change otherwise
-#endif
     const float qf = __builtin_floorf(__builtin_fabsf(sp) * c);
     const float r = __builtin_fmaf(-qf, den, __builtin_fabsf(sp) * 4096.0f);
     const float q = qf + clamp01(r - (den - 1.0f));
     const float qs = u2f(f2u(q) ^ (f2u(sp) & 0x80000000u));
     const float base = 8192.0f - u2f(0x45800000u ^ sx);                  // 4096 or 12288 (:395,400)
     const float res = u2f(f2u(base - qs) ^ (f2u(yf) & 0x80000000u));
-#if FMD_DISC_TRIM
     return fmd_cvt_i32_nan0(res);
-#else
-    return (int)(res * clamp01(den + den));
-#endif
 }
 
 __device__ __forceinline__ int disc_f32(uint32_t a, uint32_t b)
@@ -248,9 +222,6 @@ __device__ __forceinline__ int disc_f32(uint32_t a, uint32_t b)
 // The same with the samples' components already in f32 (exact integers): c = a * conj(b) by two multiplies and two
 // fmas -- every product is below 2^22 and every sum below 2^23 for downsample <= 16, so nothing rounds -- instead of
 // pack, swap, conjugate, two dot products and two conversions.
-#ifndef FMD_ZERO_FIX
-#define FMD_ZERO_FIX 0.0f            /* -0.0f in a test build switches the canonicalisation off: test_near_silence must then fail */
-#endif
 template <bool NOWRAP = false>
 __device__ __forceinline__ int disc_f32_c(float ar, float ai, float br, float bi)
 {
@@ -259,8 +230,8 @@ __device__ __forceinline__ int disc_f32_c(float ar, float ai, float br, float bi
     // (x too: with x = -0 the sign-bit form takes fast_atan2's "x < 0" branch, which agrees with the "x >= 0" one at x = 0 only
     //  while `(4096 * s) as i32` does not wrap: (x, y) = (-0, 2^19) -- a = (0, -768), b = (-768, 0) at downsample 6 -- would
     //  come out as 16384 instead of 8192.)
-    const float xf = __builtin_fmaf(ai, bi, ar * br) + FMD_ZERO_FIX;        // ar*br + ai*bi
-    const float yf = __builtin_fmaf(ai, br, -(ar * bi)) + FMD_ZERO_FIX;     // ai*br - ar*bi
+    const float xf = __builtin_fmaf(ai, bi, ar * br) + 0.0f;        // ar*br + ai*bi
+    const float yf = __builtin_fmaf(ai, br, -(ar * bi)) + 0.0f;     // ai*br - ar*bi
     return disc_f32_xy<NOWRAP>(xf, yf);
 }
 
@@ -271,4 +242,3 @@ __device__ __forceinline__ int lp_im(uint32_t p) { return (int)(int16_t)(p >> 16
 
 }  // namespace fmd_dev
 
-#endif

@@ -188,9 +188,9 @@ __global__ void __launch_bounds__(kFirThreads, 8) fmd_fir_mfma_kernel(const FirL
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     const uint32_t tid = threadIdx.x;
-    __builtin_amdgcn_s_setprio(3);                                  // get the loads out first (see fmd_tile_kernel.hip)
+    __builtin_amdgcn_s_setprio(3);                                  // get the loads out first (see fmd_tile_body.h)
     uint32_t c = blockIdx.y + 65535u * blockIdx.z, tix = blockIdx.x;
-    // XCD-aware block -> (channel, tile) mapping as in fmd_tile_kernel.hip: XCD k works through its own contiguous
+    // XCD-aware block -> (channel, tile) mapping as in fmd_tile_body.h: XCD k works through its own contiguous
     // eighth of the channels tile after tile (about -1 % per call here).
     uint32_t ntiles = gridDim.x;
     if (L.xcd_swizzle == 3u) {                                      // grid (8, tiles, ceil(C / 8)): blockIdx.x is the XCD

@@ -1,8 +1,7 @@
 // fmd_fir_common.h -- host-side construction of the banded Toeplitz tap matrix the matrix-core FIR kernels use
 // (fmd_fir.hip: stand-alone operator; fmd_firdemod.hip: FIR fused with the discriminator and the resampler).
 // See the header comment of fmd_fir.hip for the data path.
-#ifndef FMD_FIR_COMMON_H
-#define FMD_FIR_COMMON_H
+#pragma once
 
 #include <stdint.h>
 
@@ -55,4 +54,3 @@ inline bool fmd_fir_build_mfma(const int16_t* taps, uint32_t n_taps, uint32_t de
     return true;
 }
 
-#endif  // FMD_FIR_COMMON_H

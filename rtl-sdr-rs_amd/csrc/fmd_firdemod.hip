@@ -92,9 +92,6 @@ struct FirDemodLaunch {
     FdRow rows[kFdRows];
 };
 
-#ifndef FD_PREXOR
-#define FD_PREXOR 0   /* measured: equal to slightly slower (0.1505 vs 0.1477 ms); the extra barrier costs what the 57 v_xor per wave save */
-#endif
 #ifdef FMD_EXPERIMENT
 #define FD_ABLATE(bit) ((L.dbg >> (bit)) & 1u)
 #define FD_KNOB_PC_EVEN ((L.dbg >> 8) & 1u)                /* A/B: keep an even column pitch (FMD_DBG bit 8) */
@@ -150,7 +147,7 @@ __global__ void __launch_bounds__(kThreads, 8) fmd_firdemod_kernel(const FirDemo
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     const uint32_t tid = threadIdx.x, lane = tid & 63u;
     const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid >> 6));   // scalar: the group tests below become s_cbranch
-    __builtin_amdgcn_s_setprio(3);                           // get the loads out first (see fmd_tile_kernel.hip)
+    __builtin_amdgcn_s_setprio(3);                           // get the loads out first (see fmd_tile_body.h)
     uint32_t c, t;
     if (L.xcd == 3u) { c = blockIdx.x * gridDim.z + blockIdx.z; t = blockIdx.y; }   // grid (8, tiles, ceil(C / 8))
     else { c = blockIdx.y + 65535u * blockIdx.z; t = blockIdx.x; }
@@ -203,14 +200,8 @@ __global__ void __launch_bounds__(kThreads, 8) fmd_firdemod_kernel(const FirDemo
     __builtin_amdgcn_s_waitcnt(0x0F70);                      // vmcnt(0): the LDS-DMAs (and the A fragments) have landed
     __syncthreads();
 
-    // u8 -> s8 (b - 128) once per staged byte: every byte is the B operand of ~5 MFMAs (columns 64 bytes apart, 320-byte
-    // windows), so flipping the sign bits here costs a fifth of the v_xor the fragment reads would need (70 -> 13 per
-    // wave), for one more barrier
-    if (FD_PREXOR) {
-        for (uint32_t i = tid; i < nq; i += kThreads) lq[i] = lq[i] ^ (int)0x80808080;
-        __syncthreads();
-    }
-
+    // (Measured and rejected twice: one u8 -> s8 pass over the staged bytes instead of an xor per fragment read -- the extra
+    //  barrier costs what the v_xor it saves would, profiles/HISTORY.md.)
     // ---- FIR on the matrix cores (see fmd_fir.hip) -----------------------------------------------------------
     const uint8_t* lb = reinterpret_cast<const uint8_t*>(lds);
     const uint32_t groups = (no + 63u) >> 6;
@@ -258,7 +249,7 @@ __global__ void __launch_bounds__(kThreads, 8) fmd_firdemod_kernel(const FirDemo
 #pragma unroll
                 for (int k = 0; k < NKU; ++k) {
                     fd_i4 B = *reinterpret_cast<const fd_i4*>(col + 64 * k + 16u * q);
-                    if (!FD_PREXOR) B = B ^ (int)0x80808080;                                   // u8 -> s8
+                    B = B ^ (int)0x80808080;                                                   // u8 -> s8
                     acc[gi] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A[k], B, acc[gi], 0, 0, 0);
                 }
             }
@@ -285,7 +276,7 @@ __global__ void __launch_bounds__(kThreads, 8) fmd_firdemod_kernel(const FirDemo
     if (jfirst < 0 && tid == 0) ypk[0] = pack_lp(st.demod_pre_re, st.demod_pre_im);     // lp[-1]
     // audio group k of the tile (k == nk: the trailing partial group): zero its accumulator and tabulate its first and
     // last discriminator sample -- sample k0 + k ends at e = eq + k * fa + (er + k * fb) / sr and holds fa samples, or
-    // fa + 1 when the remainder of that division is below fb (fmd_tile_kernel.hip, low_pass_real): one division per
+    // fa + 1 when the remainder of that division is below fb (fmd_tile_body.h, low_pass_real): one division per
     // GROUP here instead of one per lane in the pass below
     int* const gse = gsum + (r.kt + 2u);
     for (uint32_t k = tid; k <= r.kt; k += kThreads) {

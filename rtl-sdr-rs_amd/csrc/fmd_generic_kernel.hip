@@ -2,7 +2,7 @@
 // the device, (2) the synthetic IQ source.  gfx950 only.
 //
 // The generic kernel fuses every pass of Demod::demodulate (examples/simple_fm.rs:256-269) exactly
-// like the production tile kernel (fmd_tile_kernel.hip) but makes no assumption beyond
+// like the production tile kernel (fmd_tile_body.h) but makes no assumption beyond
 // fmd_ranges_fit32(): any downsample, any phase per channel, any tiling.  It is what runs
 // when the phase-class plans do not apply (> FMD_MAX_CLASSES distinct phases in one bank, or reduced
 // rates beyond the exact-small-divide range of the tile kernel), under FMD_FORCE_GENERIC=1 (experiment build), and for
@@ -217,13 +217,14 @@ size_t fmd_generic_lds_bytes(const FmdLaunch& L)
     return ((size_t)L.raw_cap + per * (size_t)L.lp_cap + 2u * (size_t)L.lp_cap + 15u) & ~(size_t)15u;
 }
 
-hipError_t fmd_launch_generic(const FmdLaunch& L, hipStream_t stream)
+hipError_t fmd_launch_generic(const FmdLaunch& L, hipStream_t stream, FmdKernelId* used)
 {
     const size_t lds = fmd_generic_lds_bytes(L);
     const uint64_t blocks = (uint64_t)L.n_channels * L.tiles;
     if (blocks == 0 || blocks > 0x7FFFFFFFull) return hipErrorInvalidValue;
     if (L.r.D > FMD_MAX_DOWNSAMPLE) hipLaunchKernelGGL(fmd_demod_generic_kernel<true>, dim3((uint32_t)blocks), dim3(FMD_BLOCK_THREADS), lds, stream, L);
     else hipLaunchKernelGGL(fmd_demod_generic_kernel<false>, dim3((uint32_t)blocks), dim3(FMD_BLOCK_THREADS), lds, stream, L);
+    if (used) { used->family = FMD_KERNEL_GENERIC; used->dh = L.r.D > FMD_MAX_DOWNSAMPLE ? 1 : 0; used->fast = 0; used->kt = L.r.kt; used->lds = (uint32_t)lds; }
     return hipGetLastError();
 }
 

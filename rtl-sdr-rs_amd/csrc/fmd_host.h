@@ -1,7 +1,6 @@
 // fmd_host.h -- host-side helpers shared by the translation units of libfmd_hip.so (fmd_api.cpp, fmd_fir.hip,
 // fmd_firdemod.hip, fmd_sink.cpp).  Not part of the C ABI.
-#ifndef FMD_HOST_H
-#define FMD_HOST_H
+#pragma once
 
 #include <hip/hip_runtime.h>
 
@@ -73,4 +72,3 @@ struct FmdStreamOrder {
     void destroy() { if (ev) (void)hipEventDestroy(ev); ev = nullptr; have_last = false; }
 };
 
-#endif  // FMD_HOST_H

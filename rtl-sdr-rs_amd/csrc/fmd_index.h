@@ -5,7 +5,7 @@
 // the discriminator (fm_demod :355-367) and the fractional boxcar resampler (low_pass_real
 // :408-426).  None of their *index* state depends on sample values, so every output is a
 // pure function of (call-start phases, position).  This header is that algebra; the HIP
-// kernels (fmd_tile_kernel.hip, fmd_generic_kernel.hip), the host bookkeeping (fmd_api.cpp) and the CPU closed-form
+// kernels (fmd_tile_body.h, fmd_generic_kernel.hip), the host bookkeeping (fmd_api.cpp) and the CPU closed-form
 // model used by the tests (oracle/closed_form.cpp) all include it, so the tests exercise
 // the very expressions the kernel uses.
 //
@@ -22,8 +22,7 @@
 //
 // All index arithmetic is unsigned 32-bit; fmd_ranges_fit32() is the host-side guard that
 // makes that exact (a call that fails it is rejected with FMD_ERR_UNSUPPORTED).
-#ifndef FMD_INDEX_H
-#define FMD_INDEX_H
+#pragma once
 
 #include <stdint.h>
 
@@ -335,4 +334,3 @@ FMD_HD void fmd_mul_conj(int32_t ar, int32_t ai, int32_t br, int32_t bi, int32_t
     ci = (int32_t)((uint32_t)ai * (uint32_t)br - (uint32_t)ar * (uint32_t)bi);
 }
 
-#endif  // FMD_INDEX_H

@@ -1,7 +1,6 @@
 // fmd_internal.h -- what the other translation units of libfmd_hip.so may ask of a fmd_demod handle beyond the C
 // ABI (fmd_api.cpp owns the struct).  Not part of the boundary.
-#ifndef FMD_INTERNAL_H
-#define FMD_INTERNAL_H
+#pragma once
 
 #include "../../include/fmd.h"
 #include "fmd_kernels.h"
@@ -25,4 +24,3 @@ FmdHandleView fmd_internal_view(fmd_demod* d);
 int fmd_internal_resolve_exc(FmdExcBuf* d_exc, int32_t R, uint32_t host_seq, uint32_t state_seq, FmdChanState* d_state_cur,
                              int16_t* host_out, size_t host_cap, uint64_t* guarded, uint64_t* patched);
 
-#endif  // FMD_INTERNAL_H

@@ -1,6 +1,5 @@
-// fmd_kernels.h -- launch descriptors shared by the kernels (fmd_tile_kernel.hip, fmd_generic_kernel.hip) and fmd_api.cpp.
-#ifndef FMD_KERNELS_H
-#define FMD_KERNELS_H
+// fmd_kernels.h -- launch descriptors shared by the kernels (fmd_tile_body.h, fmd_generic_kernel.hip) and fmd_api.cpp.
+#pragma once
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -8,9 +7,7 @@
 #include "fmd_index.h"
 
 #define FMD_BLOCK_THREADS 256
-#ifndef FMD_MAX_CLASSES
 #define FMD_MAX_CLASSES 16       /* phase classes one launch can carry (32-byte plans in the kernel arguments) */
-#endif
 #define FMD_STREAM_MAX_ROUNDS 12  /* register-streaming kernel: wave-rounds of 127 decimated samples per wave and tile (straight-line code) */
 #define FMD_TILE_MAX_LOADS 8      /* 16-byte chunks per thread the tile kernel can stage */
 
@@ -107,7 +104,6 @@ struct FmdLaunch {
     uint32_t  seq;            // launch sequence number (FmdF64Exc::seq)
     int32_t   f64_skew;       // -DFMD_EXPERIMENT builds only: added to the kernel's value of guarded samples (patch-path test)
     uint32_t dbg;             // ablation bits, honoured only by -DFMD_EXPERIMENT builds (tuning; never shipped)
-    uint32_t block_threads;   // one-block-per-tile kernel: 64, 128 or 256 (default) threads
     uint32_t stream;          // 1: register-streaming kernel (fmd_demod_stream_kernel): no LDS staging, raw_cap unused
     // ---- tile kernel only (phase-class plans; see fmd_index.h) ----
     uint32_t Qt;              // decimated samples per full tile = kt * fr / sr (== tl.Qt)
@@ -116,7 +112,6 @@ struct FmdLaunch {
     float    inv_sr, inv_R;
     uint32_t sr_shift;        // log2(sr) when sr is a power of two, else 32
     FmdMagic magic_R;         // fmd_sdiv_magic(sum, magic_R) == sum / R for |sum| < 2^24
-    const uint32_t* bx_amat;  // matrix-core boxcar (fmd_boxcar_mfma.h): A fragments [2][ceil(DH/2)][64 lanes][4 dwords], or nullptr
     const uint8_t* chan_class;// [n_channels] class id, or nullptr when every channel is class 0
     FmdClassPlan cls[FMD_MAX_CLASSES];
 };
@@ -135,8 +130,19 @@ bool fmd_tile_kernel_supports(const FmdRates& r, uint32_t raw_cap);
 
 size_t fmd_generic_lds_bytes(const FmdLaunch& L);
 size_t fmd_tile_lds_bytes(const FmdLaunch& L);
-hipError_t fmd_launch_generic(const FmdLaunch& L, hipStream_t stream);
-hipError_t fmd_launch_tile(const FmdLaunch& L, hipStream_t stream);
+// Which kernel a launch ran (fmd_demod_last_kernel): family, instantiation, prologue form, tiling.
+#define FMD_KERNEL_NONE    0
+#define FMD_KERNEL_TILE    1     /* fmd_tk::fmd_demod_tile_kernel<dh, fast>: LDS-DMA staging */
+#define FMD_KERNEL_STREAM  2     /* fmd_tk::fmd_demod_stream_kernel<dh, fast>: register streaming */
+#define FMD_KERNEL_GENERIC 3     /* fmd_demod_generic_kernel<wide> (dh = 1: wide) */
+struct FmdKernelId {
+    uint8_t  family = FMD_KERNEL_NONE;
+    uint8_t  fast = 0;        // 0 general prologue, 1 closed form, 2 per-tile table
+    int16_t  dh = 0;          // template argument: half the (even) downsample, minus the odd one, 0 = catch-all
+    uint32_t kt = 0;          // audio samples per tile
+    uint32_t lds = 0;         // dynamic LDS bytes per block
+};
+hipError_t fmd_launch_generic(const FmdLaunch& L, hipStream_t stream, FmdKernelId* used);
+hipError_t fmd_launch_tile(const FmdLaunch& L, hipStream_t stream, FmdKernelId* used);
 hipError_t fmd_launch_synth(const FmdSynthLaunch& S, hipStream_t stream);
 
-#endif

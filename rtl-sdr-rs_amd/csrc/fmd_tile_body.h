@@ -1,4 +1,6 @@
-// fmd_tile_kernel.hip -- the production demodulation kernels for gfx950 (CDNA4, wave64).
+// fmd_tile_body.h -- device code of the production demodulation kernels for gfx950 (CDNA4, wave64); the kernels are
+// instantiated in fmd_tile_lds_*.hip (LDS-DMA staging, one kernel per downsample factor) and fmd_tile_stream.hip
+// (register streaming, downsample 2 and 4), and launched by fmd_tile_launch.hip.
 //
 // One launch fuses every pass of Demod::demodulate (examples/simple_fm.rs:256-269):
 //   rotate_90 (:276-299) + `as i16 - 127` (:258) + buf_to_complex (:441-450)
@@ -14,24 +16,28 @@
 // per-phase-class plans and per-handle tiling constants (FmdClassPlan, FmdTiling, fmd_index.h), so the
 // device does multiply-adds and at most one small division per tile.
 //   tile_body (shared):
-//     * boxcar: for an even downsample <= 10 a window is DH whole dwords, 3 VALU ops per dword (xor, 2 x dot4)
-//       with per-lane weight registers that already carry the rotation sign of the dword parity; any other
+//     * boxcar: for an even downsample <= 14 a window is DH whole dwords, 3 VALU ops per dword (xor, 2 x dot4)
+//       with weight registers that already carry the rotation sign of the dword parity; any other
 //       downsample / phase runs the same loop with the window's half dwords masked out of the weights;
 //     * predecessor sample from the neighbouring lane (DPP wave_shr:1): a wave-round is 127 new windows
 //       + 1 overlap, two per lane, so there is no LDS exchange and no barrier between boxcar and discriminator;
-//     * discriminator: complex multiply by 2 x v_dot2_i32_i16 on packed (re, im); branch-free
-//       fast_atan2 with an exact f32-reciprocal divide;
+//     * discriminator: a * conj(b) in exact f32 (downsample <= 16) or by 2 x v_dot2_i32_i16 on packed (re, im);
+//       branch-free fast_atan2 with an exact reciprocal divide;
 //     * resampler: one audio sample per lane from the tile's discriminator samples in LDS.
-//   fmd_demod_tile_kernel: one block per tile, LDS-DMA staging (global_load_lds_dwordx4).
-#include "fmd_boxcar_mfma.h"
+#pragma once
+
 #include "fmd_device.h"
 #include "fmd_kernels.h"
 
-#include <cstdlib>
-
-namespace {
+namespace fmd_tk {
 
 using namespace fmd_dev;
+
+constexpr int kThreads = FMD_BLOCK_THREADS;     // one 256-thread block (4 waves) per tile
+constexpr int NW = kThreads / 64;
+// New decimated samples per wave-round: 128 windows minus the overlap.  A block's round stride NW * RS windows keeps a
+// lane's rotation phase fixed (a lane's windows are an even number of samples apart).
+constexpr int RS = 127;
 
 // Ablation switches exist only in -DFMD_EXPERIMENT tuning builds (libfmd_hip_exp.so); the shipped
 // library compiles them to `false`.
@@ -42,38 +48,6 @@ using namespace fmd_dev;
 #define FMD_ABLATE(bit) false
 #define FMD_F64_SKEW 0
 #endif
-#ifndef FMD_ROT_MASK
-#define FMD_ROT_MASK 3               /* rotate the window walk when the dword count is a multiple of 4 (see tile_body) */
-#endif
-#ifndef FMD_DH4_B128
-#define FMD_DH4_B128 1
-#endif
-#ifndef FMD_DPP_DEAD
-#define FMD_DPP_DEAD 1
-#endif
-#ifndef FMD_ODD_KERNELS
-#define FMD_ODD_KERNELS 1
-#endif
-// The boxcar of the adjacent-window rounds on the matrix cores (fmd_boxcar_mfma.h, mfma_pair_rounds below): bit-exact, and
-// measured 1 ... 4 % SLOWER than the v_dot4 form at every downsample it covers (profiles/r03_boxcar_mfma.md),
-// so it is compiled into the -DFMD_EXPERIMENT build only (FMD_BX_MFMA=1 selects it there at run time).
-#ifndef FMD_BX_MFMA
-#ifdef FMD_EXPERIMENT
-#define FMD_BX_MFMA 1
-#else
-#define FMD_BX_MFMA 0
-#endif
-#endif
-#ifndef FMD_PAIR
-#define FMD_PAIR 1                   /* 0: windows i and i + 64 per lane, packed samples (A/B builds) */
-#endif
-#ifndef FMD_MASKED_UNROLL
-#define FMD_MASKED_UNROLL 1      /* 0: run-time masked-window loop for every dword count (A/B builds) */
-#endif
-#ifndef FMD_USE_F32
-#define FMD_USE_F32 1            /* 0: integer discriminator everywhere (A/B builds) */
-#endif
-
 // Explicit address spaces exist only in the device pass (the host pass parses the same bodies).
 #if defined(__HIP_DEVICE_COMPILE__)
 #define FMD_AS_GLOBAL __attribute__((address_space(1)))
@@ -85,12 +59,10 @@ using namespace fmd_dev;
 #define FMD_AS_LDS
 #endif
 
-// Cache policy of the staging loads (aux of global_load_lds): 0 = default, 2 = nt (read once, do not keep).
-// Settled-clock A/B at the bench configuration, three interleaved rounds: nt 0.1815-0.1818 ms vs default
-// 0.1826-0.1839 ms (-0.8 %); equal at the other configurations tried.
-#ifndef FMD_DMA_AUX
-#define FMD_DMA_AUX 2
-#endif
+// Cache policy of the staging loads (aux of global_load_lds): 2 = nt (read once, do not keep).  Settled-clock A/B at the
+// bench configuration: nt -0.8 % against the default policy (0), equal elsewhere; on some boxes the default is 15 % slower
+// (profiles/HISTORY.md).
+constexpr int kDmaAux = 2;
 
 __device__ __forceinline__ uint32_t wave_shr1(uint32_t v)
 {
@@ -107,7 +79,7 @@ __device__ __forceinline__ uint32_t wave_shr1_old(uint32_t old, uint32_t v)
 // the destination is tied to `old`, so the v_mov 0 of wave_shr1 disappears.  bound_ctrl stays off (see fmd_device.h).
 __device__ __forceinline__ uint32_t wave_shr1_dead(uint32_t dead, uint32_t v)
 {
-    return (uint32_t)__builtin_amdgcn_update_dpp(FMD_DPP_DEAD ? (int)dead : 0, (int)v, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
+    return (uint32_t)__builtin_amdgcn_update_dpp((int)dead, (int)v, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
 }
 
 // lane l <- v[(l + 63) % 64]: lane 0 receives lane 63.
@@ -136,7 +108,7 @@ __device__ __forceinline__ uint32_t pack_lp_perm(int re, int im)
 __device__ __forceinline__ void lds_dma16(const unsigned char* g, unsigned char* lds_wave_base)
 {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
-                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, FMD_DMA_AUX);
+                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, kDmaAux);
 }
 
 // Where a tile's bytes are and where they land in LDS (all wave-uniform).
@@ -175,11 +147,10 @@ __device__ __forceinline__ TileCtx tile_setup(const FmdLaunch& L, uint32_t c, ui
 
 // Synchronous staging for the one tile whose last chunk crosses the end of the input array
 // (array sizes are multiples of 8, chunks of 16).
-template <int NT>
 __device__ __forceinline__ void stage_slow(const FmdLaunch& L, const TileCtx& X, unsigned char* smem, uint32_t tid)
 {
     const uint64_t gend = (uint64_t)(uintptr_t)L.iq + L.total_bytes;
-    for (uint32_t i = tid; i < X.nchunks; i += NT) {
+    for (uint32_t i = tid; i < X.nchunks; i += kThreads) {
         const uint64_t a = X.a0 + 16ull * i;
         uint4 v;
         if (a + 16 <= gend) v = *reinterpret_cast<const uint4*>((uintptr_t)a);
@@ -235,12 +206,11 @@ __device__ __forceinline__ void tile_exc_flush(const FmdLaunch& L, const TileCtx
 // into 2 * NDW per-lane weight registers and the body is the same 3 VALU instructions per dword as the whole-dword
 // loop -- no run-time trip counts, no per-dword branches.  (Round 1 ran these through the run-time loop below:
 // downsample 7 sat at 57 % of the HBM spec against 70 % for 6 and 8.)
-template <int NDW, int NT>
+template <int NDW>
 __device__ __forceinline__ void masked_rounds(const uint32_t* __restrict__ raw_w, int16_t* __restrict__ d16, int wofs, int s00,
                                               int D, int cnt, uint32_t lane, uint32_t wave, uint32_t wreA, uint32_t wreB,
                                               uint32_t wimA, uint32_t wimB, uint32_t mf, uint32_t ml, int cre, int cim, bool smallD)
 {
-    constexpr int NW = NT / 64, RS = NW == 1 ? 124 : 127;
     uint32_t wr[NDW], wi[NDW];
 #pragma unroll
     for (int u = 0; u < NDW; ++u) {
@@ -268,115 +238,6 @@ __device__ __forceinline__ void masked_rounds(const uint32_t* __restrict__ raw_w
         else { d1 = disc_nosel(pk1, prev1); d2 = disc_nosel(pk2, prev2); }
         if (lane > 0 && i1 < cnt) d16[i1] = (int16_t)d1;
         if (i2 < cnt) d16[i2] = (int16_t)d2;
-    }
-}
-
-// Boxcar on the matrix cores (fmd_boxcar_mfma.h) for the adjacent-window ("pair") rounds of an even downsample 2 DH:
-// lane l = 16 g + c of the wave-round owns windows base + 2 l and base + 2 l + 1, 8 DH contiguous bytes of the staged
-// tile; ceil(DH / 2) chained v_mfma_i32_16x16x64_i8 over the raw bytes (u8 ^ 0x80) against the banded +-1 weight matrix
-// leave (re1, im1, re2, im2) -- the four boxcar sums of the lane's two windows, constants included through the C operand --
-// in the lane's four result registers.  The discriminator stage behind it is the VALU form's, unchanged.
-typedef int fmd_i4 __attribute__((ext_vector_type(4)));
-
-// The tap-weight fragments of the matrix-core boxcar, fetched in the kernel PROLOGUE -- while the tile's LDS-DMAs are in
-// flight -- so that their global-memory latency hides under the tile's own (fetched after the barrier they cost every
-// wave a full memory round trip in front of its first matrix instruction: +9 % launch time, measured).
-template <int DH>
-struct BxFrag {
-    static constexpr int NM = DH > 0 && DH <= (int)FMD_BX_MAX_DH ? (DH + 1) / 2 : 1;
-    fmd_i4 A[NM];
-    bool use;                 // block-uniform: this tile's pair rounds run on the matrix cores
-    bool o1;                  // rotation parity of a wave's first window (wave-uniform)
-    int e;                    // 0 / -1: the rounds start one window early (odd DH, first window at an odd dword)
-};
-
-template <int DH, int NT>
-__device__ __forceinline__ BxFrag<DH> bx_prefetch(const FmdLaunch& L, const TileCtx& X, uint32_t tid)
-{
-    BxFrag<DH> F;
-    F.use = false; F.o1 = false; F.e = 0;
-#pragma unroll
-    for (int m = 0; m < BxFrag<DH>::NM; ++m) F.A[m] = fmd_i4{0, 0, 0, 0};
-    if constexpr (FMD_BX_MFMA && FMD_USE_F32 && FMD_PAIR && DH > 0 && DH <= (int)FMD_BX_MAX_DH) {
-        constexpr int NW = NT / 64, RS = NW == 1 ? 124 : 126, NM = BxFrag<DH>::NM;
-        const uint32_t p0 = L.cls[X.cls].p0, hp = p0 >> 1;
-        const int wbase = X.wofs - (int)hp + DH * X.jfirst;
-        // whole-dword windows (even boxcar phase); for an even DH they must also start at even dwords (8-byte aligned reads)
-        F.use = L.bx_amat != nullptr && (p0 & 1u) == 0u && ((DH & 1) != 0 || (wbase & 1) == 0) && !FMD_ABLATE(6);
-        if (F.use) {
-            const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid >> 6));
-            F.e = (DH & 1) ? -(wbase & 1) : 0;
-            const int jw = X.jfirst + F.e + (int)wave * RS;
-            F.o1 = ((((DH & 1) ? ((uint32_t)jw ^ hp) : hp)) & 1u) != 0u;
-            typedef const FMD_AS_GLOBAL fmd_i4* gq;
-            const gq amat = (gq)(uintptr_t)L.bx_amat + (F.o1 ? NM * 64 : 0) + (tid & 63u);
-#pragma unroll
-            for (int m = 0; m < NM; ++m) F.A[m] = amat[m * 64];
-        }
-    }
-    return F;
-}
-
-template <int DH, int NT>
-__device__ __forceinline__ void mfma_pair_rounds(const BxFrag<DH>& F, const unsigned char* __restrict__ smem, int16_t* __restrict__ d16,
-                                                 int wbase, int cnt, uint32_t lane, uint32_t wave)
-{
-    // A round is 128 windows (two per lane); RS of them are new.  RS is EVEN here (126, against 127 in the dot-product
-    // form): every round of every wave then starts at a window of the same parity, so the operand reads are 8-byte
-    // aligned in LDS for all of them -- a misaligned ds_read_b64 costs far more than the 0.8 % of extra rounds
-    // (measured: odd downsample halves with 127, where every other wave was misaligned, ran 20 % SLOWER than the
-    // dot-product form).  For an odd DH a tile whose first window sits at an odd dword starts one window early (e = -1:
-    // the extra window only ever serves as a predecessor); for an even DH the caller checks wbase.  The last window of a
-    // round (lane 63's second) is the next round's first new one: both store the same value to the same slot.
-    constexpr int NW = NT / 64, RS = NW == 1 ? 124 : 126;
-    constexpr int NM = (DH + 1) / 2;
-    constexpr uint32_t STRIDE = 4u * DH * NW * RS;           // bytes from one round of a wave to its next
-    wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)wave);   // scalar: the round loop's control flow becomes s_cbranch
-    const int last = cnt - 1;
-    const int e = F.e;
-    const bool o1 = F.o1, o2 = o1 != ((DH & 1) != 0);        // rotation parity of the lane's two windows (wave-uniform)
-    const int c1 = 2 * (o1 ? DH / 2 : (DH + 1) / 2), c2 = 2 * (o2 ? DH / 2 : (DH + 1) / 2);
-    int base = e + (int)wave * RS;
-    if (base >= last) return;
-    // Explicit LDS pointers: 32-bit addresses that wrap, and a read outside the allocation returns 0 (windows before the
-    // tile's first byte / beyond its last only feed results that are not stored) -- through a generic pointer the same
-    // read would be a flat access outside the aperture, which faults.
-    typedef const FMD_AS_LDS unsigned char* lds_bp;
-    typedef const FMD_AS_LDS uint2* lds_u2p;
-    // the lane's own span of the wave's first round: windows base + 2 lane and base + 2 lane + 1, 8 DH contiguous bytes
-    lds_bp p = (lds_bp)smem + (4u * (uint32_t)(wbase + DH * base) + 8u * DH * lane);
-    const fmd_i4 cinit = {DH, c1, DH, c2};                   // the additive constants of the two windows (re gets +1 per dword)
-    uint32_t dead1 = 0, dead2 = 0;                           // operand registers that are dead after the matrix instruction (DPP `old`)
-    auto boxcar = [&](lds_bp pr) {
-        fmd_i4 acc = cinit;
-#pragma unroll
-        for (int m = 0; m < NM; ++m) {
-            const uint2 lo = *(lds_u2p)(pr + 16 * m);
-            const uint2 hi = *(lds_u2p)(pr + 16 * m + 8);
-            const fmd_i4 B = {(int)(lo.x ^ 0x80808080u), (int)(lo.y ^ 0x80808080u), (int)(hi.x ^ 0x80808080u), (int)(hi.y ^ 0x80808080u)};
-            acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(F.A[m], B, acc, 0, 0, 0);
-            dead1 = (uint32_t)B.x; dead2 = (uint32_t)B.y;
-        }
-        return acc;
-    };
-    // software pipeline: the next round's reads and matrix instructions are issued before the current round's
-    // discriminators, which then run in their shadow (no wait states in front of the conversions)
-    fmd_i4 cur = boxcar(p);
-    for (;;) {
-        const int nb = base + NW * RS;
-        const bool more = nb < last;                         // wave-uniform
-        fmd_i4 nxt = cur;
-        if (more) { p += STRIDE; nxt = boxcar(p); }
-        __builtin_amdgcn_sched_barrier(0);
-        const int i1 = base + 2 * (int)lane, i2 = i1 + 1;
-        const float ar1 = (float)cur.x, ai1 = (float)cur.y, ar2 = (float)cur.z, ai2 = (float)cur.w;
-        const float br1 = u2f(wave_shr1_dead(dead1, f2u(ar2))), bi1 = u2f(wave_shr1_dead(dead2, f2u(ai2)));   // second window of lane l - 1
-        const int d1 = disc_f32_c<DH == 1>(ar1, ai1, br1, bi1);
-        const int d2 = disc_f32_c<DH == 1>(ar2, ai2, ar1, ai1);
-        if (lane > 0 && i1 < cnt) d16[i1] = (int16_t)d1;
-        if (i2 < cnt) d16[i2] = (int16_t)d2;
-        if (!more) break;
-        cur = nxt; base = nb;
     }
 }
 
@@ -417,11 +278,11 @@ __device__ __forceinline__ void stream_load(const unsigned char* __restrict__ p,
     if constexpr (NDW % 2 == 1) w[NDW - 1] = __builtin_nontemporal_load((g1)(uintptr_t)(p + 4 * (NDW - 1)));
 }
 
-template <int DH, int NT>
+template <int DH>
 __device__ __forceinline__ void stream_pair_rounds(const unsigned char* __restrict__ chan, uint32_t nbytes, int16_t* __restrict__ d16,
                                                    int jfirst, uint32_t hp, int cnt, uint32_t lane, uint32_t wave)
 {
-    constexpr int NW = NT / 64, RS = NW == 1 ? 124 : 127, NDW = 2 * DH;
+    constexpr int NDW = 2 * DH;
     constexpr int P = NDW <= 6 ? 4 : (NDW <= 10 ? 3 : 2);   // rounds in flight per wave (register budget: 64 VGPRs)
     constexpr int32_t STRIDE = 4 * DH * NW * RS;             // bytes from one round of a wave to its next
     wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)wave);
@@ -487,8 +348,8 @@ __device__ __forceinline__ void stream_pair_rounds(const unsigned char* __restri
 // registers (stream_pair_rounds), LDS holds the discriminator samples only, and the few one-lane window sums of the
 // call-start patch / the guard record / the state update read the channel in global memory through the same helper
 // (raw_w = the channel-call's first dword, wofs = 0).
-template <int DH, int NT, bool STREAM = false>
-__device__ __forceinline__ void tile_body(const FmdLaunch& L, const TileCtx& X, unsigned char* smem, const BxFrag<DH>& F)
+template <int DH, bool STREAM = false>
+__device__ __forceinline__ void tile_body(const FmdLaunch& L, const TileCtx& X, unsigned char* smem)
 {
     const FmdRates& r = L.r;
     const FmdClassPlan& P = L.cls[X.cls];
@@ -515,10 +376,6 @@ __device__ __forceinline__ void tile_body(const FmdLaunch& L, const TileCtx& X, 
     // m0 = DH*j - p0/2; rotate_90's sign pattern has period 2 dwords, a lane's two windows are 64 samples
     // apart and a wave-round advances by an even number, so the parity of m0 -- hence the weights -- is
     // fixed per lane for the whole tile.
-    constexpr int NW = NT / 64;
-    // new decimated samples per wave-round: 128 windows minus the overlap.  A block's round stride NW * RS windows
-    // must keep a lane's rotation phase fixed (see above); one wave per block (NW == 1) therefore steps 124.
-    constexpr int RS = NW == 1 ? 124 : 127;
     const uint32_t hp = p0 >> 1;
     const int j0 = jfirst + (int)wave * RS + (int)lane;
     const bool odd = ((((DH & 1) ? ((uint32_t)j0 ^ hp) : hp)) & 1u) != 0u;
@@ -534,15 +391,12 @@ __device__ __forceinline__ void tile_body(const FmdLaunch& L, const TileCtx& X, 
     // DH == 4 (downsample 8): lanes 8 dwords apart are a 4-way conflict for dword reads, which costs more than the pair
     // form saves -- unless the windows are 16-byte aligned in LDS (channel buffers aligned, boxcar phase 0: the usual
     // case), where one ds_read_b128 fetches a whole window: then the pair form is taken with two such reads per lane.
-    const bool dh4_aligned = DH == 4 && FMD_DH4_B128 && (((wofs - (int)hp) & 3) == 0);     // block-uniform
+    const bool dh4_aligned = DH == 4 && (((wofs - (int)hp) & 3) == 0);     // block-uniform
     if constexpr (STREAM) {
         // (the host only selects this kernel for an even downsample at an even boxcar phase: whole-dword windows)
         if constexpr (DH == 1 || DH == 2)
-            stream_pair_rounds<DH, NT>(reinterpret_cast<const unsigned char*>((uintptr_t)X.gbase), 2u * L.ns, d16, jfirst, hp, cnt, lane, wave);
-    } else if (F.use) {
-        // the boxcar of the adjacent-window rounds on the matrix cores (see mfma_pair_rounds); F.use implies fastwin
-        if constexpr (DH > 0 && DH <= (int)FMD_BX_MAX_DH) mfma_pair_rounds<DH, NT>(F, smem, d16, wofs - (int)hp + DH * jfirst, cnt, lane, wave);
-    } else if (fastwin && FMD_USE_F32 && FMD_PAIR && (DH != 4 || dh4_aligned)) {
+            stream_pair_rounds<DH>(reinterpret_cast<const unsigned char*>((uintptr_t)X.gbase), 2u * L.ns, d16, jfirst, hp, cnt, lane, wave);
+    } else if (fastwin && (DH != 4 || dh4_aligned)) {
         // Whole-dword windows, f32 discriminator (downsample 2 ... 10).  Lane l takes the ADJACENT windows i = base + 2l
         // and i + 1: the second window's predecessor is the lane's own first one, and only the first one's comes from
         // the neighbour (the second window of lane l - 1; lane 0's first window is the round's overlap and is not
@@ -619,8 +473,7 @@ __device__ __forceinline__ void tile_body(const FmdLaunch& L, const TileCtx& X, 
             const uint32_t prev2 = wave_shr1_old(wave_ror1(pk1), pk2);   // lane l <- second of l-1; lane 0 <- first of 63
             int d1, d2;
             if (FMD_ABLATE(0)) { d1 = (int)(pk1 ^ prev1); d2 = (int)(pk2 ^ prev2); }    // ablation: no discriminator
-            else if (FMD_USE_F32) { d1 = disc_f32(pk1, prev1); d2 = disc_f32(pk2, prev2); }   // (:362); whole-dword windows: downsample <= 10 (<= FMD_DISC_F32_MAX_D)
-            else { d1 = disc_fast(pk1, prev1); d2 = disc_fast(pk2, prev2); }
+            else { d1 = disc_f32(pk1, prev1); d2 = disc_f32(pk2, prev2); }   // (:362); whole-dword windows: downsample <= 14 (<= FMD_DISC_F32_MAX_D)
             // (Measured and rejected in round 2: storing the full rounds without predication -- lane 0 to a dummy slot --
             //  so that both discriminators run as one interleaved stream: +2 % at downsample 6 / 10, +7 % at 7.  The
             //  two separately masked regions the compiler builds here are the faster form.)
@@ -657,8 +510,8 @@ __device__ __forceinline__ void tile_body(const FmdLaunch& L, const TileCtx& X, 
         // wraps; an even rotation keeps the A, B weight order.
         // (A window length of 2 mod 4 dwords -- downsample 12, 20, 28 -- is only a 2-way conflict: cheaper to take than
         //  to rotate around; those run the plain loops.)
-        const bool rotate = (D & 1) == 0 && (p0 & 1u) == 0u && (ndw & FMD_ROT_MASK) == 0 && ndw >= 4;
-        const bool smallD = FMD_USE_F32 && D <= FMD_DISC_F32_MAX_D;
+        const bool rotate = (D & 1) == 0 && (p0 & 1u) == 0u && (ndw & 3) == 0 && ndw >= 4;
+        const bool smallD = D <= FMD_DISC_F32_MAX_D;
         uint32_t rot0 = 0;
         if (rotate) {
             const uint32_t low = (uint32_t)ndw & (0u - (uint32_t)ndw);                   // lanes 32 / g apart share a bank,
@@ -666,11 +519,11 @@ __device__ __forceinline__ void tile_body(const FmdLaunch& L, const TileCtx& X, 
             rot0 = 2u * ((((lane & 31u) * g) >> 5) % ((uint32_t)ndw >> 1));
         }
         // compile-time dword counts (see masked_rounds); anything else runs the general loop below
-#define FMD_MASKED(N) case N: masked_rounds<N, NT>(raw_w, d16, wofs, s00, D, cnt, lane, wave, wreA, wreB, wimA, wimB, mf, ml, cre, cim, smallD); break
+#define FMD_MASKED(N) case N: masked_rounds<N>(raw_w, d16, wofs, s00, D, cnt, lane, wave, wreA, wreB, wimA, wimB, mf, ml, cre, cim, smallD); break
         bool done = false;
         // (the catch-all kernel, DH == 0, only sees downsample >= 16 once every smaller factor has a kernel of its own:
         //  windows of 9 dwords and more, none of the compile-time counts below)
-        if (!rotate && FMD_MASKED_UNROLL && (DH != 0 || !FMD_ODD_KERNELS)) {
+        if (!rotate && DH != 0) {
             done = true;
             switch (ndw) {                                   // wave-uniform
                 FMD_MASKED(1); FMD_MASKED(2); FMD_MASKED(3); FMD_MASKED(4); FMD_MASKED(5); FMD_MASKED(6); FMD_MASKED(7); FMD_MASKED(8);
@@ -813,7 +666,7 @@ __device__ __forceinline__ void tile_body(const FmdLaunch& L, const TileCtx& X, 
     // (it continues the previous call's partial sum, :410-417): one lane redoes it below.
     const uint32_t nk = FMD_ABLATE(7) ? 0u : T.k1 - T.k0;
     int16_t* const outc = L.out + (uint64_t)c * L.out_stride;
-    for (uint32_t q = tid; q < nk; q += NT) {
+    for (uint32_t q = tid; q < nk; q += kThreads) {
         if (FMD_ABLATE(2)) { outc[T.k0 + q] = d16[q + 1]; continue; }           // ablation: no resampler
         const uint32_t x = T.er + q * L.fb;
         // sr (the reduced resample rate) is a power of two at the reference's rates (170 k -> 32 k: 16) and at the
@@ -948,21 +801,20 @@ __device__ __forceinline__ TileCtx fast_ctx(const FmdLaunch& L, const FastAddr& 
     return X;
 }
 
-template <int NT>
 __device__ __forceinline__ void issue_dma(uint64_t a0, uint32_t nchunks, unsigned char* smem, uint32_t tid)
 {
     // global_load_lds_dwordx4: 1 KiB per wave-instruction straight into the tile image, destination =
     // wave-uniform base (M0) + lane * 16; no VGPR round trip, no ds_write pass, one wait for all.
     const unsigned char* src = reinterpret_cast<const unsigned char*>((uintptr_t)a0) + 16u * tid;
     unsigned char* dst = smem + 1024u * (tid >> 6);
-    const uint32_t nfull = nchunks / NT, ntail = nchunks - nfull * NT;
-    for (uint32_t l = 0; l < nfull; ++l) lds_dma16(src + (16u * NT) * l, dst + (16u * NT) * l);
-    if (tid < ntail) lds_dma16(src + (16u * NT) * nfull, dst + (16u * NT) * nfull);
+    const uint32_t nfull = nchunks / kThreads, ntail = nchunks - nfull * kThreads;
+    for (uint32_t l = 0; l < nfull; ++l) lds_dma16(src + (16u * kThreads) * l, dst + (16u * kThreads) * l);
+    if (tid < ntail) lds_dma16(src + (16u * kThreads) * nfull, dst + (16u * kThreads) * nfull);
 }
 
 // ---- one block per tile, LDS-DMA staging ------------------------------------------------------------
-template <int DH, int NT, int FAST>
-__global__ void __launch_bounds__(NT) fmd_demod_tile_kernel(const FmdLaunch L)
+template <int DH, int FAST>
+__global__ void __launch_bounds__(kThreads) fmd_demod_tile_kernel(const FmdLaunch L)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const uint32_t tid = threadIdx.x;
@@ -977,11 +829,10 @@ __global__ void __launch_bounds__(NT) fmd_demod_tile_kernel(const FmdLaunch L)
         if (A.c >= L.fg.n_channels) return;
         if (FMD_ABLATE(4)) {
         } else if (A.whole) {
-            issue_dma<NT>(A.a0, A.nchunks, smem, tid);
+            issue_dma(A.a0, A.nchunks, smem, tid);
         }
         const TileCtx X = fast_ctx<FAST>(L, A);              // scalar work under the load latency
-        const BxFrag<DH> F = bx_prefetch<DH, NT>(L, X, tid);  // ... and the matrix-core boxcar's weight fragments
-        if (!A.whole && !FMD_ABLATE(4)) stage_slow<NT>(L, X, smem, tid);
+        if (!A.whole && !FMD_ABLATE(4)) stage_slow(L, X, smem, tid);
         if (FMD_ABLATE(3)) {                                 // ablation: staging skeleton only
             __syncthreads();
             if (tid == 0) L.out[(uint64_t)X.c * L.out_stride + X.T.k0] = (int16_t)reinterpret_cast<uint32_t*>(smem)[blockIdx.y & 63u];
@@ -990,7 +841,7 @@ __global__ void __launch_bounds__(NT) fmd_demod_tile_kernel(const FmdLaunch L)
         __builtin_amdgcn_s_waitcnt(0x0F70);
         __syncthreads();
         __builtin_amdgcn_s_setprio(0);
-        tile_body<DH, NT>(L, X, smem, F);
+        tile_body<DH>(L, X, smem);
         return;
     }
     uint32_t c = blockIdx.z * 65535u + blockIdx.y, tix = blockIdx.x;
@@ -1012,11 +863,10 @@ __global__ void __launch_bounds__(NT) fmd_demod_tile_kernel(const FmdLaunch L)
     if (!X.valid || !tile_fits(L, X, tid)) return;
     if (FMD_ABLATE(4)) {                                     // ablation: no loads at all (compute on LDS garbage)
     } else if (X.whole) {
-        issue_dma<NT>(X.a0, X.nchunks, smem, tid);
+        issue_dma(X.a0, X.nchunks, smem, tid);
     } else {
-        stage_slow<NT>(L, X, smem, tid);
+        stage_slow(L, X, smem, tid);
     }
-    const BxFrag<DH> F = bx_prefetch<DH, NT>(L, X, tid);      // in flight with the tile's bytes
     if (FMD_ABLATE(3)) {                                     // ablation: staging skeleton only
         __syncthreads();
         if (tid == 0) L.out[(uint64_t)c * L.out_stride + X.T.k0] = (int16_t)reinterpret_cast<uint32_t*>(smem)[blockIdx.x & 63u];
@@ -1029,7 +879,7 @@ __global__ void __launch_bounds__(NT) fmd_demod_tile_kernel(const FmdLaunch L)
     // (Measured and rejected: touching the lines of a tile 512..3584 dispatch slots ahead to pre-warm
     //  L2 / Infinity Cache made the launch 4..40 % SLOWER -- the stream is bandwidth-, not latency-bound.)
     __builtin_amdgcn_s_setprio(0);
-    tile_body<DH, NT>(L, X, smem, F);
+    tile_body<DH>(L, X, smem);
 }
 
 // ---- register-streaming form: no staging, no staging barrier (see stream_pair_rounds) -------------------------------
@@ -1040,162 +890,26 @@ __global__ void __launch_bounds__(256, 8) fmd_demod_stream_kernel(const FmdLaunc
     const FastAddr A = fast_addr<FAST>(L);
     if (A.c >= L.fg.n_channels) return;
     const TileCtx X = fast_ctx<FAST>(L, A);
-    BxFrag<DH> F;
-    F.use = false; F.o1 = false; F.e = 0;
-    tile_body<DH, 256, true>(L, X, smem, F);
+    tile_body<DH, true>(L, X, smem);
+}
+
+// Host side of the instantiations: launch_lds<DH> / launch_stream<DH> are defined here and explicitly instantiated in
+// fmd_tile_lds_*.hip / fmd_tile_stream.hip (one translation unit per group of downsample factors: `make -j` builds them
+// side by side); fmd_tile_launch.hip only sees the declarations.
+template <int DH>
+void launch_lds(const FmdLaunch& L, dim3 g, size_t lds, hipStream_t stream)
+{
+    if (L.fast == 1u) hipLaunchKernelGGL((fmd_demod_tile_kernel<DH, 1>), g, dim3(kThreads), lds, stream, L);
+    else if (L.fast == 2u) hipLaunchKernelGGL((fmd_demod_tile_kernel<DH, 2>), g, dim3(kThreads), lds, stream, L);
+    else hipLaunchKernelGGL((fmd_demod_tile_kernel<DH, 0>), g, dim3(kThreads), lds, stream, L);
 }
 
 template <int DH>
-void launch_one(const FmdLaunch& L, dim3 g, size_t lds, hipStream_t stream)
+void launch_stream(const FmdLaunch& L, dim3 g, size_t lds, hipStream_t stream)
 {
-    switch (L.block_threads) {
-#ifdef FMD_EXPERIMENT                                        // 64- / 128-thread blocks (FMD_NT): measured equal or slower, kept for A/B only
-        case 128:
-            if (L.fast == 1u) hipLaunchKernelGGL((fmd_demod_tile_kernel<DH, 128, 1>), g, dim3(128), lds, stream, L);
-            else if (L.fast == 2u) hipLaunchKernelGGL((fmd_demod_tile_kernel<DH, 128, 2>), g, dim3(128), lds, stream, L);
-            else hipLaunchKernelGGL((fmd_demod_tile_kernel<DH, 128, 0>), g, dim3(128), lds, stream, L);
-            break;
-        case 64: hipLaunchKernelGGL((fmd_demod_tile_kernel<DH, 64, 0>), g, dim3(64), lds, stream, L); break;
-#endif
-        default:
-            if constexpr (DH == 1 || DH == 2) {
-                if (L.stream && L.fast == 2u) { hipLaunchKernelGGL((fmd_demod_stream_kernel<DH, 2>), g, dim3(256), lds, stream, L); break; }
-                if (L.stream && L.fast == 1u) { hipLaunchKernelGGL((fmd_demod_stream_kernel<DH, 1>), g, dim3(256), lds, stream, L); break; }
-            }
-            if (L.fast == 1u) hipLaunchKernelGGL((fmd_demod_tile_kernel<DH, 256, 1>), g, dim3(256), lds, stream, L);
-            else if (L.fast == 2u) hipLaunchKernelGGL((fmd_demod_tile_kernel<DH, 256, 2>), g, dim3(256), lds, stream, L);
-            else hipLaunchKernelGGL((fmd_demod_tile_kernel<DH, 256, 0>), g, dim3(256), lds, stream, L);
-            break;
-    }
+    if (L.fast == 2u) hipLaunchKernelGGL((fmd_demod_stream_kernel<DH, 2>), g, dim3(kThreads), lds, stream, L);
+    else hipLaunchKernelGGL((fmd_demod_stream_kernel<DH, 1>), g, dim3(kThreads), lds, stream, L);
 }
 
-}  // namespace
+}  // namespace fmd_tk
 
-size_t fmd_tile_lds_bytes(const FmdLaunch& L)
-{
-    const size_t glen = (size_t)L.fa + 1u;
-    return (L.stream ? 0u : (size_t)L.raw_cap) + ((2u * ((size_t)L.lp_cap + glen + 1u) + 15u) & ~(size_t)15u) + 16u;
-}
-
-bool fmd_tile_kernel_supports(const FmdRates& r, uint32_t raw_cap)
-{
-    // disc_fast / disc_nosel need |x| + |y| < 2^30: |lp| <= 128*D, so |x| + |y| < 4 * (128*D)^2 <= 2^30 up to D = 128
-    if (r.D > FMD_MAX_DOWNSAMPLE) return false;
-    if ((uint64_t)r.sr * (r.kt + 2) >= (1u << 24)) return false;          // fmd_udiv_small operands
-    if ((uint64_t)((r.fr + r.sr - 1) / r.sr + 2) * 32768ull >= (1u << 24)) return false;   // |group sum| < 2^24
-    if ((uint32_t)r.R >= (1u << 24)) return false;
-    if (raw_cap > 60u * 1024u) return false;
-    return true;
-}
-
-// Fills L.fg (and L.rows) when the launch qualifies for a fast prologue: one phase class, 256-thread blocks, every tile
-// of the launch within the LDS sizing (checked here, once, instead of by every block).  Returns the mode: 1 = closed
-// form (tiles repeat exactly: kt * fr % sr == 0), 2 = per-tile table (any rates, at most FMD_FAST_ROWS tiles), 0 = none.
-static uint32_t fmd_fast_geometry(FmdLaunch& L, uint32_t per)
-{
-    if (!L.fast || L.chan_class || (L.block_threads != 256u && L.block_threads != 128u)) return 0u;   // L.fast on entry: allowed (FMD_FAST != 0)
-    const FmdRates& r = L.r;
-    const FmdClassPlan& P = L.cls[0];
-    if (P.nt != L.tiles || P.nt == 0u) return 0u;
-    const FmdTiling& tl = L.tl;
-    const uint64_t ns2 = 2ull * L.ns;
-    if (ns2 >= (1ull << 31)) return 0u;
-    FmdFastGeo& g = L.fg;
-    g.iq = (uint64_t)(uintptr_t)L.iq; g.iq_end = g.iq + L.total_bytes; g.chan_stride = L.chan_stride;
-    g.n_channels = L.n_channels; g.per = per; g.nt = P.nt; g.ns2 = (uint32_t)ns2; g.Qt = tl.Qt;
-    // the table whenever it fits (measured ~1 % faster than the closed form even where both apply: two scalar loads and
-    // no multiply-adds); FMD_FAST=1 keeps the closed form for A/B
-    if (P.nt <= FMD_FAST_ROWS && (tl.Rt != 0u || L.fast != 1u) ) {
-        for (uint32_t t = 0; t < P.nt; ++t) {
-            const FmdTile T = fmd_tile_fast(r, P, tl, L.ns, t);
-            if ((uint64_t)(T.jB - T.jA + 2) > L.lp_cap || (!L.stream && 2ull * (uint64_t)(T.nHi - T.nLo) + 30u > L.raw_cap)) return 0u;
-            L.rows[t] = FmdTileRow{2u * (uint32_t)T.nLo, 2u * (uint32_t)T.nHi, T.jA, T.jB, T.eq, T.er};
-        }
-        return 2u;
-    }
-    if (tl.Rt != 0u) return 0u;
-    const int64_t jA_off = (int64_t)P.eq0 - tl.fq + (P.er0 >= tl.frr ? 1 : 0);
-    const int64_t jB_off = (int64_t)P.eq0 + tl.Bq + (P.er0 + tl.Br >= r.sr ? 1 : 0);
-    const int64_t lo_off2 = 2 * ((int64_t)r.D * (jA_off - 1) - P.p0), hi_off2 = 2 * ((int64_t)r.D * (jB_off + 1) - P.p0);
-    const uint64_t step2 = 2ull * r.D * tl.Qt;
-    if (jA_off > 0 || step2 * P.nt + (uint64_t)(hi_off2 > 0 ? hi_off2 : 0) >= (1ull << 31)) return 0u;
-    // every tile: the same expressions as fmd_tile_fast (tests/test_plan_and_divides.py proves that one), plus the LDS sizing
-    for (uint32_t t = 0; t < P.nt; ++t) {
-        const FmdTile T = fmd_tile_fast(r, P, tl, L.ns, t);
-        const int64_t ja = (int64_t)t * tl.Qt + jA_off, lo = (int64_t)t * step2 + lo_off2;
-        const int64_t jA = ja > 0 ? ja : 0, jB = T.last ? (int64_t)P.M - 1 : (int64_t)t * tl.Qt + jB_off;
-        const int64_t nLo2 = lo > 0 ? lo : 0, nHi2 = T.last ? (int64_t)ns2 : (int64_t)t * step2 + hi_off2;
-        if (jA != T.jA || jB != T.jB || nLo2 != 2ll * T.nLo || nHi2 != 2ll * T.nHi) return 0u;
-        if ((uint64_t)(jB - jA + 2) > L.lp_cap || (!L.stream && (uint64_t)(nHi2 - nLo2) + 30u > L.raw_cap)) return 0u;
-    }
-    g.step2 = (uint32_t)step2; g.lo_off2 = (int32_t)lo_off2; g.hi_off2 = (int32_t)hi_off2;
-    g.jA_off = (int32_t)jA_off; g.jB_off = (int32_t)jB_off;
-    return 1u;
-}
-
-hipError_t fmd_launch_tile(const FmdLaunch& L, hipStream_t stream)
-{
-    if (L.n_channels == 0 || L.tiles == 0) return hipErrorInvalidValue;
-    const int dh = (L.r.D % 2 == 0) ? (int)(L.r.D / 2) : -(int)L.r.D;
-    uint32_t gy = L.n_channels < 65535u ? L.n_channels : 65535u;
-    uint32_t gz = (L.n_channels + 65534u) / 65535u;
-    dim3 g(L.tiles, gy, gz);
-    FmdLaunch K = L;
-    // XCD-aware mapping without index arithmetic: grid (8, tiles, ceil(C / 8)), x fastest in dispatch order, so
-    // blockIdx.x IS the XCD and channel = x * gridDim.z + z (blocks of channels >= C exit at once).
-    const uint32_t per = (L.n_channels + 7u) / 8u;
-    if (L.xcd_swizzle && L.n_channels >= 8u && L.tiles <= 65535u && per <= 65535u) {
-        g = dim3(8u, L.tiles, per);
-        K.xcd_swizzle = 3u;
-        K.fast = fmd_fast_geometry(K, per);
-    } else K.fast = 0u;
-    // the streaming kernel has the table / closed-form prologue only, and its tiles do not fit the LDS kernel: the caller
-    // plans the call again with the LDS tiling
-    if (K.stream && !K.fast) return hipErrorNotSupported;
-    const size_t lds = fmd_tile_lds_bytes(K);                // (after K.stream is final: the streaming form stages nothing)
-    switch (dh) {
-        case 1: launch_one<1>(K, g, lds, stream); break;
-        case 2: launch_one<2>(K, g, lds, stream); break;
-        case 3: launch_one<3>(K, g, lds, stream); break;
-        case 4: launch_one<4>(K, g, lds, stream); break;
-        case 5: launch_one<5>(K, g, lds, stream); break;
-#if FMD_ODD_KERNELS
-        // kernels of their own for the other downsample factors the f32 discriminator covers: with the factor a
-        // compile-time constant each one holds a single window loop and gets its own register allocation (one kernel
-        // with every window length in it measured 2-4 % slower at downsample 5 and 7).  DH < 0: odd downsample -DH.
-        case 6: launch_one<6>(K, g, lds, stream); break;     // downsample 12, 14: whole-dword windows like 2 ... 10
-        case 7: launch_one<7>(K, g, lds, stream); break;
-        // downsample 16 ... 32, 64, 128 and the odd factors to 31: the wrap-around walk / the general window loop with
-        // compile-time trip counts (16: -7 %, 32: -7.5 %, 64: -6.3 % against the catch-all kernel)
-        case 8: launch_one<8>(K, g, lds, stream); break;
-        case 9: launch_one<9>(K, g, lds, stream); break;
-        case 10: launch_one<10>(K, g, lds, stream); break;
-        case 11: launch_one<11>(K, g, lds, stream); break;
-        case 12: launch_one<12>(K, g, lds, stream); break;
-        case 13: launch_one<13>(K, g, lds, stream); break;
-        case 14: launch_one<14>(K, g, lds, stream); break;
-        case 15: launch_one<15>(K, g, lds, stream); break;
-        case 16: launch_one<16>(K, g, lds, stream); break;
-        case 32: launch_one<32>(K, g, lds, stream); break;
-        case 64: launch_one<64>(K, g, lds, stream); break;
-        case -17: launch_one<-17>(K, g, lds, stream); break;
-        case -19: launch_one<-19>(K, g, lds, stream); break;
-        case -21: launch_one<-21>(K, g, lds, stream); break;
-        case -23: launch_one<-23>(K, g, lds, stream); break;
-        case -25: launch_one<-25>(K, g, lds, stream); break;
-        case -27: launch_one<-27>(K, g, lds, stream); break;
-        case -29: launch_one<-29>(K, g, lds, stream); break;
-        case -31: launch_one<-31>(K, g, lds, stream); break;
-        case -1: launch_one<-1>(K, g, lds, stream); break;
-        case -3: launch_one<-3>(K, g, lds, stream); break;
-        case -5: launch_one<-5>(K, g, lds, stream); break;
-        case -7: launch_one<-7>(K, g, lds, stream); break;
-        case -9: launch_one<-9>(K, g, lds, stream); break;
-        case -11: launch_one<-11>(K, g, lds, stream); break;
-        case -13: launch_one<-13>(K, g, lds, stream); break;
-        case -15: launch_one<-15>(K, g, lds, stream); break;
-#endif
-        default: launch_one<0>(K, g, lds, stream); break;
-    }
-    return hipGetLastError();
-}

@@ -123,6 +123,12 @@ class DemodBank:
         check(lib().fmd_demod_tiling(self._h, C.byref(a), C.byref(b), C.byref(c)))
         return {"audio_per_tile": a.value, "lds_bytes": b.value, "block_threads": c.value}
 
+    def last_kernel(self):
+        """Name of the kernel the most recent launch ran, as rocprofv3 --kernel-trace prints it ('' before the first launch)."""
+        buf = C.create_string_buffer(128)
+        check(lib().fmd_demod_last_kernel(self._h, buf, len(buf)))
+        return buf.value.decode()
+
     def set_block_len(self, block_bytes):
         """Treat every call as nbytes / block_bytes consecutive reference calls (0 = off): fmd_demod_set_block_len."""
         check(lib().fmd_demod_set_block_len(self._h, block_bytes))

@@ -110,6 +110,7 @@ extern "C" {
     pub fn fmd_device_count(count: *mut c_int) -> c_int;
     pub fn fmd_version() -> c_int;
     pub fn fmd_demod_tiling(d: *const fmd_demod, audio_per_tile: *mut u32, lds_bytes: *mut u32, block_threads: *mut u32) -> c_int;
+    pub fn fmd_demod_last_kernel(d: *const fmd_demod, name: *mut c_char, cap: usize) -> c_int;
     pub fn fmd_demod_set_tiling(d: *mut fmd_demod, audio_per_tile: u32) -> c_int;
     pub fn fmd_synth_fill_device(device_id: c_int, d_iq: *mut c_void, n_channels: u32, nbytes: usize, sample_offset: u64, p: *const SynthParams, stream: *mut c_void) -> c_int;
     pub fn fmd_fir_new(taps: *const i16, n_taps: u32, decim: u32, dev: *const DeviceConfig, out: *mut *mut fmd_fir) -> c_int;

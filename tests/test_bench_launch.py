@@ -103,6 +103,24 @@ def test_two_ranks_on_one_box():
         assert 0.05 < r["roofline"]["frac"] < 1.0 and r["roofline"]["bound"] == "hbm"
 
 
+@pytest.mark.gpu
+def test_two_rank_line_is_self_verifying():
+    """the N > 1 line must carry what makes it creditable -- a parity bit from EVERY rank (gathered), the CPU
+    baseline (rank 0), every GPU's clock / power and the kernel name the library reports -- not only the N = 1 line.  Two
+    gloo ranks share the test box's one GPU."""
+    r = run_bench(["--gpus", "2", "--backend", "gloo", "--steps", "5", "--warmup", "2", "--settle", "10", "--channels", "1024",
+                   "--min-timed-s", "0.05", "--cpu-seconds", "1", "--power-only"])
+    assert r["n_gpus"] == 2
+    p = r["parity"]
+    assert p["ok"] is True and p["ranks_checked"] == 2 and p["ranks_ok"] == [True, True] and p["channels_checked"] >= 2 * 60
+    cb = r["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["value"] > 0 and cb["cores"] >= 1
+    pg = r["extra"]["power_clock"]["per_gpu"]
+    assert [g["rank"] for g in pg] == [0, 1] and all(g["ms_per_call"] is None or g["ms_per_call"] > 0 for g in pg)
+    assert set(r["extra"]) == {"power_clock"}                   # the other side lines belong to the one-GPU line
+    assert r["roofline"]["kernel"] == r["roofline"]["kernel_expected"] and r["roofline"]["kernel_is_expected"] is True
+
+
 def torchrun_cmd(n, port, extra):
     """The driver's own launch line for N > 1 (one rank per GPU, rendezvous on 127.0.0.1)."""
     return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
@@ -161,6 +179,11 @@ def test_force_dist_runs_the_rccl_branch_with_one_rank():
     assert abs(forced["per_gpu_msamples_per_s"][0] - forced["value"]) < 0.05 * forced["value"]
     assert 0.7 * plain["value"] < forced["value"] < 1.4 * plain["value"], (plain["value"], forced["value"])
     assert forced["timing"]["regions"] >= 2
+    # ... and with the parity bit, the CPU baseline and the per-GPU sensors gathered over RCCL (all_gather on device tensors)
+    full = run_bench(["--steps", "20", "--warmup", "2", "--settle", "50", "--min-timed-s", "0.2", "--force-dist", "--cpu-seconds", "1", "--power-only"])
+    assert full["parity"]["ok"] is True and full["parity"]["ranks_checked"] == 1 and full["parity"]["channels_checked"] >= 60
+    assert full["cpu_baseline"]["value"] > 0 and len(full["extra"]["power_clock"]["per_gpu"]) == 1
+    assert full["roofline"]["kernel_is_expected"] is True and full["roofline"]["kernel"].startswith("fmd_tk::fmd_demod_tile_kernel<5,")
 
 
 @pytest.mark.gpu
@@ -172,10 +195,15 @@ def test_default_line_carries_parity_and_the_side_lines():
     assert r["parity"]["ok"] is True and r["parity"]["channels_checked"] >= 32
     assert r["roofline"]["traffic_measured_in_this_run"] is False
     ex = r["extra"]
-    for k in ("cfg_ref", "check_per_step", "config2_1channel", "config4_fir", "config4_fir_demod_fused", "sink_pcie"):
+    assert r["roofline"]["kernel_is_expected"] is True and r["parity"]["ranks_checked"] == 1
+    for k in ("cfg_ref", "check_per_step", "config2_1channel", "config4_fir", "config4_fir_demod_fused", "sink_pcie", "domain"):
         assert k in ex and "error" not in ex[k], (k, ex.get(k))
     assert 0.3 < ex["cfg_ref"]["frac"] < 1.0 and ex["check_per_step"]["ms_per_step"] >= r["ms_per_step"] * 0.9
     assert ex["sink_pcie"]["all_status_ok"] and ex["sink_pcie"]["delivered"] >= 40
+    rows = {row["downsample"]: row for row in ex["domain"]["rows"]}
+    assert set(rows) == {1, 2, 4, 5, 7, 8, 12, 16, 64} and all("error" not in row and 0.05 < row["frac"] < 1.0 for row in rows.values())
+    assert rows[4]["kernel"].startswith("fmd_tk::fmd_demod_stream_kernel<2,") and rows[7]["kernel"].startswith("fmd_tk::fmd_demod_tile_kernel<-7,")
+    assert ex["cfg_ref"]["kernel"].startswith("fmd_tk::fmd_demod_tile_kernel<3,")
     pc = ex["power_clock"]                                      # clock and power under load: sensors may be absent on a box,
     assert "error" in pc or (1000 <= pc["sclk_mhz"]["median"] <= 2500 and pc["power_w"]["median"] > pc["idle"]["power_w"]["median"]
                              and isinstance(pc["at_power_cap"], bool)), pc     # but when present they must read sensibly

@@ -393,6 +393,30 @@ def test_streaming_kernel_long_calls(fmd, oracle, D, fast, slow):
     check_stream(fmd, oracle, D, fast, slow, blocks, n_channels=nch)
 
 
+def test_last_kernel_and_tiling_report_what_ran(fmd):
+    """fmd_demod_last_kernel / fmd_demod_tiling describe the launch that actually happened (the tiling used to
+    describe the streaming kernel whenever it COULD run, also when the call had fallen back to the LDS-DMA kernel)."""
+    rng = np.random.default_rng(11)
+    bank = fmd.DemodBank(mkcfg(fmd, 4, 256000, 48000), 9)
+    assert bank.last_kernel() == ""
+    planned = bank.tiling()                                    # before any launch: what whole read_sync buffers will run
+    bank.demodulate_batch(rng.integers(0, 256, (9, 3 << 20), dtype=np.uint8))     # > 32 tiles, tiles do not repeat: LDS-DMA kernel, general prologue
+    assert bank.last_kernel() == "fmd_tk::fmd_demod_tile_kernel<2, 0>"
+    lds_tiling = bank.tiling()
+    assert lds_tiling["lds_bytes"] > 8192 and lds_tiling["audio_per_tile"] < planned["audio_per_tile"]
+    bank.demodulate_batch(rng.integers(0, 256, (9, fmd.DEFAULT_BUF_LENGTH), dtype=np.uint8))
+    assert bank.last_kernel() == "fmd_tk::fmd_demod_stream_kernel<2, 2>" and bank.tiling() == planned
+    bank.close()
+    one = fmd.DemodBank(mkcfg(fmd, *CFG_24), 1)                 # < 8 channels: no XCD-aware grid, general prologue
+    one.demodulate_batch(rng.integers(0, 256, (1, fmd.DEFAULT_BUF_LENGTH), dtype=np.uint8))
+    assert one.last_kernel() == "fmd_tk::fmd_demod_tile_kernel<5, 0>"
+    one.close()
+    wide = fmd.DemodBank(mkcfg(fmd, 200, 5000, 5000), 2)
+    wide.demodulate_batch(rng.integers(0, 256, (2, fmd.DEFAULT_BUF_LENGTH), dtype=np.uint8))
+    assert wide.last_kernel() == "fmd_demod_generic_kernel<true>"
+    wide.close()
+
+
 def test_large_single_channel_call(fmd, oracle):
     """Config 2 throughput shape: one channel, 16 MiB in one call (time-tiled inside the channel)."""
     N = 16 << 20

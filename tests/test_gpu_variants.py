@@ -1,7 +1,7 @@
-"""GPU parity of the non-default kernel variants (same results by construction): 64/128-thread tile blocks (FMD_NT),
-the plain and index-arithmetic block mappings (FMD_XCD), the general and the closed-form prologue (FMD_FAST=0 / 1; the
-default prefers the per-tile table), the generic fallback kernel (FMD_FORCE_GENERIC), the boxcar on the matrix cores (FMD_BX_MFMA, measured slower than the
-v_dot4 form and therefore not in the shipped library).  These knobs exist in the
+"""GPU parity of the non-default kernel variants (same results by construction): the plain and index-arithmetic block
+mappings (FMD_XCD), the general and the closed-form prologue (FMD_FAST=0 / 1; the default prefers the per-tile table), the
+LDS-DMA kernel where the register-streaming one would run (FMD_STREAM=0), the generic fallback kernel
+(FMD_FORCE_GENERIC).  These knobs exist in the
 -DFMD_EXPERIMENT build only -- the shipped library reads no environment variable -- so every case re-runs itself in a
 child process on libfmd_hip_exp.so (conftest.run_in_exp_child).  What the shipped library selects by itself (general
 prologue for several phase classes, generic kernel beyond 16 of them) is covered in tests/test_gpu_parity.py."""
@@ -26,14 +26,16 @@ def blocks_for(fmd, nch, ncalls, seed, n=None):
     return out
 
 
-@pytest.mark.parametrize("env", [{"FMD_NT": "128"}, {"FMD_NT": "64"}, {"FMD_XCD": "0"}, {"FMD_XCD": "1"}, {"FMD_FAST": "0"}, {"FMD_FAST": "1"},
-                                 {"FMD_FORCE_GENERIC": "1"}, {"FMD_BX_MFMA": "1"}])
+@pytest.mark.parametrize("env", [{"FMD_XCD": "0"}, {"FMD_XCD": "1"}, {"FMD_FAST": "0"}, {"FMD_FAST": "1"}, {"FMD_STREAM": "0"},
+                                 {"FMD_FORCE_GENERIC": "1"}])
 def test_kernel_variants_bit_exact(fmd, oracle, request, env):
     if run_in_exp_child(request, env):
         return
     cfgs = [CFG_24, CFG_REF, (4, 300000, 50000), (16, 62500, 31250)]
-    if "FMD_BX_MFMA" in env:                                  # the boxcar on the matrix cores: every even downsample 2 ... 14
-        cfgs = [(2, 500000, 32000), (4, 300000, 50000), CFG_REF, (8, 250000, 44100), CFG_24, (12, 192000, 32000), (14, 224000, 32000)]
+    if "FMD_STREAM" in env:                                   # downsample 2 and 4 with >= 8 channels: where the streaming kernel is the default
+        for cfg in [(2, 500000, 32000), (4, 300000, 50000)]:
+            check_stream(fmd, oracle, *cfg, blocks_for(fmd, 9, 3, seed=cfg[0]), n_channels=9)
+        return
     for cfg in cfgs:
         check_stream(fmd, oracle, *cfg, blocks_for(fmd, 7, 3, seed=cfg[0]), n_channels=7)
         check_stream(fmd, oracle, *cfg, blocks_for(fmd, 3, 3, seed=cfg[0] + 1, n=8 * 517), n_channels=3)   # ragged small calls
@@ -46,6 +48,6 @@ def test_shipped_library_ignores_the_knobs(fmd, monkeypatch):
         pytest.skip("a tuning build is loaded")
     from test_gpu_parity import mkcfg
     ref = fmd.DemodBank(mkcfg(fmd, *CFG_24), 16).tiling()
-    for k, v in {"FMD_NT": "64", "FMD_KT": "7", "FMD_FORCE_GENERIC": "1", "FMD_F64_GUARD_LOG2": "-1"}.items():
+    for k, v in {"FMD_XCD": "0", "FMD_KT": "7", "FMD_FORCE_GENERIC": "1", "FMD_F64_GUARD_LOG2": "-1"}.items():
         monkeypatch.setenv(k, v)
     assert fmd.DemodBank(mkcfg(fmd, *CFG_24), 16).tiling() == ref

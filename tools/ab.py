@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Interleaved A/B of library variants inside ONE process on ONE box (same clocks, same memory): every variant is a
-set of environment variables read when a handle is created (FMD_FAST, FMD_KT, FMD_NT, FMD_XCD, ...) or a different
+set of environment variables read when a handle is created (FMD_FAST, FMD_KT, FMD_XCD, ...) or a different
 library build (LIB=path is handled by running this tool once per build).  Usage:
     tools/ab.py [--cfg ref|24|D,fast,slow]... [--rounds 3] [--steps 100] name:VAR=val,VAR=val name2: ...
 Prints one line per (config, variant) with the per-round times and their median."""
