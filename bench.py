@@ -207,7 +207,7 @@ def extra_config4(fmd, torch, dev, stream, fused):
     alg = nch * n + nch * out_bytes(int(nout))
     res = {"workload": "BASELINE configs[3]: %d-tap FIR, decimate %d, %d channels x %d B/call (20 Msps x 52.4 ms)%s"
                        % (T, M, nch, n, ", fused with the discriminator and the %d -> %d Hz resampler" % (fast, slow) if fused else ""),
-           "kernel": "fmd_firdemod_kernel" if fused else "fmd_fir_mfma_kernel", "ms_per_call": round(ms, 4),
+           "kernel": bank.kernel_name() if fused else "fmd_fir_mfma_kernel", "ms_per_call": round(ms, 4),
            "ms_min_max": [round(lo, 4), round(hi, 4)],
            "iq_msamples_per_s": round(nch * (n // 2) / ms / 1e3, 1), "outputs_per_channel": int(nout),
            "algorithmic_bytes_per_launch": alg, "GBps": round(alg / ms / 1e6, 1), "frac": round(alg / ms / 1e6 / HBM_PEAK_GBS, 4)}

@@ -244,6 +244,8 @@ int fmd_firdemod_check(fmd_firdemod *f);
 int fmd_firdemod_get_state(fmd_firdemod *f, uint32_t channel, fmd_demod_state *state);
 int fmd_firdemod_f64_stats(const fmd_firdemod *f, uint64_t *guarded, uint64_t *patched);
 int fmd_firdemod_tiling(const fmd_firdemod *f, uint32_t *audio_per_tile, uint32_t *lds_bytes);
+/* Name of the kernel this handle launches, as `rocprofv3 --kernel-trace` prints it (see fmd_demod_last_kernel). */
+int fmd_firdemod_kernel_name(const fmd_firdemod *f, char *name, size_t cap);
 
 /* ---- pipelined, multi-GPU sink for read_sync buffers ------------------------------------------------------- */
 /* NEW SURFACE (the reference has no asynchronous reader).  It mirrors the hand-off the example

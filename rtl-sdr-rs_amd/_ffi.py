@@ -103,6 +103,7 @@ PROTOTYPES = {
     "fmd_firdemod_get_state": (C.c_int, [_vp, C.c_uint32, C.POINTER(DemodState)]),
     "fmd_firdemod_f64_stats": (C.c_int, [_vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "fmd_firdemod_tiling": (C.c_int, [_vp, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
+    "fmd_firdemod_kernel_name": (C.c_int, [_vp, C.c_char_p, C.c_size_t]),
     "fmd_sink_new": (C.c_int, [C.POINTER(DemodConfig), C.c_uint32, C.POINTER(C.c_int32), C.c_uint32, _sz, C.c_uint32, _vp, _vp, C.POINTER(_vp)]),
     "fmd_sink_free": (None, [_vp]),
     "fmd_sink_acquire": (C.c_int, [_vp, C.POINTER(_vp)]),
@@ -150,7 +151,12 @@ def lib():
             pass
         l = C.CDLL(SO_PATH)
         for name, (res, args) in PROTOTYPES.items():
-            fn = getattr(l, name)
+            try:
+                fn = getattr(l, name)
+            except AttributeError:
+                if os.environ.get("FMD_LIB"):             # an older build loaded for an A/B (tools/ab.py): newer entry points absent
+                    continue
+                raise
             fn.restype, fn.argtypes = res, args
         _lib = l
     return _lib

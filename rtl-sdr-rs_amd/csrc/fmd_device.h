@@ -46,18 +46,26 @@ __device__ __forceinline__ void lds_window_sum(const uint32_t* __restrict__ raw_
 // atan2 sample of every call (:359).  Kept out of line: it runs on one lane per channel-call.
 // Exact directions first (integer decisions; libm and ocml both return the exact f64 there, so the reference's
 // values are 0, +-4096, +-8192, +-12288, 16384 -- tests/test_oracle_kat.py pins that table against the host libm).
-// Otherwise `*guarded` reports whether the value lies within `guard` of an integer (see FmdF64Exc, fmd_kernels.h).
-static __device__ __noinline__ int polar_f64(int cr, int ci, double guard, bool* guarded)
+// Otherwise `guarded` reports whether the value lies within `guard` of an integer (see FmdF64Exc, fmd_kernels.h).
+// The out-of-line part returns value and flag in ONE register (|value| <= 16384; bit 30 = guarded): a pointer
+// out-parameter gave every kernel that calls it a 16-byte scratch frame per lane (private-segment setup on every wave
+// of every launch for a path one lane per channel-call takes).
+static __device__ __noinline__ int polar_f64_packed(int cr, int ci, double guard)
 {
-    *guarded = false;
-    if (ci == 0) return cr >= 0 ? 0 : 16384;                 // atan2(+-0, x): 0 or pi (0, 0 -> 0)
-    if (cr == 0) return ci > 0 ? 8192 : -8192;               // +-pi/2
-    if (cr == ci) return cr > 0 ? 4096 : -12288;             // pi/4, -3pi/4
-    if (cr == -ci) return cr > 0 ? -4096 : 12288;            // -pi/4, 3pi/4
+    if (ci == 0) return (cr >= 0 ? 0 : 16384) & 0x3FFFFFFF;                 // atan2(+-0, x): 0 or pi (0, 0 -> 0)
+    if (cr == 0) return (ci > 0 ? 8192 : -8192) & 0x3FFFFFFF;               // +-pi/2
+    if (cr == ci) return (cr > 0 ? 4096 : -12288) & 0x3FFFFFFF;             // pi/4, -3pi/4
+    if (cr == -ci) return (cr > 0 ? -4096 : 12288) & 0x3FFFFFFF;            // -pi/4, 3pi/4
     const double angle = atan2((double)ci, (double)cr);
     const double v = angle / kPi * 16384.0;
-    *guarded = fabs(v - rint(v)) < guard;
-    return (int)v;
+    return ((int)v & 0x3FFFFFFF) | (fabs(v - rint(v)) < guard ? 0x40000000 : 0);
+}
+
+__device__ __forceinline__ int polar_f64(int cr, int ci, double guard, bool& guarded)
+{
+    const int r = polar_f64_packed(cr, ci, guard);
+    guarded = (r & 0x40000000) != 0;
+    return (int)((uint32_t)r << 2) >> 2;                     // sign-extend the 30-bit value
 }
 
 // Append the record of one guarded sample (one lane, after the tile's d16[] is complete: d16[j - jfirst] holds
@@ -175,7 +183,9 @@ __device__ __forceinline__ int disc_nosel(uint32_t a, uint32_t b)
 // tests: test_near_silence, the silence cases of tests/test_gpu_fuzz.py, test_axis_aligned_full_scale.
 __device__ __forceinline__ int fmd_cvt_i32_nan0(float v)
 {
-#if defined(__HIP_DEVICE_COMPILE__)
+#if defined(FMD_CVT_BUILTIN)
+    return (int)v;
+#elif defined(__HIP_DEVICE_COMPILE__)
     int r;
     asm("v_cvt_i32_f32 %0, %1" : "=v"(r) : "v"(v));
     return r;

@@ -52,8 +52,10 @@ constexpr int kGroupsPerWave = 4;                         // a wave accumulates 
 constexpr uint32_t kMaxOutputs = 64u * 4u * kGroupsPerWave;   // FIR outputs one tile can form
 typedef int fd_i4 __attribute__((ext_vector_type(4)));
 
-struct FdRow { int32_t jA, jB; uint32_t eq, er; };            // geometry of one tile (fmd_tile_fast), tabulated by the host
-constexpr uint32_t kFdRows = 192;                               // 3 KB of the 4 KB of kernel arguments
+// geometry of one tile (fmd_tile_fast), tabulated by the host; x0 = jA * sr + i0r - k0 * fr in [0, fr): discriminator sample m
+// of the tile lies in its audio group (x0 + (m - jA) * sr) / fr (fmd_audio_end solved for k)
+struct FdRow { int32_t jA, jB; uint32_t eq, er, x0; };
+constexpr uint32_t kFdRows = 160;                               // 3.2 KB of the 4 KB of kernel arguments
 
 struct FirDemodLaunch {
     // ---- FIR (same meaning as FirLaunch in fmd_fir.hip) ----
@@ -89,6 +91,8 @@ struct FirDemodLaunch {
     uint32_t sr_shift;         // log2(sr) when the reduced resample rate is a power of two, else 32
     uint32_t reuse;            // host only: decim / 8 selects the fragment-reuse instantiation (decim == 8, one pass; 16 in the experiment build), 0 the plain one
     uint32_t f32_disc;         // 1: |lp| <= 2048 (the boxcar's range at downsample 16): the f32 discriminator is exact (fmd_device.h)
+    uint32_t reg_ng;           // host only: > 0 selects fmd_firdemod_reg_kernel<NKU, reg_ng> (discriminator out of the matrix-core result registers)
+    FmdMagic magic_fr;         // fmd_udiv_magic(x, magic_fr) == x / fr for x < 2^24
     FdRow rows[kFdRows];
 };
 
@@ -352,7 +356,7 @@ __global__ void __launch_bounds__(kThreads, 8) fmd_firdemod_kernel(const FirDemo
                     const uint32_t a = yp[0], b = yp[-1];
                     fmd_mul_conj(lp_re(a), lp_im(a), lp_re(b), lp_im(b), cr0, ci0);
                     bool g;
-                    int d = polar_f64(cr0, ci0, L.f64_guard, &g);
+                    int d = polar_f64(cr0, ci0, L.f64_guard, g);
 #ifdef FMD_EXPERIMENT
                     if (g) d += L.f64_skew;
 #endif
@@ -389,10 +393,228 @@ __global__ void __launch_bounds__(kThreads, 8) fmd_firdemod_kernel(const FirDemo
     }
 }
 
+// ---- the same operator with the discriminator taken straight out of the matrix-core result registers (round 4) ---------
+// fmd_firdemod_kernel above keeps the normalised FIR outputs in LDS (one packed dword each), meets at a barrier and
+// runs the discriminator as a second pass over that array.  Here, for decimate 8 (BASELINE config 4), the FIR outputs
+// never leave the registers the matrix instructions put them in:
+//   * a wave's 16 columns hold PC = 4 NG - 2 consecutive outputs each (14, 18, 22 for NG = 4, 5, 6: a column pitch of
+//     2 mod 4 outputs keeps the ds_read_b128 operand reads conflict-free, see above), lane (j, q) of the wave owns
+//     outputs 4 gi + q of column j, gi < NG, in acc[gi]; consecutive waves overlap by ONE output, so every output a wave
+//     owns has its predecessor inside the same wave;
+//   * the predecessor of lane (j, q >= 1)'s output gi is lane (j, q - 1)'s output gi: 16 lanes down, one
+//     ds_bpermute_b32 per component (a crossbar move, no LDS memory, no bank conflicts); lane (j, 0) takes lane
+//     (j, 3)'s output gi - 1 -- the same move of the previous register -- and, for gi = 0, the last output of column
+//     j - 1 (lane (j - 1, 1), register NG - 1);
+//   * each lane then runs its NG discriminators (f32 component form), splits their sum at the one audio-group boundary
+//     its outputs can straddle (a group is at least 4 NG - 3 outputs long: checked by the host, which otherwise takes the
+//     kernel above) and adds the two partial sums to the groups' accumulators in LDS.
+// Gone: the packed-sample array (4 bytes per output: the tile grows from 17 to 22 audio samples at 8 tiles per CU), its
+// stores and 4-way-conflicting reads, one barrier, the per-lane run bookkeeping of the second pass.
+template <int NKU, int NG>
+__global__ void __launch_bounds__(kThreads, 8) fmd_firdemod_reg_kernel(const FirDemodLaunch L)
+{
+    constexpr int PC = 4 * NG - 2;                           // outputs per column
+    constexpr int WSTEP = 16 * PC - 1;                       // tile outputs from one wave's first column to the next wave's
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+    const uint32_t tid = threadIdx.x, lane = tid & 63u;
+    const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid >> 6));
+    __builtin_amdgcn_s_setprio(3);                           // get the loads out first (see fmd_tile_body.h)
+    uint32_t c, t;
+    if (L.xcd == 3u) { c = blockIdx.x * gridDim.z + blockIdx.z; t = blockIdx.y; }   // grid (8, tiles, ceil(C / 8))
+    else { c = blockIdx.y + 65535u * blockIdx.z; t = blockIdx.x; }
+    if (c >= L.n_channels || t >= L.P.nt) return;
+
+    const FmdRates& r = L.r;
+    const FmdClassPlan& P = L.P;
+    const bool last = t + 1u == P.nt;
+    const uint32_t k0 = t * r.kt, k1 = k0 + r.kt < P.K ? k0 + r.kt : P.K;
+    int jA, jB;
+    uint32_t eq, er, x0;
+    if (L.use_rows) {                                        // tabulated by the host (fd_enqueue): no division, no comparisons
+        jA = L.rows[t].jA; jB = L.rows[t].jB; eq = L.rows[t].eq; er = L.rows[t].er; x0 = L.rows[t].x0;
+    } else {
+        const FmdTile T = fmd_tile_fast(r, P, L.tl, 0u, t);
+        jA = T.jA; jB = T.jB; eq = T.eq; er = T.er;
+        x0 = (uint32_t)jA * r.sr + P.i0r - k0 * r.fr;        // (all three terms below 2^32: fmd_ranges_fit32)
+    }
+    const int jfirst = jA - 1;                               // lp[jfirst .. jB]; lp[-1] is demod_pre
+    const uint32_t o0 = jfirst > 0 ? (uint32_t)jfirst : 0u;  // first FIR output (of this call) the tile forms
+    const uint32_t no = (uint32_t)jB - o0 + 1u;              // FIR outputs formed
+    const uint32_t w0 = L.wd_first + o0 * L.half_M;          // first virtual dword of the tile
+    const uint32_t nq = ((((no - 1) * L.half_M + L.NP + 3u) >> 2) + 3u) & ~3u;   // 16-byte slots, whole 64-byte chunks
+    if (nq * 16u > L.raw_bytes || no > (uint32_t)(64 * PC - 3)) {
+        if (tid == 0) atomicOr(&L.exc->err, FMD_DEVERR_RAW_CAP);
+        return;
+    }
+    int* const gsum = reinterpret_cast<int*>(lds + (L.raw_bytes >> 2));   // audio group sums of the tile: [nk] + the carried tail
+    int* const gse = gsum + (r.kt + 2u);                     // (first, last) discriminator sample of every group
+    int* const tail = gse + 2u * (r.kt + 2u);                // the tile's last FIR output (re, im): demod_pre of the next call
+
+    const uint32_t j = lane & 15u, q = lane >> 4;
+    typedef const FMD_AS_GLOBAL fd_i4* gq;
+    const gq amat = (gq)(uintptr_t)L.amat + lane;
+    fd_i4 A[NKU];                                            // the tap fragments: in flight with the data
+#pragma unroll
+    for (int k = 0; k < NKU; ++k) A[k] = amat[k * 64];
+
+    const bool fast = ((((uintptr_t)L.iq + ((uint64_t)c * L.stride_w + (uint64_t)w0 - L.Hw) * 4u)) & 15u) == 0u;
+    const bool whole = fast && w0 >= L.Hw && (uint64_t)(w0 - L.Hw) + 4ull * nq <= L.stride_w;
+    fd_i4* lq = reinterpret_cast<fd_i4*>(lds);
+    if (whole) {
+        const unsigned char* src = reinterpret_cast<const unsigned char*>(L.iq + (uint64_t)c * L.stride_w + (w0 - L.Hw)) + 16u * tid;
+        unsigned char* dst = reinterpret_cast<unsigned char*>(lds) + 1024u * wave;
+        const uint32_t nfull = nq / kThreads, ntail = nq - nfull * kThreads;
+        for (uint32_t l = 0; l < nfull; ++l) dma16(src + (16u * kThreads) * l, dst + (16u * kThreads) * l);
+        if (tid < ntail) dma16(src + (16u * kThreads) * nfull, dst + (16u * kThreads) * nfull);
+    } else {
+        for (uint32_t i = tid; i < nq; i += kThreads) lq[i] = virt_chunk(L, c, w0 + 4u * i, fast);
+    }
+    FmdChanState st{};
+    if (jfirst < 0 || k0 == 0 || last) st = L.st_in[c];
+    // under the load latency: audio group k of the tile (k == nk: the trailing partial group) -- zero its accumulator and
+    // tabulate its first and last discriminator sample (see fmd_firdemod_kernel)
+    for (uint32_t k = tid; k <= r.kt; k += kThreads) {
+        gsum[k] = 0;
+        const uint32_t x = er + k * L.fb;
+        uint32_t u, xrem;
+        if (L.sr_shift < 32u) { u = x >> L.sr_shift; xrem = x & (r.sr - 1u); }
+        else { u = fmd_udiv_small(x, r.sr, L.inv_sr); xrem = x - u * r.sr; }
+        int e = (int)(eq + k * L.fa + u);
+        int s0 = e - (int)L.fa + (xrem < L.fb ? 0 : 1);
+        s0 = s0 > 0 ? s0 : 0;                                // the call's first group starts at sample 0
+        e = e < jB ? e : jB;                                 // the carried group ends with the call
+        gse[2u * k] = s0; gse[2u * k + 1u] = e;
+    }
+    // the channel's last tile also writes the next call's history (the raw bytes are all in global memory)
+    if (last) {
+        typedef const FMD_AS_GLOBAL uint32_t* gw;
+        for (uint32_t k = tid; k < L.Hw; k += kThreads) {
+            const uint64_t w = L.stride_w + k;               // virtual dword (history ++ call), < Hw + stride_w
+            L.hist_out[(uint64_t)c * L.Hw + k] = w < L.Hw ? ((gw)(uintptr_t)L.hist_in)[(uint64_t)c * L.Hw + w]
+                                                         : ((gw)(uintptr_t)L.iq)[(uint64_t)c * L.stride_w + (w - L.Hw)];
+        }
+    }
+    __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_s_waitcnt(0x0F70);                      // vmcnt(0): the LDS-DMAs (and the A fragments) have landed
+    __syncthreads();
+
+    // ---- FIR on the matrix cores: NKU + NG - 1 operand fragments feed NG accumulators (fragment reuse, see above) ----------
+    const uint32_t tcol = wave * (uint32_t)WSTEP + j * (uint32_t)PC;     // tile output index of the column's first output
+    fd_i4 acc[NG];
+#pragma unroll
+    for (int gi = 0; gi < NG; ++gi) acc[gi] = fd_i4{0, 0, 0, 0};
+    {
+        const uint8_t* col = reinterpret_cast<const uint8_t*>(lds) + 16u * tcol + 16u * q;   // decimate 8: 16 bytes per output
+#pragma unroll
+        for (int sft = 0; sft < NKU + NG - 1; ++sft) {
+            fd_i4 B = *reinterpret_cast<const fd_i4*>(col + 64 * sft);
+            B = B ^ (int)0x80808080;                                                       // u8 -> s8
+#pragma unroll
+            for (int jj = 0; jj < NG; ++jj)
+                if (sft - jj >= 0 && sft - jj < NKU) acc[jj] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A[sft - jj], B, acc[jj], 0, 0, 0);
+        }
+    }
+    // lane (j, q) holds (re_lo, re_hi, im_lo, im_hi) of tile output tcol + 4 gi + q in acc[gi]: combine the tap digits, add
+    // the window-parity constant, normalise -- and keep the components as exact f32 integers
+    const uint32_t par_tile = (L.par_first + o0 * L.half_M) & 1u;
+    const uint32_t par = (par_tile ^ (L.half_M * q)) & 1u;
+    const int cre = par ? L.mre[1] : L.mre[0], cim = par ? L.mim[1] : L.mim[0];
+    const uint32_t sgn = 0u - par_tile;                      // wave-uniform sign mask: (v ^ m) - m = m ? -v : v
+    float fr[NG], fi[NG];
+    int re_last = 0, im_last = 0;                            // integer components of the lane's last register (for demod_pre)
+#pragma unroll
+    for (int gi = 0; gi < NG; ++gi) {
+        const uint32_t ure = (uint32_t)acc[gi].x + ((uint32_t)acc[gi].y << 7), uim = (uint32_t)acc[gi].z + ((uint32_t)acc[gi].w << 7);
+        const int re = ((int)((ure ^ sgn) - sgn) + cre) >> L.shift;          // floor(y / 2^shift)
+        const int im = ((int)((uim ^ sgn) - sgn) + cim) >> L.shift;
+        fr[gi] = (float)re; fi[gi] = (float)im;
+        if (last) {                                          // block-uniform: the output that becomes demod_pre
+            const uint32_t tt = tcol + 4u * (uint32_t)gi + q;
+            if (tt == no - 1u && (gi < NG - 1 || q < 2u)) { re_last = re; im_last = im; tail[0] = re; tail[1] = im; }
+        }
+    }
+    (void)re_last; (void)im_last;
+    // predecessors: 16 lanes down (q - 1, same column); lane (j, 0) takes the previous register of lane (j, 3), and for its
+    // first output the last output of column j - 1 (lane (j - 1, 1), register NG - 1: PC - 1 = 4 (NG - 1) + 1)
+    const int down = (int)(((lane + 48u) & 63u) << 2);       // byte address of lane - 16 (mod 64)
+    const int left = (int)((16u + ((j + 15u) & 15u)) << 2);  // byte address of lane (j - 1, 1)
+    float pr[NG], pi[NG];
+#pragma unroll
+    for (int gi = 0; gi < NG; ++gi) {
+        pr[gi] = u2f((uint32_t)__builtin_amdgcn_ds_bpermute(down, (int)f2u(fr[gi])));
+        pi[gi] = u2f((uint32_t)__builtin_amdgcn_ds_bpermute(down, (int)f2u(fi[gi])));
+    }
+    const float xr = u2f((uint32_t)__builtin_amdgcn_ds_bpermute(left, (int)f2u(fr[NG - 1])));
+    const float xi = u2f((uint32_t)__builtin_amdgcn_ds_bpermute(left, (int)f2u(fi[NG - 1])));
+    const bool q0 = q == 0u;
+    // ---- fm_demod (:355-367) per output, summed per audio group (:408-417) -------------------------------------------
+    const uint32_t tmin = jfirst < 0 ? 0u : 1u;              // tile output 0 is only a predecessor (except at the call start)
+    const uint32_t t_first = tcol + q;                       // the lane's first tile output; sample index m = o0 + t
+    // audio group of the lane's first output and that group's last sample
+    const int dm = (int)(o0 + t_first) - jA;                 // >= -1
+    const uint32_t kq = (uint32_t)fmd_sdiv_magic((int)(x0 + (uint32_t)(dm > 0 ? dm : 0) * r.sr), L.magic_fr);
+    const uint32_t kqc = kq <= r.kt ? kq : r.kt;             // (lanes beyond the tile: any valid row)
+    const int e_lo = gse[2u * kqc + 1u];
+    int sum_all = 0, sum_lo = 0;
+    int d_first = 0, cr0 = 0, ci0 = 0;
+    bool any_guard = false;
+#pragma unroll
+    for (int gi = 0; gi < NG; ++gi) {
+        const float br = q0 ? (gi == 0 ? xr : pr[gi - 1]) : pr[gi];
+        const float bi = q0 ? (gi == 0 ? xi : pi[gi - 1]) : pi[gi];
+        int d = disc_f32_c(fr[gi], fi[gi], br, bi);          // (:362); the value fits i16, `as i16` changes nothing
+        const uint32_t tt = t_first + 4u * (uint32_t)gi;
+        if (gi == 0 && jfirst < 0 && tid == 0) {             // the first sample of the call takes the f64 path (:359) against demod_pre
+            fmd_mul_conj((int)fr[0], (int)fi[0], st.demod_pre_re, st.demod_pre_im, cr0, ci0);
+            bool g;
+            d = polar_f64(cr0, ci0, L.f64_guard, g);
+#ifdef FMD_EXPERIMENT
+            if (g) d += L.f64_skew;
+#endif
+            any_guard = g;
+            d = (int)(int16_t)d;
+            d_first = d;
+        }
+        // owned: inside the tile, not the tile's leading predecessor, not the overlap with the previous wave, a real row of the column
+        const bool own = tt >= tmin && tt < no && !(gi == 0 && q0 && j == 0u && wave > 0u) && (gi < NG - 1 || q < 2u);
+        const int dv = own ? d : 0;
+        sum_all += dv;
+        sum_lo += (int)(o0 + tt) <= e_lo ? dv : 0;
+    }
+    // (a lane whose outputs are all beyond the tile or not owned adds zeros: harmless)
+    if (kq <= r.kt) atomicAdd(&gsum[kqc], sum_lo);
+    if (kq + 1u <= r.kt && sum_all != sum_lo) atomicAdd(&gsum[kq + 1u], sum_all - sum_lo);
+    __syncthreads();
+
+    // ---- low_pass_real (:418-422): one divide per audio sample ---------------------------------------------------
+    const uint32_t nk = k1 - k0;
+    int16_t* const outc = L.out + (uint64_t)c * L.out_stride;
+    for (uint32_t k = tid; k < nk; k += kThreads) {
+        int sum = gsum[k];
+        if (k0 + k == 0u) sum += st.now_lpr;                 // continues the previous call's partial sum (:410-417)
+        outc[k0 + k] = (int16_t)fmd_sdiv_small(sum, r.R, L.inv_R);
+    }
+    if (jfirst < 0 && tid == 0 && any_guard) {               // guarded f64 sample (FmdF64Exc, fmd_kernels.h)
+        const bool in_audio = P.K > 0u;                      // sample 0 lies in audio group 0, or in the carried tail
+        exc_emit_direct(L.exc, c, L.seq, in_audio ? 0 : -1, gsum[0] + st.now_lpr, d_first, cr0, ci0, outc);
+    }
+    // ---- state after the call (last tile; simple_fm.rs:232-239) --------------------------------------------------
+    if (last && tid == 0) {
+        FmdChanState ns_{};
+        ns_.now_lpr = gsum[nk] + (P.K == 0 ? st.now_lpr : 0);       // the trailing partial group
+        ns_.lpr_index_r = fmd_next_lpr_index_r(r, P.i0r, P.M, P.K);
+        ns_.demod_pre_re = tail[0]; ns_.demod_pre_im = tail[1];     // demod_pre = the last filter output (M >= 2 guaranteed by the host)
+        L.st_out[c] = ns_;
+    }
+}
+
 template <int NKU>
 void launch(const FirDemodLaunch& L, dim3 g, size_t lds, hipStream_t s)
 {
-    if (L.reuse == 1u) hipLaunchKernelGGL((fmd_firdemod_kernel<NKU, 1>), g, dim3(kThreads), lds, s, L);
+    if (L.reg_ng == 4u) hipLaunchKernelGGL((fmd_firdemod_reg_kernel<NKU, 4>), g, dim3(kThreads), lds, s, L);
+    else if (L.reg_ng == 5u) hipLaunchKernelGGL((fmd_firdemod_reg_kernel<NKU, 5>), g, dim3(kThreads), lds, s, L);
+    else if (L.reg_ng == 6u) hipLaunchKernelGGL((fmd_firdemod_reg_kernel<NKU, 6>), g, dim3(kThreads), lds, s, L);
+    else if (L.reuse == 1u) hipLaunchKernelGGL((fmd_firdemod_kernel<NKU, 1>), g, dim3(kThreads), lds, s, L);
 #ifdef FMD_EXPERIMENT
     else if (L.reuse == 2u) hipLaunchKernelGGL((fmd_firdemod_kernel<NKU, 2>), g, dim3(kThreads), lds, s, L);   // FMD_FD_REUSE16: measured 4-6 % slower than the plain mapping
 #endif
@@ -440,6 +662,7 @@ struct fmd_firdemod {
     bool no_rows = false;                                 // FMD_FD_ROWS=0: geometry on the device (A/B)
     bool reuse16 = false;                                 // FMD_FD_REUSE16 (experiment build): fragment reuse at decim 16 too
     bool no_reuse = false, int_disc = false;              // FMD_FD_NOREUSE / FMD_FD_INT_DISC: plain MFMA mapping / integer discriminator (A/B), read at creation
+    uint32_t reg_ng = 0;                                  // > 0: fmd_firdemod_reg_kernel with this many output groups per column (decimate 8, f32 discriminator)
     size_t lds_budget = 20480;                            // LDS per tile (8 tiles per CU); FMD_FD_LDS (tuning)
     hipStream_t stream = nullptr;
     uint8_t* d_iq = nullptr; size_t d_iq_cap = 0;
@@ -478,9 +701,19 @@ bool fd_sizes(const fmd_firdemod* f, uint32_t kt, uint32_t* lp_cap, uint32_t* ra
 {
     FmdRates r = f->r; r.kt = kt;
     const uint32_t cap = fmd_tile_lp_cap(r);
-    if (cap > kMaxOutputs) return false;
     const uint32_t half_M = f->M / 2;
     const uint64_t staged = (((((uint64_t)(cap - 1) * half_M + f->NP + 3) / 4) + 3) & ~(uint64_t)3) * 16;
+    if (f->reg_ng) {                                      // register form: no packed-sample array; the columns' operand reads bound the raw region
+        const uint32_t pc = 4u * f->reg_ng - 2u;
+        if (cap > 64u * pc - 3u) return false;
+        const uint64_t touched = 16ull * (63u * pc - 3u) + 64ull * (f->plan.nku + f->reg_ng - 1u);
+        const uint64_t raw = ((staged > touched ? staged : touched) + 15) & ~(uint64_t)15;
+        const uint64_t total = raw + 12ull * (kt + 2) + 8 + 16;               // + group sums, the (first, last) table, the tail sample
+        if (total > 60 * 1024) return false;
+        *lp_cap = cap; *raw_bytes = (uint32_t)raw; *lds = (size_t)total;
+        return true;
+    }
+    if (cap > kMaxOutputs) return false;
     const uint64_t touched = (uint64_t)16 * ((cap + 63) / 64) * (8u * f->M) + (uint64_t)64 * f->plan.n_pass * f->plan.nku;
     const uint64_t raw = ((staged > touched ? staged : touched) + 15) & ~(uint64_t)15;
     const uint64_t total = raw + 4ull * (cap + 1) + 12ull * (kt + 2) + 16;   // + group sums and the (first, last) table
@@ -526,6 +759,8 @@ int fd_enqueue(fmd_firdemod* f, const void* d_iq, size_t nbytes, void* d_out, si
     L.exc = f->d_exc; L.f64_guard = f->f64_guard; L.seq = f->seq + 1; L.f64_skew = f->f64_skew;
     L.dbg = f->dbg;
     fd_lanes(L.fa, r.kt, &L.lg, &L.lg_magic, &L.ch);
+    L.reg_ng = f->reg_ng;
+    L.magic_fr = fmd_make_magic(r.fr);
     L.reuse = (f->M == 8u || (f->M == 16u && f->reuse16)) && f->plan.n_pass == 1u && !f->no_reuse ? f->M / 8u : 0u;
     L.f32_disc = f->lp_bound <= 2048u && !f->int_disc ? 1u : 0u;
     L.sr_shift = 32u;
@@ -534,7 +769,7 @@ int fd_enqueue(fmd_firdemod* f, const void* d_iq, size_t nbytes, void* d_out, si
     if (L.P.nt <= kFdRows && !f->no_rows) {
         for (uint32_t t = 0; t < L.P.nt; ++t) {
             const FmdTile T = fmd_tile_fast(r, L.P, L.tl, 0u, t);
-            L.rows[t] = FdRow{T.jA, T.jB, T.eq, T.er};
+            L.rows[t] = FdRow{T.jA, T.jB, T.eq, T.er, (uint32_t)((uint64_t)T.jA * r.sr + f->i0r - (uint64_t)T.k0 * r.fr)};
         }
         L.use_rows = 1u;
     }
@@ -634,6 +869,13 @@ int fmd_firdemod_new(const int16_t* taps, uint32_t n_taps, uint32_t decim, uint3
     f->reuse16 = fmd_knob("FMD_FD_REUSE16") != nullptr;
     f->int_disc = fmd_knob("FMD_FD_INT_DISC") != nullptr;
     f->dbg = fmd_knob_u32("FMD_DBG", 0);
+    // decimate 8 with the f32 discriminator and audio groups of at least 4 NG outputs: the register form (NG = 5: columns of 18
+    // outputs, 22 audio samples per tile at BASELINE config 4 instead of 17); FMD_FD_REG = 0 / 4 / 6 in the experiment build
+    f->reg_ng = 0;
+    if (decim == 8u && f->plan.n_pass == 1u && f->lp_bound <= 2048u && !f->no_reuse && !f->int_disc) {
+        const uint32_t ng = fmd_knob_u32("FMD_FD_REG", 5);
+        if (ng >= 4u && ng <= 6u && fa >= 4ull * ng && (uint64_t)r.sr * (64u * (4u * ng - 2u)) < (1u << 24)) f->reg_ng = ng;
+    }
     for (uint32_t kt = 1; kt <= 1024; ++kt) {
         if ((uint64_t)r.sr * (kt + 2) >= (1u << 24)) break;
         uint32_t lc, rb; size_t l;
@@ -759,6 +1001,16 @@ int fmd_firdemod_f64_stats(const fmd_firdemod* f, uint64_t* guarded, uint64_t* p
     if (guarded) *guarded = f->f64_guarded;
     if (patched) *patched = f->f64_patched;
     return FMD_OK;
+}
+
+int fmd_firdemod_kernel_name(const fmd_firdemod* f, char* name, size_t cap)
+{
+    if (!f || !name || cap == 0) return FMD_ERR_INVALID_ARG;
+    const uint32_t nku = f->plan.nku < 8u ? f->plan.nku : 8u;
+    const bool reuse = f->M == 8u && f->plan.n_pass == 1u && !f->no_reuse;
+    const int n = f->reg_ng ? snprintf(name, cap, "fmd_firdemod_reg_kernel<%u, %u>", nku, f->reg_ng)
+                            : snprintf(name, cap, "fmd_firdemod_kernel<%u, %u>", nku, reuse ? 1u : 0u);
+    return n < 0 || (size_t)n >= cap ? FMD_ERR_CAPACITY : FMD_OK;
 }
 
 int fmd_firdemod_tiling(const fmd_firdemod* f, uint32_t* audio_per_tile, uint32_t* lds_bytes)

@@ -102,7 +102,7 @@ __global__ void __launch_bounds__(FMD_BLOCK_THREADS) fmd_demod_generic_kernel(co
         int pcm;
         if (jfirst + i == 0) {                               // first sample of the call (:359)
             bool g;
-            pcm = polar_f64(cr, ci, L.f64_guard, &g);
+            pcm = polar_f64(cr, ci, L.f64_guard, g);
 #ifdef FMD_EXPERIMENT
             if (g) pcm += L.f64_skew;
 #endif
@@ -128,7 +128,7 @@ __global__ void __launch_bounds__(FMD_BLOCK_THREADS) fmd_demod_generic_kernel(co
         lp.get(1, ar, ai); lp.get(0, br, bi);
         fmd_mul_conj(ar, ai, br, bi, cr, ci);
         bool g;
-        (void)polar_f64(cr, ci, L.f64_guard, &g);
+        (void)polar_f64(cr, ci, L.f64_guard, g);
         if (g) exc_emit(exc_args(L, c, i0r, K, st.now_lpr, d16, jfirst), 0, cr, ci);
     }
 

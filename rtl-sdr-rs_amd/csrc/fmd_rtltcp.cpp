@@ -7,7 +7,8 @@
 // like RtlSdr::read_sync (src/lib.rs:153): fill the caller's buffer, report the bytes written -- fewer than asked means
 // the stream ended, which every caller of the reference treats as "samples lost" (examples/simple_fm.rs:122).  A dongle
 // on another host thereby feeds the GPU sink with no USB code here.  Host code only: sockets and bytes, no arithmetic,
-// no HIP (it works on a box without a GPU).
+// no HIP header (it works on a box without a GPU, and builds with plain g++ -fsanitize=address,undefined:
+// tests/test_sanitizers.py runs it against hostile servers that way).
 #include "../../include/fmd.h"
 
 #include <arpa/inet.h>
@@ -21,11 +22,12 @@
 #include <sys/types.h>
 #include <unistd.h>
 
+#include <climits>
 #include <cstdio>
 #include <cstring>
 #include <new>
 
-#include "fmd_host.h"
+void fmd_internal_set_err(const char* msg);                  // thread-local text behind fmd_last_error() (fmd_api.cpp)
 
 struct fmd_rtltcp {
     int fd = -1;
@@ -95,7 +97,7 @@ int fmd_rtltcp_open(const char* host, uint16_t port, uint32_t timeout_ms, fmd_rt
     }
     fmd_rtltcp* s = new (std::nothrow) fmd_rtltcp();
     if (!s) { freeaddrinfo(res); return FMD_ERR_NOMEM; }
-    s->timeout_ms = timeout_ms ? (int)timeout_ms : 10000;
+    s->timeout_ms = timeout_ms == 0 ? 10000 : (timeout_ms > (uint32_t)INT_MAX ? INT_MAX : (int)timeout_ms);   // (a negative poll() timeout waits forever)
     int last_errno = ECONNREFUSED;
     for (struct addrinfo* a = res; a && s->fd < 0; a = a->ai_next) {
         const int fd = socket(a->ai_family, a->ai_socktype, a->ai_protocol);
@@ -161,9 +163,11 @@ int fmd_rtltcp_command(fmd_rtltcp* s, uint8_t opcode, uint32_t param)
     if (!s) { fmd_internal_set_err("null argument"); return FMD_ERR_INVALID_ARG; }
     const uint8_t msg[5] = {opcode, (uint8_t)(param >> 24), (uint8_t)(param >> 16), (uint8_t)(param >> 8), (uint8_t)param};   // :653-657
     size_t sent = 0;
-    while (sent < sizeof msg) {
-        const ssize_t r = send(s->fd, msg + sent, sizeof msg - sent, MSG_NOSIGNAL);
-        if (r < 0) { if (errno == EINTR) continue; err("command"); return FMD_ERR_IO; }
+    while (sent < sizeof msg) {                              // the timeout covers a server that stopped reading, too
+        const int w = wait_fd(s->fd, POLLOUT, s->timeout_ms);
+        if (w <= 0) { if (w == 0) errno = ETIMEDOUT; err("command"); return FMD_ERR_IO; }
+        const ssize_t r = send(s->fd, msg + sent, sizeof msg - sent, MSG_NOSIGNAL | MSG_DONTWAIT);
+        if (r < 0) { if (errno == EINTR || errno == EAGAIN || errno == EWOULDBLOCK) continue; err("command"); return FMD_ERR_IO; }
         sent += (size_t)r;
     }
     return FMD_OK;

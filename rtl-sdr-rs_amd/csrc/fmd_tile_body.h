@@ -89,6 +89,9 @@ __device__ __forceinline__ uint32_t wave_ror1(uint32_t v)
 }
 
 // Sum of one audio group: FA samples plus one optional (low_pass_real, :411-415).
+// (hipcc merges the FA + 1 int16_t loads into ONE ds_read_b64 / b96 / b128 at a 2-byte aligned address.  Round 4 measured
+//  the alternative -- aligned dword pairs summed by v_dot2_i32_i16 against 0 / 1 half-word weights -- 0.8 ... 1.3 % SLOWER at
+//  downsample 4, 6, 7 and 18 % slower at downsample 1, where the resampler dominates: profiles/r04_experiments.md.)
 template <int FA>
 __device__ __forceinline__ int group_sum(const int16_t* __restrict__ dp, bool extra)
 {
@@ -177,7 +180,7 @@ __device__ __forceinline__ void tile_exc_flush(const FmdLaunch& L, const TileCtx
         lds_window_sum(raw_w, wofs, 0, fmd_win_end(r.D, p0, 0), r0, i0);
         r0 += st.lp_now_re; i0 += st.lp_now_im;
         fmd_mul_conj(r0, i0, st.demod_pre_re, st.demod_pre_im, cr, ci);
-        (void)polar_f64(cr, ci, L.f64_guard, &g);
+        (void)polar_f64(cr, ci, L.f64_guard, g);
         if (g) exc_emit(exc_args(L, X.c, P.i0r, P.K, st.now_lpr, d16, jfirst), 0, cr, ci);
     }
     if (L.block_ns) {
@@ -194,7 +197,7 @@ __device__ __forceinline__ void tile_exc_flush(const FmdLaunch& L, const TileCtx
             lds_window_sum(raw_w, wofs, fmd_win_begin(D, p0, j - 1), fmd_win_end(D, p0, j - 1), br, bi);
             if (j - 1 == 0) { br += st.lp_now_re; bi += st.lp_now_im; }
             fmd_mul_conj(ar, ai, br, bi, cr, ci);
-            (void)polar_f64(cr, ci, L.f64_guard, &g);
+            (void)polar_f64(cr, ci, L.f64_guard, g);
             if (g) exc_emit(exc_args(L, X.c, P.i0r, P.K, st.now_lpr, d16, jfirst), j, cr, ci);
         }
     }
@@ -603,7 +606,7 @@ __device__ __forceinline__ void tile_body(const FmdLaunch& L, const TileCtx& X, 
         if (jfirst < 0) {
             fmd_mul_conj(r0, i0, st.demod_pre_re, st.demod_pre_im, cr, ci);
             bool g;
-            const int v = polar_f64(cr, ci, L.f64_guard, &g);
+            const int v = polar_f64(cr, ci, L.f64_guard, g);
             d16[1] = (int16_t)(v + (g ? FMD_F64_SKEW : 0));
             any_guard = g;
         }
@@ -649,7 +652,7 @@ __device__ __forceinline__ void tile_body(const FmdLaunch& L, const TileCtx& X, 
             if (j - 1 == 0) { br += st.lp_now_re; bi += st.lp_now_im; }
             fmd_mul_conj(ar, ai, br, bi, cr, ci);
             bool g;
-            const int v = polar_f64(cr, ci, L.f64_guard, &g);
+            const int v = polar_f64(cr, ci, L.f64_guard, g);
             d16[j - jfirst] = (int16_t)(v + (g ? FMD_F64_SKEW : 0));
             any_guard |= g;
         }

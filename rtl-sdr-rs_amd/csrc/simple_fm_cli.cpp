@@ -19,6 +19,7 @@
 // EOF policy (the reference ignores the read count and never terminates at EOF): only COMPLETE
 // blocks are demodulated; a trailing partial block is dropped with a note on stderr.  Logging goes to stderr
 // because stdout carries audio (:37-38).
+#include <algorithm>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -109,10 +110,29 @@ static int run_bank(const std::vector<const char*>& paths, const char* prefix, u
 // receive() + process() of the example over rtl_tcp (-t host:port)
 static int run_rtl_tcp(const char* hostport, uint32_t freq, uint32_t rate, uint32_t resample, size_t max_blocks)
 {
-    std::string host(hostport);
-    uint16_t port = 1234;
-    const size_t colon = host.rfind(':');
-    if (colon != std::string::npos) { port = (uint16_t)atoi(host.c_str() + colon + 1); host.resize(colon); }
+    // host, host:port, [v6-literal] or [v6-literal]:port (a bare IPv6 literal holds colons of its own); port 1 ... 65535
+    std::string host(hostport), portstr;
+    uint16_t port = 1234;                                    // rtl_tcp's default
+    if (!host.empty() && host[0] == '[') {
+        const size_t close = host.find(']');
+        if (close == std::string::npos) { fprintf(stderr, "-t %s: missing ']'\n", hostport); return 2; }
+        if (close + 1 < host.size()) {
+            if (host[close + 1] != ':') { fprintf(stderr, "-t %s: expected ':port' after ']'\n", hostport); return 2; }
+            portstr = host.substr(close + 2);
+        }
+        host = host.substr(1, close - 1);
+    } else if (std::count(host.begin(), host.end(), ':') == 1) {
+        const size_t colon = host.find(':');
+        portstr = host.substr(colon + 1);
+        host.resize(colon);
+    }                                                        // (several colons without brackets: an IPv6 literal, default port)
+    if (!portstr.empty()) {
+        char* end = nullptr;
+        const unsigned long v = strtoul(portstr.c_str(), &end, 10);
+        if (*end != '\0' || v < 1 || v > 65535) { fprintf(stderr, "-t %s: port must be 1 ... 65535\n", hostport); return 2; }
+        port = (uint16_t)v;
+    }
+    if (host.empty()) { fprintf(stderr, "-t %s: empty host\n", hostport); return 2; }
     try {
         const auto settings = fm::optimal_settings(freq, rate, resample);           // :48
         const fm::DemodConfig& dc = settings.second;

@@ -121,3 +121,9 @@ class FirDemodBank:
         a, b = C.c_uint32(), C.c_uint32()
         check(lib().fmd_firdemod_tiling(self._h, C.byref(a), C.byref(b)))
         return {"audio_per_tile": a.value, "lds_bytes": b.value}
+
+    def kernel_name(self):
+        """The kernel this bank launches, as rocprofv3 --kernel-trace prints it."""
+        buf = C.create_string_buffer(128)
+        check(lib().fmd_firdemod_kernel_name(self._h, buf, len(buf)))
+        return buf.value.decode()

@@ -129,6 +129,7 @@ extern "C" {
     pub fn fmd_firdemod_get_state(f: *mut fmd_firdemod, channel: u32, state: *mut DemodState) -> c_int;
     pub fn fmd_firdemod_f64_stats(f: *const fmd_firdemod, guarded: *mut u64, patched: *mut u64) -> c_int;
     pub fn fmd_firdemod_tiling(f: *const fmd_firdemod, audio_per_tile: *mut u32, lds_bytes: *mut u32) -> c_int;
+    pub fn fmd_firdemod_kernel_name(f: *const fmd_firdemod, name: *mut c_char, cap: usize) -> c_int;
     pub fn fmd_sink_new(config: *const DemodConfig, n_channels: u32, device_ids: *const i32, n_devices: u32, nbytes: usize, depth: u32, callback: fmd_sink_callback, user: *mut c_void, out: *mut *mut fmd_sink) -> c_int;
     pub fn fmd_sink_free(s: *mut fmd_sink);
     pub fn fmd_sink_acquire(s: *mut fmd_sink, iq: *mut *mut u8) -> c_int;

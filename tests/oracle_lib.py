@@ -36,6 +36,8 @@ class ChanState(C.Structure):
 
 
 def build():
+    if os.environ.get("FMO_LIB"):                             # an instrumented build of the same sources (tests/test_sanitizers.py)
+        return os.environ["FMO_LIB"]
     srcs = [os.path.join(ODIR, f) for f in ("fm_oracle.c", "fm_oracle.h", "closed_form.cpp", "Makefile")]
     srcs.append(os.path.join(ROOT, "rtl-sdr-rs_amd", "csrc", "fmd_index.h"))
     if os.path.exists(SO) and all(os.path.getmtime(SO) >= os.path.getmtime(s) for s in srcs):

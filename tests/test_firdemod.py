@@ -29,7 +29,7 @@ def state_tuple(s):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("D,fast,slow", [(6, 170000, 32000), (10, 240000, 32000), (2, 48000, 48000), (16, 150000, 32000),
-                                         (64, 37500, 8000)])
+                                         (64, 37500, 8000), (8, 250000, 8000)])      # the last one: the register form (decimate 8)
 def test_gpu_all_ones_is_the_boxcar_kernel_and_the_reference(fmd, oracle, D, fast, slow):
     """taps = 1...1, n_taps = decim = downsample, shift 0: fused FIR kernel == boxcar kernel == oracle of the reference."""
     rng = np.random.default_rng(D + 100)
@@ -86,10 +86,40 @@ def test_gpu_fused_reuse_at_decim_16(fmd, oracle, request):
         fused_case(fmd, oracle, T, M, fast, slow)
 
 
-def fused_case(fmd, oracle, T, M, fast, slow):
+REG_SHAPES = [(127, 8, 2500000, 48000), (127, 8, 1000000, 44100), (8, 8, 250000, 8000), (200, 8, 480000, 8000), (33, 8, 960000, 48000),
+              (1, 8, 640000, 32000)]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("T,M,fast,slow", REG_SHAPES)
+def test_gpu_fused_register_form(fmd, oracle, T, M, fast, slow):
+    """Decimate 8 with the f32 discriminator (|lp| <= 2048) and audio groups of >= 20 filter outputs: the form that takes
+    the discriminator straight out of the matrix-core result registers (fmd_firdemod_reg_kernel): tiny first calls, many
+    tiles per channel, full scale, state carried over six calls."""
+    kn = fused_case(fmd, oracle, T, M, fast, slow, f32_only=True)
+    assert kn.startswith("fmd_firdemod_reg_kernel<"), kn
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("ng", ["0", "4", "6"])
+def test_gpu_fused_register_form_variants(fmd, oracle, request, ng):
+    """The same shapes with 4 / 6 output groups per column (columns of 14 / 22 outputs) and with the form switched off (the
+    LDS-array kernel that every other decimation runs): knobs of the -DFMD_EXPERIMENT build."""
+    from conftest import run_in_exp_child
+    if run_in_exp_child(request, {"FMD_FD_REG": ng}):
+        return
+    for T, M, fast, slow in REG_SHAPES[:4]:
+        kn = fused_case(fmd, oracle, T, M, fast, slow, f32_only=True)
+        want_reg = ng != "0" and fast // slow >= 4 * int(ng)         # an audio group must hold a lane's 4 ng - 3 consecutive outputs
+        assert kn.startswith("fmd_firdemod_reg_kernel<") == want_reg and (not want_reg or kn.endswith(", %s>" % ng)), kn
+
+
+def fused_case(fmd, oracle, T, M, fast, slow, f32_only=False):
     rng = np.random.default_rng(T * 11 + M)
     taps = rng.integers(-2047, 2048, T).astype(np.int16)
     shift = fmd.auto_shift(taps, 16384) + int(rng.integers(0, 6))     # both discriminator forms (|lp| <= 2048: f32)
+    if f32_only:
+        shift = fmd.auto_shift(taps, 2048) + int(rng.integers(0, 3))
     nch = 5
     fd = fmd.FirDemodBank(taps, M, fast, slow, nch, shift=shift)
     hs = [oracle.firdemod_new(taps, M, shift, fast, slow) for _ in range(nch)]
@@ -111,6 +141,7 @@ def fused_case(fmd, oracle, T, M, fast, slow):
         oracle.lib.fmo_firdemod_free(hs[c])
     fd.reset()
     assert fd.get_state(0).as_dict()["demod_pre"] == [0, 0]
+    return fd.kernel_name()
 
 
 @pytest.mark.gpu

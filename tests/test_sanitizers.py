@@ -1,0 +1,191 @@
+"""AddressSanitizer + UndefinedBehaviorSanitizer leg of the CPU suite.  Everything host-only is built with
+`-fsanitize=address,undefined` and exercised: the oracle and the closed-form planner model (oracle/fm_oracle.c,
+oracle/closed_form.cpp over the product header fmd_index.h) by re-running their own test files in a child interpreter with
+the instrumented library preloaded, and the rtl_tcp client of the C ABI (csrc/fmd_rtltcp.cpp -- it parses network input)
+against hostile servers: handshakes cut at every length 0 ... 11, a wrong magic, a reset in the middle of a buffer, a server
+that sends nothing, one that stops reading commands.  Matches the wire format of examples/rtl_tcp.rs:691-697,609-631.
+GPU AddressSanitizer is not available on this pool: the kernels are covered by the parity suites instead."""
+import os
+import socket
+import struct
+import subprocess
+import sys
+import threading
+import time
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SAN = ["-fsanitize=address,undefined", "-fno-sanitize-recover=undefined", "-fno-omit-frame-pointer", "-g", "-O1"]
+REPORT = ("ERROR: AddressSanitizer", "runtime error:", "ERROR: LeakSanitizer")
+
+
+def gcc_lib(name):
+    p = subprocess.run(["gcc", "-print-file-name=" + name], capture_output=True, text=True).stdout.strip()
+    return p if os.path.isabs(p) and os.path.exists(p) else None
+
+
+pytestmark = pytest.mark.skipif(gcc_lib("libasan.so") is None, reason="gcc has no libasan.so")
+
+
+@pytest.fixture(scope="module")
+def san_dir(tmp_path_factory):
+    return str(tmp_path_factory.mktemp("san"))
+
+
+def test_oracle_and_planner_under_asan_ubsan(san_dir):
+    """oracle/fm_oracle.c + oracle/closed_form.cpp (fmd_index.h: tile planner, exact small divides) instrumented; their KAT,
+    closed-form, planner and cross-restatement tests re-run against that build (FMO_LIB) with libasan preloaded."""
+    odir, pkg = os.path.join(ROOT, "oracle"), os.path.join(ROOT, "rtl-sdr-rs_amd", "csrc")
+    so = os.path.join(san_dir, "libfm_oracle_san.so")
+    subprocess.check_call(["gcc"] + SAN + ["-fwrapv", "-ffp-contract=off", "-fPIC", "-std=c11", "-D_POSIX_C_SOURCE=200809L", "-c",
+                           os.path.join(odir, "fm_oracle.c"), "-o", os.path.join(san_dir, "fm_oracle.o")])
+    subprocess.check_call(["g++"] + SAN + ["-fwrapv", "-ffp-contract=off", "-fPIC", "-std=c++17", "-I" + pkg, "-I" + os.path.join(ROOT, "include"), "-c",
+                           os.path.join(odir, "closed_form.cpp"), "-o", os.path.join(san_dir, "closed_form.o")])
+    subprocess.check_call(["g++"] + SAN + ["-shared", "-o", so, os.path.join(san_dir, "fm_oracle.o"), os.path.join(san_dir, "closed_form.o"), "-lm", "-lpthread"])
+    env = dict(os.environ, FMO_LIB=so, LD_PRELOAD=gcc_lib("libasan.so"), PYTHONPATH=ROOT,
+               ASAN_OPTIONS="detect_leaks=0:abort_on_error=1:verify_asan_link_order=0", UBSAN_OPTIONS="print_stacktrace=1:halt_on_error=1")
+    files = ["tests/test_oracle_kat.py", "tests/test_closed_form.py", "tests/test_plan_and_divides.py", "tests/test_oracle_vs_pyref.py"]
+    p = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "not gpu", "-p", "no:cacheprovider"] + files,
+                       cwd=ROOT, env=env, capture_output=True, text=True, timeout=1500)
+    out = p.stdout[-3000:] + p.stderr[-3000:]
+    assert p.returncode == 0 and " passed" in p.stdout, out
+    assert not any(r in p.stdout or r in p.stderr for r in REPORT), out
+
+
+@pytest.fixture(scope="module")
+def harness(san_dir):
+    exe = os.path.join(san_dir, "rtltcp_harness")
+    subprocess.check_call(["g++"] + SAN + ["-std=c++17", "-Wall", "-Wextra", os.path.join(ROOT, "tests", "sanitize", "rtltcp_harness.cpp"),
+                           os.path.join(ROOT, "rtl-sdr-rs_amd", "csrc", "fmd_rtltcp.cpp"), "-o", exe])
+    return exe
+
+
+class Server:
+    """One-connection TCP server running `script(conn)` in a thread."""
+
+    def __init__(self, script):
+        self.lsock = socket.socket()
+        self.lsock.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
+        self.lsock.bind(("127.0.0.1", 0))
+        self.lsock.listen(1)
+        self.port = self.lsock.getsockname()[1]
+        self.script, self.error = script, None
+        self.thread = threading.Thread(target=self.run, daemon=True)
+        self.thread.start()
+
+    def run(self):
+        try:
+            conn, _ = self.lsock.accept()
+            try:
+                self.script(conn)
+            finally:
+                conn.close()
+        except Exception as e:          # a client that hung up first is part of several scenarios
+            self.error = e
+        finally:
+            self.lsock.close()
+
+
+def run_harness(harness, port, timeout_ms, nbytes, reads, cmds=()):
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=0", UBSAN_OPTIONS="print_stacktrace=1:halt_on_error=1")
+    args = [harness, str(port), str(timeout_ms), str(nbytes), str(reads)] + [str(x) for c in cmds for x in c]
+    p = subprocess.run(args, capture_output=True, text=True, timeout=60, env=env)
+    assert not any(r in p.stderr for r in REPORT), p.stderr[-3000:]
+    assert p.returncode == 0, (p.returncode, p.stdout, p.stderr[-2000:])
+    return [l.split(" ", 3) for l in p.stdout.splitlines()]
+
+
+HS = b"RTL0" + struct.pack(">II", 5, 29)            # send_handshake, examples/rtl_tcp.rs:691-697
+FMD_ERR_IO = -11                    # include/fmd.h
+
+
+def rst_close(conn):
+    conn.setsockopt(socket.SOL_SOCKET, socket.SO_LINGER, struct.pack("ii", 1, 0))     # close() sends RST
+
+
+@pytest.mark.parametrize("cut", list(range(0, 12)))
+def test_handshake_cut_short(harness, cut):
+    """The server closes after `cut` < 12 handshake bytes: open fails with FMD_ERR_IO and frees everything."""
+    srv = Server(lambda c: c.sendall(HS[:cut]))
+    lines = run_harness(harness, srv.port, 2000, 4096, 1)
+    assert lines[0][:2] == ["open", str(FMD_ERR_IO)], lines
+
+
+def test_wrong_magic_and_stalled_handshake(harness):
+    srv = Server(lambda c: c.sendall(b"RTL1" + HS[4:]))
+    assert run_harness(harness, srv.port, 2000, 4096, 1)[0][:2] == ["open", str(FMD_ERR_IO)]
+    srv = Server(lambda c: (c.sendall(HS[:7]), time.sleep(1.0)))                     # 7 bytes, then silence: the timeout ends it
+    t0 = time.time()
+    assert run_harness(harness, srv.port, 300, 4096, 1)[0][:2] == ["open", str(FMD_ERR_IO)]
+    assert time.time() - t0 < 5.0
+
+
+def test_full_stream_then_orderly_end(harness):
+    """Two whole buffers and a partial third: statuses 0, the byte counts of read_sync, the payload intact."""
+    payload = bytes((7 * k + 3) & 0xFF for k in range(2 * 4096 + 1000))
+
+    got = bytearray()
+
+    def script(c):
+        c.sendall(HS)
+        c.settimeout(5.0)
+        while len(got) < 15:                                                           # the three 5-byte commands (:633-689) come first
+            got.extend(c.recv(15 - len(got)))
+        for k in range(0, len(payload), 1500):                                         # dribbled in odd-sized pieces
+            c.sendall(payload[k:k + 1500])
+    srv = Server(script)
+    lines = run_harness(harness, srv.port, 2000, 4096, 5, cmds=[(0x01, 95155000), (0x02, 1020000), (0x0e, 0)])
+    assert lines[0] == ["open", "0", "5", "29"]
+    assert [l[:2] for l in lines[1:4]] == [["cmd", "0"]] * 3
+    assert bytes(got) == struct.pack(">BI", 0x01, 95155000) + struct.pack(">BI", 0x02, 1020000) + struct.pack(">BI", 0x0e, 0)
+    reads = [l for l in lines if l[0] == "read"]
+    assert [(r[1], r[2]) for r in reads] == [("0", "4096"), ("0", "4096"), ("0", "1000")]
+    assert [int(r[3]) for r in reads] == [sum(payload[0:4096]), sum(payload[4096:8192]), sum(payload[8192:])]
+
+
+def test_reset_in_the_middle_of_a_buffer(harness):
+    """The connection is RESET after 1.5 buffers: the second read fails with FMD_ERR_IO and reports how many bytes of
+    it did arrive (the caller keeps the I/Q byte alignment); nothing is written past them."""
+    def script(c):
+        c.sendall(HS + bytes(4096 + 2048))
+        time.sleep(0.3)                                                                # let the client drain what was sent
+        rst_close(c)
+    srv = Server(script)
+    lines = run_harness(harness, srv.port, 2000, 4096, 3)
+    reads = [l for l in lines if l[0] == "read"]
+    assert reads[0][1:3] == ["0", "4096"]
+    assert reads[1][1] in (str(FMD_ERR_IO), "0") and int(reads[1][2]) <= 2048          # RST may overtake queued bytes
+    assert len(reads) == 2
+
+
+def test_zero_byte_stream_and_silent_server(harness):
+    srv = Server(lambda c: c.sendall(HS))                                              # handshake, then an orderly close: 0-byte read
+    lines = run_harness(harness, srv.port, 2000, 4096, 2)
+    assert lines[0][1] == "0" and [l[1:3] for l in lines if l[0] == "read"] == [["0", "0"]]
+    srv = Server(lambda c: (c.sendall(HS + bytes(100)), time.sleep(1.5)))               # 100 bytes, then nothing: timeout, partial count kept
+    lines = run_harness(harness, srv.port, 300, 4096, 2)
+    assert [l[1:3] for l in lines if l[0] == "read"] == [[str(FMD_ERR_IO), "100"]]
+    srv = Server(lambda c: c.sendall(HS))
+    lines = run_harness(harness, srv.port, 2000, 0, 1)                                 # a zero-length read is a no-op, not a hang
+    assert [l[1:3] for l in lines if l[0] == "read"] == [["0", "0"]]
+
+
+def test_server_that_stops_reading_commands(harness):
+    """fmd_rtltcp_command against a peer whose receive window is full: the timeout applies to the send as well (ADVICE r3:
+    it used to block in send() forever)."""
+    def script(c):
+        c.setsockopt(socket.SOL_SOCKET, socket.SO_RCVBUF, 1024)
+        c.sendall(HS)
+        time.sleep(3.0)                                                                # never reads a command
+    srv = Server(script)
+    cmds = [(0x05, k) for k in range(60000)]                                           # 300 kB of commands into a closed window
+    env_cap = 60
+    t0 = time.time()
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=1", UBSAN_OPTIONS="halt_on_error=1")
+    p = subprocess.run([harness, str(srv.port), "300", "0", "0"] + [str(x) for c in cmds[:20000] for x in c], capture_output=True, text=True,
+                       timeout=env_cap, env=env)
+    assert p.returncode == 0 and not any(r in p.stderr for r in REPORT), p.stderr[-2000:]
+    sts = [l.split()[1] for l in p.stdout.splitlines() if l.startswith("cmd")]
+    assert sts and sts[0] == "0" and time.time() - t0 < 30
+    assert str(FMD_ERR_IO) in sts or len(sts) == 20000      # either the window filled and the timeout fired, or the kernel buffered it all

@@ -34,5 +34,7 @@ for r in range(3):
     ts.append(e0.elapsed_time(e1) / 100)
 ms = sorted(ts)[1]
 alg = nch * n + 2 * nch * k
-print(json.dumps({"decim": M, "noreuse": os.environ.get("FMD_FD_NOREUSE"), "reuse16": os.environ.get("FMD_FD_REUSE16"), "dbg": os.environ.get("FMD_DBG"), "kt": os.environ.get("FMD_FD_KT"), "tpb": os.environ.get("FMD_FD_TPB"), "ms": round(ms, 4), "GBps": round(alg / ms / 1e6, 1),
-                  "frac": round(alg / ms / 1e6 / 8000, 4), "tiling": bank.tiling(), "audio": k}))
+knobs = {k: v for k, v in os.environ.items() if k.startswith("FMD_FD_") or k == "FMD_DBG"}
+print(json.dumps({"decim": M, "knobs": knobs, "kernel": bank.kernel_name() if hasattr(bank, "kernel_name") else None, "ms": round(ms, 4),
+                  "ms_all": [round(t, 4) for t in ts], "GBps": round(alg / ms / 1e6, 1), "frac": round(alg / ms / 1e6 / 8000, 4),
+                  "tiling": bank.tiling(), "audio": k}))
