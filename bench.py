@@ -553,6 +553,8 @@ def main():
     if world != args.gpus:
         raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d: launch with --nproc-per-node equal to --gpus" % (args.gpus, world))
 
+    import faulthandler
+    faulthandler.enable()                                    # a rank that dies in native code leaves its Python stack on stderr
     import torch
     import rtl_sdr_rs_amd as fmd
 

@@ -313,7 +313,22 @@ int fmd_rtltcp_open(const char *host, uint16_t port, uint32_t timeout_ms, fmd_rt
 void fmd_rtltcp_close(fmd_rtltcp *s);
 int fmd_rtltcp_info(const fmd_rtltcp *s, uint32_t *tuner_type, uint32_t *gain_count);
 int fmd_rtltcp_read_sync(fmd_rtltcp *s, uint8_t *buf, size_t nbytes, size_t *n_read);
+/* read_sync for MANY sources behind one poll(): row c (row_stride bytes apart, the first nbytes of it) is filled from
+ * sources[c], n_read[c] = bytes written to it.  FMD_OK with n_read[c] < nbytes: that stream ended early; FMD_ERR_IO: a
+ * socket error, or no byte on any unfinished stream within the smallest timeout of the sources (n_read as far as it
+ * got).  The receive() loop of simple_fm.rs:100-132 for a bank of streams. */
+int fmd_rtltcp_read_many(fmd_rtltcp *const *sources, uint32_t n, uint8_t *base, size_t row_stride, size_t nbytes,
+                         size_t *n_read);
 int fmd_rtltcp_command(fmd_rtltcp *s, uint8_t opcode, uint32_t param);
+/* receive() (simple_fm.rs:89-132) for a bank of rtl_tcp streams, below the binding: acquire the next slot, fill row c from
+ * sources[c] (n_sources must equal the sink's n_channels; fmd_rtltcp_read_many: ONE poll() loop over all sockets) and
+ * submit it.  *n_short = sources that ended before their row was full: when > 0 the slot has been released unsubmitted
+ * and the run is over ("samples lost", :122-125) -- the sink stays usable, drain it to get what was submitted before.
+ * fmd_sink_pump_rtltcp repeats that until a short read or max_buffers (0 = no limit) and then drains;
+ * *n_submitted = buffers that went to the GPUs. */
+int fmd_sink_fill_from_rtltcp(fmd_sink *s, fmd_rtltcp *const *sources, uint32_t n_sources, uint32_t *n_short);
+int fmd_sink_pump_rtltcp(fmd_sink *s, fmd_rtltcp *const *sources, uint32_t n_sources, uint64_t max_buffers,
+                         uint64_t *n_submitted);
 
 /* ---- diagnostics ---------------------------------------------------------------------- */
 const char *fmd_strerror(int status);

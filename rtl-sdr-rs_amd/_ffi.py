@@ -117,6 +117,9 @@ PROTOTYPES = {
     "fmd_rtltcp_info": (C.c_int, [_vp, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
     "fmd_rtltcp_read_sync": (C.c_int, [_vp, _vp, _sz, _szp]),
     "fmd_rtltcp_command": (C.c_int, [_vp, C.c_uint8, C.c_uint32]),
+    "fmd_rtltcp_read_many": (C.c_int, [C.POINTER(C.c_void_p), C.c_uint32, C.c_void_p, C.c_size_t, C.c_size_t, _szp]),
+    "fmd_sink_fill_from_rtltcp": (C.c_int, [_vp, C.POINTER(C.c_void_p), C.c_uint32, C.POINTER(C.c_uint32)]),
+    "fmd_sink_pump_rtltcp": (C.c_int, [_vp, C.POINTER(C.c_void_p), C.c_uint32, C.c_uint64, C.POINTER(C.c_uint64)]),
 }
 
 SINK_CALLBACK = C.CFUNCTYPE(None, C.c_void_p, C.c_uint64, C.POINTER(C.c_int16), C.POINTER(C.c_size_t), C.c_size_t, C.c_int)

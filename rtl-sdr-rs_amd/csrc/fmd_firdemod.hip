@@ -411,7 +411,7 @@ __global__ void __launch_bounds__(kThreads, 8) fmd_firdemod_kernel(const FirDemo
 // Gone: the packed-sample array (4 bytes per output: the tile grows from 17 to 22 audio samples at 8 tiles per CU), its
 // stores and 4-way-conflicting reads, one barrier, the per-lane run bookkeeping of the second pass.
 template <int NKU, int NG>
-__global__ void __launch_bounds__(kThreads, 8) fmd_firdemod_reg_kernel(const FirDemodLaunch L)
+__global__ void __launch_bounds__(kThreads, NG <= 6 ? 8 : 6) fmd_firdemod_reg_kernel(const FirDemodLaunch L)
 {
     constexpr int PC = 4 * NG - 2;                           // outputs per column
     constexpr int WSTEP = 16 * PC - 1;                       // tile outputs from one wave's first column to the next wave's
@@ -502,7 +502,7 @@ __global__ void __launch_bounds__(kThreads, 8) fmd_firdemod_reg_kernel(const Fir
     const uint32_t tcol = wave * (uint32_t)WSTEP + j * (uint32_t)PC;     // tile output index of the column's first output
     fd_i4 acc[NG];
 #pragma unroll
-    for (int gi = 0; gi < NG; ++gi) acc[gi] = fd_i4{0, 0, 0, 0};
+    for (int gi = 0; gi < NG; ++gi) acc[gi] = fd_i4{0, 0, 0, 0};     // (all zero: the first matrix instruction takes the inline constant, no v_mov)
     {
         const uint8_t* col = reinterpret_cast<const uint8_t*>(lds) + 16u * tcol + 16u * q;   // decimate 8: 16 bytes per output
 #pragma unroll
@@ -516,24 +516,25 @@ __global__ void __launch_bounds__(kThreads, 8) fmd_firdemod_reg_kernel(const Fir
     }
     // lane (j, q) holds (re_lo, re_hi, im_lo, im_hi) of tile output tcol + 4 gi + q in acc[gi]: combine the tap digits, add
     // the window-parity constant, normalise -- and keep the components as exact f32 integers
-    const uint32_t par_tile = (L.par_first + o0 * L.half_M) & 1u;
-    const uint32_t par = (par_tile ^ (L.half_M * q)) & 1u;
-    const int cre = par ? L.mre[1] : L.mre[0], cim = par ? L.mim[1] : L.mim[0];
-    const uint32_t sgn = 0u - par_tile;                      // wave-uniform sign mask: (v ^ m) - m = m ? -v : v
+    // Decimate 8: every window starts at an even stream dword (4 o dwords from the call's first one, itself even), so the
+    // window parity is 0 for every output of every call: no sign flip of the matrix-core results (the general kernel
+    // negates them for odd parities) and one pair of additive constants (scalars).
+    const int cre = L.mre[0], cim = L.mim[0];
     float fr[NG], fi[NG];
-    int re_last = 0, im_last = 0;                            // integer components of the lane's last register (for demod_pre)
 #pragma unroll
     for (int gi = 0; gi < NG; ++gi) {
-        const uint32_t ure = (uint32_t)acc[gi].x + ((uint32_t)acc[gi].y << 7), uim = (uint32_t)acc[gi].z + ((uint32_t)acc[gi].w << 7);
-        const int re = ((int)((ure ^ sgn) - sgn) + cre) >> L.shift;          // floor(y / 2^shift)
-        const int im = ((int)((uim ^ sgn) - sgn) + cim) >> L.shift;
+        const int re = (int)((uint32_t)acc[gi].x + ((uint32_t)acc[gi].y << 7) + (uint32_t)cre) >> L.shift;     // floor(y / 2^shift)
+        const int im = (int)((uint32_t)acc[gi].z + ((uint32_t)acc[gi].w << 7) + (uint32_t)cim) >> L.shift;
         fr[gi] = (float)re; fi[gi] = (float)im;
-        if (last) {                                          // block-uniform: the output that becomes demod_pre
-            const uint32_t tt = tcol + 4u * (uint32_t)gi + q;
-            if (tt == no - 1u && (gi < NG - 1 || q < 2u)) { re_last = re; im_last = im; tail[0] = re; tail[1] = im; }
+    }
+    if (last) {                                              // block-uniform, one tile per channel: the output that becomes demod_pre
+        const int dl = (int)no - 1 - (int)(tcol + q);        // (tiles overlap by one output: two lanes may hold it, with the same value)
+        if (dl >= 0 && (dl & 3) == 0 && (dl >> 2) < (q < 2u ? NG : NG - 1)) {
+#pragma unroll
+            for (int gi = 0; gi < NG; ++gi)
+                if ((dl >> 2) == gi) { tail[0] = (int)fr[gi]; tail[1] = (int)fi[gi]; }
         }
     }
-    (void)re_last; (void)im_last;
     // predecessors: 16 lanes down (q - 1, same column); lane (j, 0) takes the previous register of lane (j, 3), and for its
     // first output the last output of column j - 1 (lane (j - 1, 1), register NG - 1: PC - 1 = 4 (NG - 1) + 1)
     const int down = (int)(((lane + 48u) & 63u) << 2);       // byte address of lane - 16 (mod 64)
@@ -547,6 +548,8 @@ __global__ void __launch_bounds__(kThreads, 8) fmd_firdemod_reg_kernel(const Fir
     const float xr = u2f((uint32_t)__builtin_amdgcn_ds_bpermute(left, (int)f2u(fr[NG - 1])));
     const float xi = u2f((uint32_t)__builtin_amdgcn_ds_bpermute(left, (int)f2u(fi[NG - 1])));
     const bool q0 = q == 0u;
+    // (every lane takes part in every move: ds_bpermute returns 0 for a source lane that is masked off, so the row-0 lanes
+    //  cannot fetch their previous-register values under an EXEC mask of their own -- they select instead)
     // ---- fm_demod (:355-367) per output, summed per audio group (:408-417) -------------------------------------------
     const uint32_t tmin = jfirst < 0 ? 0u : 1u;              // tile output 0 is only a predecessor (except at the call start)
     const uint32_t t_first = tcol + q;                       // the lane's first tile output; sample index m = o0 + t
@@ -555,6 +558,14 @@ __global__ void __launch_bounds__(kThreads, 8) fmd_firdemod_reg_kernel(const Fir
     const uint32_t kq = (uint32_t)fmd_sdiv_magic((int)(x0 + (uint32_t)(dm > 0 ? dm : 0) * r.sr), L.magic_fr);
     const uint32_t kqc = kq <= r.kt ? kq : r.kt;             // (lanes beyond the tile: any valid row)
     const int e_lo = gse[2u * kqc + 1u];
+    // the lane's outputs gi < g_hi lie inside the tile (and are real rows of the column: PC = 4 NG - 2), those gi < g_split in
+    // the first audio group; its output 0 is skipped where it is only a predecessor (the tile's first output away from the
+    // call start, the one output a wave shares with its predecessor)
+    const int g_max = q < 2u ? NG : NG - 1;
+    const int g_in = ((int)no - (int)t_first + 3) >> 2;
+    const int g_hi = g_in < g_max ? g_in : g_max;
+    const int g_split = ((e_lo - (int)(o0 + t_first)) >> 2) + 1;
+    const bool skip0 = q0 && j == 0u && (wave > 0u || tmin != 0u);
     int sum_all = 0, sum_lo = 0;
     int d_first = 0, cr0 = 0, ci0 = 0;
     bool any_guard = false;
@@ -563,7 +574,6 @@ __global__ void __launch_bounds__(kThreads, 8) fmd_firdemod_reg_kernel(const Fir
         const float br = q0 ? (gi == 0 ? xr : pr[gi - 1]) : pr[gi];
         const float bi = q0 ? (gi == 0 ? xi : pi[gi - 1]) : pi[gi];
         int d = disc_f32_c(fr[gi], fi[gi], br, bi);          // (:362); the value fits i16, `as i16` changes nothing
-        const uint32_t tt = t_first + 4u * (uint32_t)gi;
         if (gi == 0 && jfirst < 0 && tid == 0) {             // the first sample of the call takes the f64 path (:359) against demod_pre
             fmd_mul_conj((int)fr[0], (int)fi[0], st.demod_pre_re, st.demod_pre_im, cr0, ci0);
             bool g;
@@ -575,11 +585,9 @@ __global__ void __launch_bounds__(kThreads, 8) fmd_firdemod_reg_kernel(const Fir
             d = (int)(int16_t)d;
             d_first = d;
         }
-        // owned: inside the tile, not the tile's leading predecessor, not the overlap with the previous wave, a real row of the column
-        const bool own = tt >= tmin && tt < no && !(gi == 0 && q0 && j == 0u && wave > 0u) && (gi < NG - 1 || q < 2u);
-        const int dv = own ? d : 0;
+        const int dv = (gi < g_hi && !(gi == 0 && skip0)) ? d : 0;
         sum_all += dv;
-        sum_lo += (int)(o0 + tt) <= e_lo ? dv : 0;
+        sum_lo += gi < g_split ? dv : 0;
     }
     // (a lane whose outputs are all beyond the tile or not owned adds zeros: harmless)
     if (kq <= r.kt) atomicAdd(&gsum[kqc], sum_lo);
@@ -614,6 +622,10 @@ void launch(const FirDemodLaunch& L, dim3 g, size_t lds, hipStream_t s)
     if (L.reg_ng == 4u) hipLaunchKernelGGL((fmd_firdemod_reg_kernel<NKU, 4>), g, dim3(kThreads), lds, s, L);
     else if (L.reg_ng == 5u) hipLaunchKernelGGL((fmd_firdemod_reg_kernel<NKU, 5>), g, dim3(kThreads), lds, s, L);
     else if (L.reg_ng == 6u) hipLaunchKernelGGL((fmd_firdemod_reg_kernel<NKU, 6>), g, dim3(kThreads), lds, s, L);
+#ifdef FMD_EXPERIMENT
+    else if (L.reg_ng == 7u) hipLaunchKernelGGL((fmd_firdemod_reg_kernel<NKU, 7>), g, dim3(kThreads), lds, s, L);
+    else if (L.reg_ng == 8u) hipLaunchKernelGGL((fmd_firdemod_reg_kernel<NKU, 8>), g, dim3(kThreads), lds, s, L);
+#endif
     else if (L.reuse == 1u) hipLaunchKernelGGL((fmd_firdemod_kernel<NKU, 1>), g, dim3(kThreads), lds, s, L);
 #ifdef FMD_EXPERIMENT
     else if (L.reuse == 2u) hipLaunchKernelGGL((fmd_firdemod_kernel<NKU, 2>), g, dim3(kThreads), lds, s, L);   // FMD_FD_REUSE16: measured 4-6 % slower than the plain mapping
@@ -700,10 +712,15 @@ void fd_lanes(uint32_t fa, uint32_t kt, uint32_t* lg, uint32_t* magic, uint32_t*
 bool fd_sizes(const fmd_firdemod* f, uint32_t kt, uint32_t* lp_cap, uint32_t* raw_bytes, size_t* lds)
 {
     FmdRates r = f->r; r.kt = kt;
-    const uint32_t cap = fmd_tile_lp_cap(r);
+    uint32_t cap = fmd_tile_lp_cap(r);
     const uint32_t half_M = f->M / 2;
-    const uint64_t staged = (((((uint64_t)(cap - 1) * half_M + f->NP + 3) / 4) + 3) & ~(uint64_t)3) * 16;
-    if (f->reg_ng) {                                      // register form: no packed-sample array; the columns' operand reads bound the raw region
+    if (f->reg_ng) {
+        // Register form.  Its calls are tiled with the trailing partial audio group counted as a group (fd_enqueue: nt =
+        // K / kt + 1), so no tile holds more than kt groups -- at most ceil(kt fr / sr) discriminator samples + the
+        // predecessor -- where fmd_tile_lp_cap budgets a whole further group for the last tile: 22 instead of 20 audio
+        // samples per tile at BASELINE config 4.  No packed-sample array; the columns' operand reads bound the raw region.
+        cap = (uint32_t)(((uint64_t)kt * r.fr + r.sr - 1) / r.sr) + 3u;
+        const uint64_t staged = (((((uint64_t)(cap - 1) * half_M + f->NP + 3) / 4) + 3) & ~(uint64_t)3) * 16;
         const uint32_t pc = 4u * f->reg_ng - 2u;
         if (cap > 64u * pc - 3u) return false;
         const uint64_t touched = 16ull * (63u * pc - 3u) + 64ull * (f->plan.nku + f->reg_ng - 1u);
@@ -714,6 +731,7 @@ bool fd_sizes(const fmd_firdemod* f, uint32_t kt, uint32_t* lp_cap, uint32_t* ra
         return true;
     }
     if (cap > kMaxOutputs) return false;
+    const uint64_t staged = (((((uint64_t)(cap - 1) * half_M + f->NP + 3) / 4) + 3) & ~(uint64_t)3) * 16;
     const uint64_t touched = (uint64_t)16 * ((cap + 63) / 64) * (8u * f->M) + (uint64_t)64 * f->plan.n_pass * f->plan.nku;
     const uint64_t raw = ((staged > touched ? staged : touched) + 15) & ~(uint64_t)15;
     const uint64_t total = raw + 4ull * (cap + 1) + 12ull * (kt + 2) + 16;   // + group sums and the (first, last) table
@@ -738,7 +756,7 @@ int fd_enqueue(fmd_firdemod* f, const void* d_iq, size_t nbytes, void* d_out, si
     L.P = fmd_make_plan(r, 0u, f->i0r, 0u);
     L.P.M = (uint32_t)Mdec;
     L.P.K = fmd_num_audio(r, f->i0r, L.P.M);
-    L.P.nt = fmd_num_tiles(r, L.P.K);
+    L.P.nt = f->reg_ng ? L.P.K / r.kt + 1u : fmd_num_tiles(r, L.P.K);   // register form: the trailing partial group counts as a group (fd_sizes)
     if (L.P.K > out_cap) { fmd_internal_set_err("out_cap too small"); return FMD_ERR_CAPACITY; }
     L.iq = static_cast<const uint32_t*>(d_iq);
     L.stride_w = nbytes / 4;
@@ -874,7 +892,7 @@ int fmd_firdemod_new(const int16_t* taps, uint32_t n_taps, uint32_t decim, uint3
     f->reg_ng = 0;
     if (decim == 8u && f->plan.n_pass == 1u && f->lp_bound <= 2048u && !f->no_reuse && !f->int_disc) {
         const uint32_t ng = fmd_knob_u32("FMD_FD_REG", 5);
-        if (ng >= 4u && ng <= 6u && fa >= 4ull * ng && (uint64_t)r.sr * (64u * (4u * ng - 2u)) < (1u << 24)) f->reg_ng = ng;
+        if (ng >= 4u && ng <= 8u && fa >= 4ull * ng && (uint64_t)r.sr * (64u * (4u * ng - 2u)) < (1u << 24)) f->reg_ng = ng;
     }
     for (uint32_t kt = 1; kt <= 1024; ++kt) {
         if ((uint64_t)r.sr * (kt + 2) >= (1u << 24)) break;

@@ -26,6 +26,7 @@
 #include <cstdio>
 #include <cstring>
 #include <new>
+#include <vector>
 
 void fmd_internal_set_err(const char* msg);                  // thread-local text behind fmd_last_error() (fmd_api.cpp)
 
@@ -155,6 +156,43 @@ int fmd_rtltcp_read_sync(fmd_rtltcp* s, uint8_t* buf, size_t nbytes, size_t* n_r
     const long n = read_upto(s, buf, nbytes, n_read);       // on error *n_read = the bytes that did arrive
     if (n < 0) { err("read"); return FMD_ERR_IO; }
     *n_read = (size_t)n;                                     // < nbytes: the stream ended ("samples lost", simple_fm.rs:122)
+    return FMD_OK;
+}
+
+// receive() of the example (simple_fm.rs:100-132) for MANY streams at once: row c of a [n][row_stride] buffer is filled from
+// sources[c], all sockets behind ONE poll() -- every source is read as far as its bytes have arrived, so n slow streams cost
+// one wait, not n (n sequential blocking read_sync calls serialise the network latency of every stream).
+int fmd_rtltcp_read_many(fmd_rtltcp* const* sources, uint32_t n, uint8_t* base, size_t row_stride, size_t nbytes, size_t* n_read)
+{
+    if (!sources || !base || !n_read || n == 0 || row_stride < nbytes) { fmd_internal_set_err("bad argument"); return FMD_ERR_INVALID_ARG; }
+    int timeout_ms = INT_MAX;
+    for (uint32_t c = 0; c < n; ++c) {
+        if (!sources[c]) { fmd_internal_set_err("null source"); return FMD_ERR_INVALID_ARG; }
+        n_read[c] = 0;
+        if (sources[c]->timeout_ms < timeout_ms) timeout_ms = sources[c]->timeout_ms;
+    }
+    if (nbytes == 0) return FMD_OK;
+    std::vector<struct pollfd> pf(n);
+    std::vector<uint32_t> who(n);
+    std::vector<uint8_t> done(n, 0);                         // 1: row full, 2: stream ended early
+    uint32_t open_rows = n;
+    while (open_rows) {
+        nfds_t m = 0;
+        for (uint32_t c = 0; c < n; ++c)
+            if (!done[c]) { pf[m].fd = sources[c]->fd; pf[m].events = POLLIN; pf[m].revents = 0; who[m] = c; ++m; }
+        const int r = poll(pf.data(), m, timeout_ms);
+        if (r < 0) { if (errno == EINTR) continue; err("poll"); return FMD_ERR_IO; }
+        if (r == 0) { errno = ETIMEDOUT; err("read"); return FMD_ERR_IO; }   // no byte on ANY open stream for a whole timeout
+        for (nfds_t k = 0; k < m; ++k) {
+            if (!(pf[k].revents & (POLLIN | POLLHUP | POLLERR))) continue;
+            const uint32_t c = who[k];
+            const ssize_t g = recv(pf[k].fd, base + (size_t)c * row_stride + n_read[c], nbytes - n_read[c], MSG_DONTWAIT);
+            if (g < 0) { if (errno == EINTR || errno == EAGAIN || errno == EWOULDBLOCK) continue; err("read"); return FMD_ERR_IO; }
+            if (g == 0) { done[c] = 2; --open_rows; continue; }          // orderly end of this stream: "samples lost" for the caller
+            n_read[c] += (size_t)g;
+            if (n_read[c] == nbytes) { done[c] = 1; --open_rows; }
+        }
+    }
     return FMD_OK;
 }
 

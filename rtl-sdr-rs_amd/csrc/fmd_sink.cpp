@@ -239,6 +239,42 @@ int fmd_sink_acquire(fmd_sink* s, uint8_t** iq)
     return FMD_OK;
 }
 
+// receive() (simple_fm.rs:89-132) for a bank of rtl_tcp streams: one slot per call, all sockets behind one poll().
+int fmd_sink_fill_from_rtltcp(fmd_sink* s, fmd_rtltcp* const* sources, uint32_t n_sources, uint32_t* n_short)
+{
+    if (!s || !sources || !n_short) { fmd_internal_set_err("null argument"); return FMD_ERR_INVALID_ARG; }
+    *n_short = 0;
+    if (n_sources != s->C) { fmd_internal_set_err("one rtl_tcp source per channel of the sink"); return FMD_ERR_INVALID_ARG; }
+    uint8_t* iq = nullptr;
+    int rc = fmd_sink_acquire(s, &iq);
+    if (rc != FMD_OK) return rc;
+    std::vector<size_t> got(n_sources, 0);
+    rc = fmd_rtltcp_read_many(sources, n_sources, iq, s->nbytes, s->nbytes, got.data());
+    uint32_t shorts = 0;
+    for (uint32_t c = 0; c < n_sources; ++c) shorts += got[c] < s->nbytes ? 1u : 0u;
+    if (rc != FMD_OK || shorts) {                            // socket error / timeout, or "samples lost": nothing is submitted
+        (void)fmd_sink_release(s);
+        *n_short = shorts;
+        return rc;
+    }
+    return fmd_sink_submit(s);
+}
+
+int fmd_sink_pump_rtltcp(fmd_sink* s, fmd_rtltcp* const* sources, uint32_t n_sources, uint64_t max_buffers, uint64_t* n_submitted)
+{
+    if (!n_submitted) { fmd_internal_set_err("null argument"); return FMD_ERR_INVALID_ARG; }
+    *n_submitted = 0;
+    int rc = FMD_OK;
+    while (max_buffers == 0 || *n_submitted < max_buffers) {
+        uint32_t shorts = 0;
+        rc = fmd_sink_fill_from_rtltcp(s, sources, n_sources, &shorts);
+        if (rc != FMD_OK || shorts) break;
+        *n_submitted += 1;
+    }
+    const int rd = fmd_sink_drain(s);                        // everything submitted is delivered, also after an error
+    return rc != FMD_OK ? rc : rd;
+}
+
 // Give an acquired slot back without submitting it (a short read ends the run, simple_fm.rs:122-125): the sink stays usable.
 int fmd_sink_release(fmd_sink* s)
 {

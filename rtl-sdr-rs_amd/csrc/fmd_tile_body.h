@@ -236,11 +236,8 @@ __device__ __forceinline__ void masked_rounds(const uint32_t* __restrict__ raw_w
         const uint32_t pk1 = pack_lp_perm(re1, im1), pk2 = pack_lp_perm(re2, im2);
         const uint32_t prev1 = wave_shr1(pk1);
         const uint32_t prev2 = wave_shr1_old(wave_ror1(pk1), pk2);
-        int d1, d2;
-        if (smallD) { d1 = disc_f32(pk1, prev1); d2 = disc_f32(pk2, prev2); }             // wave-uniform
-        else { d1 = disc_nosel(pk1, prev1); d2 = disc_nosel(pk2, prev2); }
-        if (lane > 0 && i1 < cnt) d16[i1] = (int16_t)d1;
-        if (i2 < cnt) d16[i2] = (int16_t)d2;
+        if (lane > 0 && i1 < cnt) d16[i1] = (int16_t)(smallD ? disc_f32(pk1, prev1) : disc_nosel(pk1, prev1));   // smallD: wave-uniform
+        if (i2 < cnt) d16[i2] = (int16_t)(smallD ? disc_f32(pk2, prev2) : disc_nosel(pk2, prev2));
     }
 }
 
@@ -326,10 +323,10 @@ __device__ __forceinline__ void stream_pair_rounds(const unsigned char* __restri
         }
         const float ar1 = (float)re1, ai1 = (float)im1, ar2 = (float)re2, ai2 = (float)im2;
         const float br1 = u2f(wave_shr1_dead(dead1, f2u(ar2))), bi1 = u2f(wave_shr1_dead(dead2, f2u(ai2)));   // second window of lane l - 1
-        const int d1 = disc_f32_c<DH == 1>(ar1, ai1, br1, bi1);
-        const int d2 = disc_f32_c<DH == 1>(ar2, ai2, ar1, ai1);
-        if (lane > 0 && i1 < cnt) d16[i1] = (int16_t)d1;
-        if (i2 < cnt) d16[i2] = (int16_t)d2;
+        // (the discriminators sit INSIDE the predicated stores: two separately masked instruction streams, the form hipcc
+        //  built by itself while the conversion at their end was a plain cast it could sink -- and the faster one)
+        if (lane > 0 && i1 < cnt) d16[i1] = (int16_t)disc_f32_c<DH == 1>(ar1, ai1, br1, bi1);
+        if (i2 < cnt) d16[i2] = (int16_t)disc_f32_c<DH == 1>(ar2, ai2, ar1, ai1);
     };
     // Straight-line code for up to FMD_STREAM_MAX_ROUNDS rounds per wave (the host sizes the tiles accordingly): in a
     // loop hipcc's wait-count pass gives up at the back edge and waits for EVERY outstanding load (vmcnt(0)) once per trip,
@@ -445,10 +442,10 @@ __device__ __forceinline__ void tile_body(const FmdLaunch& L, const TileCtx& X, 
             }
             const float ar1 = (float)re1, ai1 = (float)im1, ar2 = (float)re2, ai2 = (float)im2;
             const float br1 = u2f(wave_shr1_dead(dead1, f2u(ar2))), bi1 = u2f(wave_shr1_dead(dead2, f2u(ai2)));   // second window of lane l - 1
-            const int d1 = disc_f32_c<DH == 1>(ar1, ai1, br1, bi1);   // (:362); DH == 1 is downsample 2: no i32 wrap to emulate
-            const int d2 = disc_f32_c<DH == 1>(ar2, ai2, ar1, ai1);
-            if (lane > 0 && i1 < cnt) d16[i1] = (int16_t)d1;
-            if (i2 < cnt) d16[i2] = (int16_t)d2;
+            // (:362); DH == 1 is downsample 2: no i32 wrap to emulate.  The discriminators sit INSIDE the predicated stores
+            // (see stream_pair_rounds)
+            if (lane > 0 && i1 < cnt) d16[i1] = (int16_t)disc_f32_c<DH == 1>(ar1, ai1, br1, bi1);
+            if (i2 < cnt) d16[i2] = (int16_t)disc_f32_c<DH == 1>(ar2, ai2, ar1, ai1);
         }
     } else if (fastwin) {
         // Hot loop: no branches, no special cases.  Lanes whose window lies outside the tile (the two
@@ -474,14 +471,12 @@ __device__ __forceinline__ void tile_body(const FmdLaunch& L, const TileCtx& X, 
             const uint32_t pk1 = pack_lp_perm(re1, im1), pk2 = pack_lp_perm(re2, im2);
             const uint32_t prev1 = wave_shr1(pk1);           // lane l <- first window of lane l-1
             const uint32_t prev2 = wave_shr1_old(wave_ror1(pk1), pk2);   // lane l <- second of l-1; lane 0 <- first of 63
-            int d1, d2;
-            if (FMD_ABLATE(0)) { d1 = (int)(pk1 ^ prev1); d2 = (int)(pk2 ^ prev2); }    // ablation: no discriminator
-            else { d1 = disc_f32(pk1, prev1); d2 = disc_f32(pk2, prev2); }   // (:362); whole-dword windows: downsample <= 14 (<= FMD_DISC_F32_MAX_D)
             // (Measured and rejected in round 2: storing the full rounds without predication -- lane 0 to a dummy slot --
             //  so that both discriminators run as one interleaved stream: +2 % at downsample 6 / 10, +7 % at 7.  The
             //  two separately masked regions the compiler builds here are the faster form.)
-            if (lane > 0 && i1 < cnt) d16[i1] = (int16_t)d1;
-            if (i2 < cnt) d16[i2] = (int16_t)d2;
+            // (:362); whole-dword windows: downsample <= 14 (<= FMD_DISC_F32_MAX_D)
+            if (lane > 0 && i1 < cnt) d16[i1] = (int16_t)(FMD_ABLATE(0) ? (int)(pk1 ^ prev1) : disc_f32(pk1, prev1));
+            if (i2 < cnt) d16[i2] = (int16_t)(FMD_ABLATE(0) ? (int)(pk2 ^ prev2) : disc_f32(pk2, prev2));
         }
     } else {
         // Any downsample, any phase: a window of D samples starting at call sample s covers the dwords
@@ -554,11 +549,8 @@ __device__ __forceinline__ void tile_body(const FmdLaunch& L, const TileCtx& X, 
                 const uint32_t pk1 = pack_lp_perm(re1, im1), pk2 = pack_lp_perm(re2, im2);
                 const uint32_t prev1 = wave_shr1(pk1);
                 const uint32_t prev2 = wave_shr1_old(wave_ror1(pk1), pk2);
-                int d1, d2;                                                              // rotate: downsample 8, 12, 16, 20, ...
-                if (smallD) { d1 = disc_f32(pk1, prev1); d2 = disc_f32(pk2, prev2); }   // wave-uniform
-                else { d1 = disc_nosel(pk1, prev1); d2 = disc_nosel(pk2, prev2); }
-                if (lane > 0 && i1 < cnt) d16[i1] = (int16_t)d1;
-                if (i2 < cnt) d16[i2] = (int16_t)d2;
+                if (lane > 0 && i1 < cnt) d16[i1] = (int16_t)(smallD ? disc_f32(pk1, prev1) : disc_nosel(pk1, prev1));   // smallD: wave-uniform
+                if (i2 < cnt) d16[i2] = (int16_t)(smallD ? disc_f32(pk2, prev2) : disc_nosel(pk2, prev2));
                 continue;
             }
             uint32_t wa = pa[0] ^ 0x80808080u, wb = pb[0] ^ 0x80808080u;                 // u8 -> s8 (b - 128)
@@ -587,11 +579,8 @@ __device__ __forceinline__ void tile_body(const FmdLaunch& L, const TileCtx& X, 
             const uint32_t pk1 = pack_lp_perm(re1, im1), pk2 = pack_lp_perm(re2, im2);
             const uint32_t prev1 = wave_shr1(pk1);
             const uint32_t prev2 = wave_shr1_old(wave_ror1(pk1), pk2);
-            int d1, d2;
-            if (smallD) { d1 = disc_f32(pk1, prev1); d2 = disc_f32(pk2, prev2); }       // wave-uniform
-            else { d1 = disc_nosel(pk1, prev1); d2 = disc_nosel(pk2, prev2); }
-            if (lane > 0 && i1 < cnt) d16[i1] = (int16_t)d1;
-            if (i2 < cnt) d16[i2] = (int16_t)d2;
+            if (lane > 0 && i1 < cnt) d16[i1] = (int16_t)(smallD ? disc_f32(pk1, prev1) : disc_nosel(pk1, prev1));   // smallD: wave-uniform
+            if (i2 < cnt) d16[i2] = (int16_t)(smallD ? disc_f32(pk2, prev2) : disc_nosel(pk2, prev2));
         }
     }
     // Call start (at most once per channel-call, one lane): lp[-1] is demod_pre, lp[0] is the clipped first

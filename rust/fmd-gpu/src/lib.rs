@@ -143,6 +143,9 @@ extern "C" {
     pub fn fmd_rtltcp_info(s: *const fmd_rtltcp, tuner_type: *mut u32, gain_count: *mut u32) -> c_int;
     pub fn fmd_rtltcp_read_sync(s: *mut fmd_rtltcp, buf: *mut u8, nbytes: usize, n_read: *mut usize) -> c_int;
     pub fn fmd_rtltcp_command(s: *mut fmd_rtltcp, opcode: u8, param: u32) -> c_int;
+    pub fn fmd_rtltcp_read_many(sources: *const *mut fmd_rtltcp, n: u32, base: *mut u8, row_stride: usize, nbytes: usize, n_read: *mut usize) -> c_int;
+    pub fn fmd_sink_fill_from_rtltcp(s: *mut fmd_sink, sources: *const *mut fmd_rtltcp, n_sources: u32, n_short: *mut u32) -> c_int;
+    pub fn fmd_sink_pump_rtltcp(s: *mut fmd_sink, sources: *const *mut fmd_rtltcp, n_sources: u32, max_buffers: u64, n_submitted: *mut u64) -> c_int;
 }
 
 /// Error in the crate's convention (`src/error.rs:8,40-44`: a Result, never a panic).

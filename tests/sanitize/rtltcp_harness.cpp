@@ -4,6 +4,8 @@
 // (the error-text sink of fmd_last_error) and prints what every call returned, one line each:
 //   open <status> [tuner gains]      read <status> <n_read> <sum of the bytes>      cmd <status>
 // usage: rtltcp_harness <port> <timeout_ms> <nbytes per read> <reads> [<opcode> <param>]...
+//        rtltcp_harness many <timeout_ms> <nbytes per row> <reads> <port>...      (fmd_rtltcp_read_many over all the ports:
+//                       many <status> <rows full> <rows short> <sum of all bytes read>)
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
@@ -15,9 +17,35 @@
 static std::string g_err;
 void fmd_internal_set_err(const char* msg) { g_err = msg ? msg : ""; }
 
+static int many(int argc, char** argv)
+{
+    const uint32_t timeout_ms = (uint32_t)strtoul(argv[2], nullptr, 10);
+    const size_t nbytes = (size_t)strtoul(argv[3], nullptr, 10);
+    const int reads = atoi(argv[4]);
+    const uint32_t n = (uint32_t)(argc - 5);
+    std::vector<fmd_rtltcp*> src(n, nullptr);
+    for (uint32_t c = 0; c < n; ++c)
+        if (fmd_rtltcp_open("127.0.0.1", (uint16_t)atoi(argv[5 + c]), timeout_ms, &src[c]) != FMD_OK) { printf("open %u failed %s\n", c, g_err.c_str()); return 0; }
+    std::vector<uint8_t> buf((size_t)n * nbytes);           // rows exactly nbytes apart: a row that overran would hit its neighbour / the end
+    std::vector<size_t> got(n);
+    for (int r = 0; r < reads; ++r) {
+        const int st = fmd_rtltcp_read_many(src.data(), n, buf.data(), nbytes, nbytes, got.data());
+        unsigned long sum = 0; uint32_t full = 0, shorts = 0;
+        for (uint32_t c = 0; c < n; ++c) {
+            for (size_t k = 0; k < got[c]; ++k) sum += buf[(size_t)c * nbytes + k];
+            if (got[c] == nbytes) ++full; else ++shorts;
+        }
+        printf("many %d %u %u %lu\n", st, full, shorts, sum);
+        if (st != FMD_OK || shorts) break;
+    }
+    for (uint32_t c = 0; c < n; ++c) fmd_rtltcp_close(src[c]);
+    return 0;
+}
+
 int main(int argc, char** argv)
 {
     if (argc < 5) return 2;
+    if (std::string(argv[1]) == "many") return many(argc, argv);
     const uint16_t port = (uint16_t)atoi(argv[1]);
     const uint32_t timeout_ms = (uint32_t)strtoul(argv[2], nullptr, 10);
     const size_t nbytes = (size_t)strtoul(argv[3], nullptr, 10);

@@ -19,10 +19,10 @@ HDR = os.path.join(ROOT, "include", "fmd.h")
 PKG = os.path.join(ROOT, "rtl-sdr-rs_amd")
 
 
-def build_consumer(tmp_path):
-    exe = str(tmp_path / "c_abi_smoke")
+def build_consumer(tmp_path, name="c_abi_smoke"):
+    exe = str(tmp_path / name)
     cmd = ["gcc", "-std=c11", "-pedantic", "-Wall", "-Wextra", "-Werror", "-I", os.path.join(ROOT, "include"),
-           os.path.join(ROOT, "tests", "c_abi_smoke.c"), "-o", exe, "-L", PKG, "-lfmd_hip", "-Wl,-rpath," + PKG]
+           os.path.join(ROOT, "tests", name + ".c"), "-o", exe, "-L", PKG, "-lfmd_hip", "-Wl,-rpath," + PKG]
     p = subprocess.run(cmd, capture_output=True)
     assert p.returncode == 0, p.stderr.decode()
     return exe
@@ -37,6 +37,7 @@ def test_header_is_plain_c11_and_links(tmp_path, fmd):
     assert p.returncode == 0, p.stderr.decode()
     assert subprocess.run([str(tmp_path / "hdr_only")]).returncode == 0     # five u32 fields, no padding
     build_consumer(tmp_path)
+    build_consumer(tmp_path, "c_abi_pump")
 
 
 # ---- Rust shim vs header ------------------------------------------------------------------------------------------
@@ -156,3 +157,35 @@ def test_c_consumer_reads_its_iq_from_an_rtl_tcp_server(tmp_path, fmd, oracle):
     exp, _ = oracle.demodulate_stream(ocfg, iq[:2 * n], n)
     assert np.array_equal(np.fromfile(str(tmp_path / "audio.s16"), dtype=np.int16), exp)
     assert (rts.CMD_SET_FREQUENCY, 95_155_000) in srv.commands and (rts.CMD_SET_SAMPLE_RATE, 1_020_000) in srv.commands
+
+
+@pytest.mark.gpu
+def test_c_pump_feeds_64_rtl_tcp_streams_through_the_sink(tmp_path, fmd, oracle):
+    """receive() for MANY sources below the binding: a plain-C program opens 64 rtl_tcp sources and calls
+    fmd_sink_pump_rtltcp -- one poll() loop fills every slot's 64 rows, submit, repeat until the streams run short -- and
+    every delivered buffer of every channel equals the oracle fed that channel's bytes (simple_fm.rs:89-170)."""
+    import struct
+    from test_rtl_tcp_source import FakeServer
+    exe = build_consumer(tmp_path, "c_abi_pump")
+    nsrc, nbytes, nbuf = 64, 32768, 3
+    iq = fmd.synth.synth_iq(nsrc, nbuf * nbytes + 1000, seed=0xC64, amplitude=100)     # 3 whole buffers + a short tail each
+    servers = [FakeServer(iq[c].tobytes()) for c in range(nsrc)]
+    p = subprocess.run([exe, str(tmp_path / "out.bin"), str(nbytes)] + [str(s.port) for s in servers], capture_output=True, timeout=600)
+    assert p.returncode == 0, p.stderr.decode()[-2000:]
+    assert p.stdout.decode().strip() == "submitted %d" % nbuf
+    _, ocfg = oracle.optimal_settings(94_900_000, 170_000)
+    exp = [oracle.demodulate_stream(ocfg, iq[c, :nbuf * nbytes], nbytes)[0] for c in range(nsrc)]
+    raw = (tmp_path / "out.bin").read_bytes()
+    off, got, seqs = 0, [[] for _ in range(nsrc)], []
+    while off < len(raw):
+        seq, nch = struct.unpack_from("<QI", raw, off); off += 12
+        assert nch == nsrc
+        seqs.append(seq)
+        for c in range(nsrc):
+            (n,) = struct.unpack_from("<I", raw, off); off += 4
+            got[c].append(np.frombuffer(raw, dtype=np.int16, count=n, offset=off)); off += 2 * n
+    assert seqs == list(range(nbuf))
+    for c in range(nsrc):
+        assert np.array_equal(np.concatenate(got[c]), exp[c]), c
+    for s in servers:
+        s.thread.join(timeout=5)

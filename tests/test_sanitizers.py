@@ -189,3 +189,42 @@ def test_server_that_stops_reading_commands(harness):
     sts = [l.split()[1] for l in p.stdout.splitlines() if l.startswith("cmd")]
     assert sts and sts[0] == "0" and time.time() - t0 < 30
     assert str(FMD_ERR_IO) in sts or len(sts) == 20000      # either the window filled and the timeout fired, or the kernel buffered it all
+
+
+def test_read_many_64_streams_one_poll_loop(harness):
+    """fmd_rtltcp_read_many under the sanitizers: 64 servers dribbling their rows at different paces into ONE poll() loop,
+    two whole rounds, then a third in which three streams end early (rows short, status OK) -- the bytes of every row land
+    in that row and nowhere else (the checksum) -- and a stream that is RESET mid-row (FMD_ERR_IO)."""
+    nsrc, nbytes = 64, 6000
+    payloads = [bytes((c * 31 + k * 7) & 0xFF for k in range(3 * nbytes)) for c in range(nsrc)]
+    cut = {5: 2 * nbytes + 100, 17: 2 * nbytes, 63: 3 * nbytes - 1}                 # streams that end early in round three
+
+    def make(c):
+        def script(conn):
+            conn.sendall(HS)
+            data = payloads[c][:cut.get(c, 3 * nbytes)]
+            step = 700 + 97 * c                                                     # every stream its own piece size
+            for k in range(0, len(data), step):
+                conn.sendall(data[k:k + step])
+                if c % 7 == 0:
+                    time.sleep(0.002)
+            time.sleep(0.5)                                                         # the others finish their rows first
+        return script
+    servers = [Server(make(c)) for c in range(nsrc)]
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=1", UBSAN_OPTIONS="print_stacktrace=1:halt_on_error=1")
+    p = subprocess.run([harness, "many", "3000", str(nbytes), "3"] + [str(s.port) for s in servers], capture_output=True, text=True, timeout=120, env=env)
+    assert p.returncode == 0 and not any(r in p.stderr for r in REPORT), p.stderr[-3000:]
+    lines = [l.split() for l in p.stdout.splitlines() if l.startswith("many")]
+    sums = [sum(sum(payloads[c][r * nbytes:min((r + 1) * nbytes, cut.get(c, 3 * nbytes))]) for c in range(nsrc)) for r in range(3)]
+    assert lines[0] == ["many", "0", "64", "0", str(sums[0])] and lines[1] == ["many", "0", "64", "0", str(sums[1])], lines
+    assert lines[2] == ["many", "0", "61", "3", str(sums[2])], lines
+
+    def rst(conn):
+        conn.sendall(HS + bytes(100))
+        time.sleep(0.2)
+        rst_close(conn)
+    servers = [Server(rst), Server(lambda c: (c.sendall(HS + bytes(4000)), time.sleep(1.0)))]
+    p = subprocess.run([harness, "many", "3000", "4000", "1"] + [str(s.port) for s in servers], capture_output=True, text=True, timeout=60, env=env)
+    assert p.returncode == 0 and not any(r in p.stderr for r in REPORT), p.stderr[-3000:]
+    st = [l.split() for l in p.stdout.splitlines() if l.startswith("many")][0]
+    assert st[1] in (str(FMD_ERR_IO), "0") and int(st[2]) <= 1          # the reset row never completes (RST may surface as an error or as an early end)
