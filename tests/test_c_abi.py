@@ -53,17 +53,21 @@ def strip_c(src):
 
 
 def c_type_to_rust(t):
-    t = t.strip()
-    const = "const " in (t + " ")
-    t = t.replace("const", "").strip()
-    stars = t.count("*")
-    base = t.replace("*", "").strip()
-    base = STRUCTS.get(base, C2R.get(base, base))             # opaque handles keep their name
-    if stars == 0:
-        return base
-    out = base
-    for i in range(stars):
-        out = ("*const " if (const and i == 0) else "*mut ") + out
+    """`const T *`, `T *const *` ...: a pointer level is *const when what it points TO is const-qualified -- the base type for
+    the first `*`, the previous pointer (a `const` written after its `*`) for the next."""
+    toks = re.findall(r"\*|\w+", t)
+    base_toks = [x for x in toks[:toks.index("*")] if x != "const"] if "*" in toks else [x for x in toks if x != "const"]
+    base = " ".join(base_toks)
+    out = STRUCTS.get(base, C2R.get(base, base))              # opaque handles keep their name
+    if "*" not in toks:
+        return out
+    pointee_const = "const" in toks[:toks.index("*")]
+    i = toks.index("*")
+    while i < len(toks):
+        assert toks[i] == "*", t
+        out = ("*const " if pointee_const else "*mut ") + out
+        pointee_const = i + 1 < len(toks) and toks[i + 1] == "const"
+        i += 2 if pointee_const else 1
     return out
 
 
