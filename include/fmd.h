@@ -91,7 +91,11 @@ int fmd_optimal_settings(uint32_t freq, uint32_t rate, uint32_t rate_resample,
 /* ---- lifecycle ------------------------------------------------------------------------ */
 
 /* Demod::new(config), simple_fm.rs:243-252, for a bank of n_channels independent streams,
- * all with zeroed state. */
+ * all with zeroed state.  downsample 1 ... 512 (FMD_ERR_UNSUPPORTED beyond).  From 129 up the
+ * reference's own i32 arithmetic wraps at full-scale input (reproduced bit for bit); where a
+ * release build of the reference would PANIC -- a zero divisor inside fast_atan2 after such a
+ * wrap, reachable from downsample 305 with particular full-scale inputs -- the audio sample
+ * that contains the discriminator value is unspecified (no status is raised). */
 int fmd_demod_new(const fmd_demod_config *config, const fmd_device_config *dev, fmd_demod **out);
 
 /* Drop for Demod. NULL is a no-op. */
@@ -281,6 +285,8 @@ int fmd_sink_release(fmd_sink *s);
 int fmd_sink_poll(fmd_sink *s);     /* deliver what has finished; returns the number of buffers delivered or < 0 */
 int fmd_sink_drain(fmd_sink *s);    /* wait for and deliver everything in flight */
 int fmd_sink_info(const fmd_sink *s, size_t *out_cap, uint32_t *n_devices, uint32_t *in_flight);
+/* f64 samples that fell into the guard band / that the host libm corrected, summed over the device parts (fmd_demod_f64_stats). */
+int fmd_sink_f64_stats(const fmd_sink *s, uint64_t *guarded, uint64_t *patched);
 
 /* ---- rtl_tcp client-side IQ source ---------------------------------------------------- */
 /* The reference ships the rtl_tcp SERVER (examples/rtl_tcp.rs); this is the matching client, so that a dongle on another

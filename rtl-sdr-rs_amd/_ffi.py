@@ -112,6 +112,7 @@ PROTOTYPES = {
     "fmd_sink_poll": (C.c_int, [_vp]),
     "fmd_sink_drain": (C.c_int, [_vp]),
     "fmd_sink_info": (C.c_int, [_vp, _szp, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
+    "fmd_sink_f64_stats": (C.c_int, [_vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "fmd_rtltcp_open": (C.c_int, [C.c_char_p, C.c_uint16, C.c_uint32, C.POINTER(_vp)]),
     "fmd_rtltcp_close": (None, [_vp]),
     "fmd_rtltcp_info": (C.c_int, [_vp, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),

@@ -740,7 +740,9 @@ int fmd_demod_set_state(fmd_demod* d, uint32_t channel, const fmd_demod_state* s
     if (!d || !state || channel >= d->C) { set_err("bad argument"); return FMD_ERR_INVALID_ARG; }
     const FmdRates& r = d->r;
     const int64_t lim_lp = 128ll * state->prev_index, lim_pre = 128ll * r.D;
-    const int64_t lim_lpr = 16384ll * ((r.fr + r.sr - 1) / r.sr);
+    // |d| <= 16384 per discriminator sample -- except beyond downsample 128, where the reference's i32 products wrap and
+    // `pcm as i16` (simple_fm.rs:362) can be anything in +-32768: a state the handle itself produced must be restorable
+    const int64_t lim_lpr = (r.D > FMD_MAX_DOWNSAMPLE ? 32768ll : 16384ll) * ((r.fr + r.sr - 1) / r.sr);
     auto within = [](int64_t v, int64_t lim) { return v >= -lim && v <= lim; };
     if (state->prev_index >= r.D || state->prev_lpr_index < 0 || (uint32_t)state->prev_lpr_index >= r.fast ||
         (uint32_t)state->prev_lpr_index % r.g != 0 || !within(state->lp_now_re, lim_lp) ||

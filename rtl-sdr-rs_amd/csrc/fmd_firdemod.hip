@@ -57,7 +57,21 @@ typedef int fd_i4 __attribute__((ext_vector_type(4)));
 struct FdRow { int32_t jA, jB; uint32_t eq, er, x0; };
 constexpr uint32_t kFdRows = 160;                               // 3.2 KB of the 4 KB of kernel arguments
 
+// What a fresh block of fmd_firdemod_reg_kernel needs before its LDS-DMAs can go out, in the FIRST 64 bytes of the kernel
+// arguments (one s_load_dwordx16, issued together with the tile's row): a block holds its LDS from dispatch to exit, so a chain
+// of dependent scalar loads in front of the first DMA is idle LDS (the boxcar kernel's FmdFastGeo, fmd_kernels.h: -5 % there).
+struct FdHot {
+    uint64_t iq;               // device address of the input
+    uint64_t stride_w;         // dwords per channel in this call
+    uint64_t amat;             // device address of the tap fragments
+    uint32_t n_channels, nt, kt;
+    uint32_t Hw, NP, half_M, wd_first;
+    uint32_t raw_bytes, use_rows, pad;
+};
+static_assert(sizeof(FdHot) == 64, "one s_load_dwordx16");
+
 struct FirDemodLaunch {
+    FdHot hot;                 // (must stay the first member)
     // ---- FIR (same meaning as FirLaunch in fmd_fir.hip) ----
     const uint32_t* iq;        // [C][stride_w] dwords
     uint64_t stride_w;         // dwords per channel in this call
@@ -410,8 +424,8 @@ __global__ void __launch_bounds__(kThreads, 8) fmd_firdemod_kernel(const FirDemo
 //     kernel above) and adds the two partial sums to the groups' accumulators in LDS.
 // Gone: the packed-sample array (4 bytes per output: the tile grows from 17 to 22 audio samples at 8 tiles per CU), its
 // stores and 4-way-conflicting reads, one barrier, the per-lane run bookkeeping of the second pass.
-template <int NKU, int NG>
-__global__ void __launch_bounds__(kThreads, NG <= 6 ? 8 : 6) fmd_firdemod_reg_kernel(const FirDemodLaunch L)
+template <int NKU, int NG, bool ROWS>
+__global__ void __launch_bounds__(kThreads, NG <= 6 ? 8 : (NG <= 8 ? 5 : 3)) fmd_firdemod_reg_kernel(const FirDemodLaunch L)
 {
     constexpr int PC = 4 * NG - 2;                           // outputs per column
     constexpr int WSTEP = 16 * PC - 1;                       // tile outputs from one wave's first column to the next wave's
@@ -419,49 +433,52 @@ __global__ void __launch_bounds__(kThreads, NG <= 6 ? 8 : 6) fmd_firdemod_reg_ke
     const uint32_t tid = threadIdx.x, lane = tid & 63u;
     const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid >> 6));
     __builtin_amdgcn_s_setprio(3);                           // get the loads out first (see fmd_tile_body.h)
-    uint32_t c, t;
-    if (L.xcd == 3u) { c = blockIdx.x * gridDim.z + blockIdx.z; t = blockIdx.y; }   // grid (8, tiles, ceil(C / 8))
-    else { c = blockIdx.y + 65535u * blockIdx.z; t = blockIdx.x; }
-    if (c >= L.n_channels || t >= L.P.nt) return;
-
+    // grid (8, tiles, ceil(C / 8)) always: blockIdx.x IS the XCD, which works through its own contiguous eighth of the channels
+    // (fewer than 8 channels: the surplus blocks exit at once)
+    // No branch in front of the LDS-DMAs: hipcc issues a block's scalar loads where they are used and waits for each batch
+    // before the next branch, so every early exit in front of the staging is one more memory round trip with the tile's
+    // LDS already allocated.  A surplus block of the grid (channel count not a multiple of 8) stages channel 0's bytes like
+    // any other and leaves right behind its loads; the sizing assertion is checked behind them too.
+    const uint32_t t = blockIdx.y;
+    const FdHot H = L.hot;
     const FmdRates& r = L.r;
     const FmdClassPlan& P = L.P;
-    const bool last = t + 1u == P.nt;
-    const uint32_t k0 = t * r.kt, k1 = k0 + r.kt < P.K ? k0 + r.kt : P.K;
     int jA, jB;
     uint32_t eq, er, x0;
-    if (L.use_rows) {                                        // tabulated by the host (fd_enqueue): no division, no comparisons
+    if constexpr (ROWS) {                                    // tabulated by the host (fd_enqueue): one more scalar load, no division
         jA = L.rows[t].jA; jB = L.rows[t].jB; eq = L.rows[t].eq; er = L.rows[t].er; x0 = L.rows[t].x0;
     } else {
         const FmdTile T = fmd_tile_fast(r, P, L.tl, 0u, t);
         jA = T.jA; jB = T.jB; eq = T.eq; er = T.er;
-        x0 = (uint32_t)jA * r.sr + P.i0r - k0 * r.fr;        // (all three terms below 2^32: fmd_ranges_fit32)
+        x0 = (uint32_t)jA * r.sr + P.i0r - T.k0 * r.fr;      // (all three terms below 2^32: fmd_ranges_fit32)
     }
+    const uint32_t gz = gridDim.z;
+    // every scalar load of the prologue -- the hot block, the row, the grid size -- goes out before anything waits (left alone, the
+    // scheduler issues them one behind the other's wait)
+    if constexpr (ROWS) __builtin_amdgcn_sched_barrier(0);
+    const uint32_t c_grid = blockIdx.x * gz + blockIdx.z;
+    const bool surplus = c_grid >= H.n_channels || t >= H.nt;
+    const uint32_t c = surplus ? 0u : c_grid;
+    const bool last = t + 1u == H.nt;
     const int jfirst = jA - 1;                               // lp[jfirst .. jB]; lp[-1] is demod_pre
     const uint32_t o0 = jfirst > 0 ? (uint32_t)jfirst : 0u;  // first FIR output (of this call) the tile forms
     const uint32_t no = (uint32_t)jB - o0 + 1u;              // FIR outputs formed
-    const uint32_t w0 = L.wd_first + o0 * L.half_M;          // first virtual dword of the tile
-    const uint32_t nq = ((((no - 1) * L.half_M + L.NP + 3u) >> 2) + 3u) & ~3u;   // 16-byte slots, whole 64-byte chunks
-    if (nq * 16u > L.raw_bytes || no > (uint32_t)(64 * PC - 3)) {
-        if (tid == 0) atomicOr(&L.exc->err, FMD_DEVERR_RAW_CAP);
-        return;
-    }
-    int* const gsum = reinterpret_cast<int*>(lds + (L.raw_bytes >> 2));   // audio group sums of the tile: [nk] + the carried tail
-    int* const gse = gsum + (r.kt + 2u);                     // (first, last) discriminator sample of every group
-    int* const tail = gse + 2u * (r.kt + 2u);                // the tile's last FIR output (re, im): demod_pre of the next call
+    const uint32_t w0 = H.wd_first + o0 * H.half_M;          // first virtual dword of the tile
+    const uint32_t nq_need = ((((no - 1) * H.half_M + H.NP + 3u) >> 2) + 3u) & ~3u;   // 16-byte slots, whole 64-byte chunks
+    const bool oversize = nq_need * 16u > H.raw_bytes || no > (uint32_t)(64 * PC - 3);   // (cannot happen: the host sized the tiles)
+    const uint32_t nq = oversize ? (H.raw_bytes >> 4) & ~3u : nq_need;
+    const uint32_t* const iq_w = reinterpret_cast<const uint32_t*>((uintptr_t)H.iq);
+    int* const gsum = reinterpret_cast<int*>(lds + (H.raw_bytes >> 2));   // audio group sums of the tile: [nk] + the carried tail
+    int* const gse = gsum + (H.kt + 2u);                     // (first, last) discriminator sample of every group
+    int* const tail = gse + 2u * (H.kt + 2u);                // the tile's last FIR output (re, im): demod_pre of the next call
 
     const uint32_t j = lane & 15u, q = lane >> 4;
     typedef const FMD_AS_GLOBAL fd_i4* gq;
-    const gq amat = (gq)(uintptr_t)L.amat + lane;
-    fd_i4 A[NKU];                                            // the tap fragments: in flight with the data
-#pragma unroll
-    for (int k = 0; k < NKU; ++k) A[k] = amat[k * 64];
-
-    const bool fast = ((((uintptr_t)L.iq + ((uint64_t)c * L.stride_w + (uint64_t)w0 - L.Hw) * 4u)) & 15u) == 0u;
-    const bool whole = fast && w0 >= L.Hw && (uint64_t)(w0 - L.Hw) + 4ull * nq <= L.stride_w;
+    const bool fast = (((H.iq + ((uint64_t)c * H.stride_w + (uint64_t)w0 - H.Hw) * 4u)) & 15u) == 0u;
+    const bool whole = fast && w0 >= H.Hw && (uint64_t)(w0 - H.Hw) + 4ull * nq <= H.stride_w;
     fd_i4* lq = reinterpret_cast<fd_i4*>(lds);
     if (whole) {
-        const unsigned char* src = reinterpret_cast<const unsigned char*>(L.iq + (uint64_t)c * L.stride_w + (w0 - L.Hw)) + 16u * tid;
+        const unsigned char* src = reinterpret_cast<const unsigned char*>(iq_w + (uint64_t)c * H.stride_w + (w0 - H.Hw)) + 16u * tid;
         unsigned char* dst = reinterpret_cast<unsigned char*>(lds) + 1024u * wave;
         const uint32_t nfull = nq / kThreads, ntail = nq - nfull * kThreads;
         for (uint32_t l = 0; l < nfull; ++l) dma16(src + (16u * kThreads) * l, dst + (16u * kThreads) * l);
@@ -469,11 +486,21 @@ __global__ void __launch_bounds__(kThreads, NG <= 6 ? 8 : 6) fmd_firdemod_reg_ke
     } else {
         for (uint32_t i = tid; i < nq; i += kThreads) lq[i] = virt_chunk(L, c, w0 + 4u * i, fast);
     }
+    if (surplus || oversize) {                               // (rare) leave -- behind the staging loads: they write this block's LDS
+        __builtin_amdgcn_s_waitcnt(0x0F70);
+        if (oversize && !surplus && tid == 0) atomicOr(&L.exc->err, FMD_DEVERR_RAW_CAP);
+        return;
+    }
+    const gq amat = (gq)(uintptr_t)H.amat + lane;
+    fd_i4 A[NKU];                                            // the tap fragments: in flight with the data
+#pragma unroll
+    for (int k = 0; k < NKU; ++k) A[k] = amat[k * 64];
+    const uint32_t k0 = t * H.kt, k1 = k0 + H.kt < P.K ? k0 + H.kt : P.K;
     FmdChanState st{};
     if (jfirst < 0 || k0 == 0 || last) st = L.st_in[c];
     // under the load latency: audio group k of the tile (k == nk: the trailing partial group) -- zero its accumulator and
     // tabulate its first and last discriminator sample (see fmd_firdemod_kernel)
-    for (uint32_t k = tid; k <= r.kt; k += kThreads) {
+    for (uint32_t k = tid; k <= H.kt; k += kThreads) {
         gsum[k] = 0;
         const uint32_t x = er + k * L.fb;
         uint32_t u, xrem;
@@ -556,7 +583,7 @@ __global__ void __launch_bounds__(kThreads, NG <= 6 ? 8 : 6) fmd_firdemod_reg_ke
     // audio group of the lane's first output and that group's last sample
     const int dm = (int)(o0 + t_first) - jA;                 // >= -1
     const uint32_t kq = (uint32_t)fmd_sdiv_magic((int)(x0 + (uint32_t)(dm > 0 ? dm : 0) * r.sr), L.magic_fr);
-    const uint32_t kqc = kq <= r.kt ? kq : r.kt;             // (lanes beyond the tile: any valid row)
+    const uint32_t kqc = kq <= H.kt ? kq : H.kt;             // (lanes beyond the tile: any valid row)
     const int e_lo = gse[2u * kqc + 1u];
     // the lane's outputs gi < g_hi lie inside the tile (and are real rows of the column: PC = 4 NG - 2), those gi < g_split in
     // the first audio group; its output 0 is skipped where it is only a predecessor (the tile's first output away from the
@@ -590,8 +617,8 @@ __global__ void __launch_bounds__(kThreads, NG <= 6 ? 8 : 6) fmd_firdemod_reg_ke
         sum_lo += gi < g_split ? dv : 0;
     }
     // (a lane whose outputs are all beyond the tile or not owned adds zeros: harmless)
-    if (kq <= r.kt) atomicAdd(&gsum[kqc], sum_lo);
-    if (kq + 1u <= r.kt && sum_all != sum_lo) atomicAdd(&gsum[kq + 1u], sum_all - sum_lo);
+    if (kq <= H.kt) atomicAdd(&gsum[kqc], sum_lo);
+    if (kq + 1u <= H.kt && sum_all != sum_lo) atomicAdd(&gsum[kq + 1u], sum_all - sum_lo);
     __syncthreads();
 
     // ---- low_pass_real (:418-422): one divide per audio sample ---------------------------------------------------
@@ -619,13 +646,18 @@ __global__ void __launch_bounds__(kThreads, NG <= 6 ? 8 : 6) fmd_firdemod_reg_ke
 template <int NKU>
 void launch(const FirDemodLaunch& L, dim3 g, size_t lds, hipStream_t s)
 {
-    if (L.reg_ng == 4u) hipLaunchKernelGGL((fmd_firdemod_reg_kernel<NKU, 4>), g, dim3(kThreads), lds, s, L);
-    else if (L.reg_ng == 5u) hipLaunchKernelGGL((fmd_firdemod_reg_kernel<NKU, 5>), g, dim3(kThreads), lds, s, L);
-    else if (L.reg_ng == 6u) hipLaunchKernelGGL((fmd_firdemod_reg_kernel<NKU, 6>), g, dim3(kThreads), lds, s, L);
+#define FD_REG(N) if (L.use_rows) hipLaunchKernelGGL((fmd_firdemod_reg_kernel<NKU, N, true>), g, dim3(kThreads), lds, s, L); \
+                  else hipLaunchKernelGGL((fmd_firdemod_reg_kernel<NKU, N, false>), g, dim3(kThreads), lds, s, L)
+    if (L.reg_ng == 4u) { FD_REG(4); }
+    else if (L.reg_ng == 5u) { FD_REG(5); }
+    else if (L.reg_ng == 6u) { FD_REG(6); }
+    else if (L.reg_ng == 7u) { FD_REG(7); }
+    else if (L.reg_ng == 8u) { FD_REG(8); }
 #ifdef FMD_EXPERIMENT
-    else if (L.reg_ng == 7u) hipLaunchKernelGGL((fmd_firdemod_reg_kernel<NKU, 7>), g, dim3(kThreads), lds, s, L);
-    else if (L.reg_ng == 8u) hipLaunchKernelGGL((fmd_firdemod_reg_kernel<NKU, 8>), g, dim3(kThreads), lds, s, L);
+    else if (L.reg_ng == 10u) { FD_REG(10); }
+    else if (L.reg_ng == 12u) { FD_REG(12); }
 #endif
+#undef FD_REG
     else if (L.reuse == 1u) hipLaunchKernelGGL((fmd_firdemod_kernel<NKU, 1>), g, dim3(kThreads), lds, s, L);
 #ifdef FMD_EXPERIMENT
     else if (L.reuse == 2u) hipLaunchKernelGGL((fmd_firdemod_kernel<NKU, 2>), g, dim3(kThreads), lds, s, L);   // FMD_FD_REUSE16: measured 4-6 % slower than the plain mapping
@@ -797,6 +829,15 @@ int fd_enqueue(fmd_firdemod* f, const void* d_iq, size_t nbytes, void* d_out, si
     const uint32_t per = (f->C + 7u) / 8u;
     dim3 g(L.tiles, f->C < 65535u ? f->C : 65535u, (f->C + 65534u) / 65535u);
     if (f->C >= 8u && L.tiles <= 65535u && per <= 65535u) { g = dim3(8u, L.tiles, per); L.xcd = 3u; }
+    if (L.reg_ng) {                                       // the register form always runs the (8, tiles, ceil(C / 8)) grid
+        if (L.tiles > 65535u || per > 65535u) { fmd_internal_set_err("call too large for the register-form grid"); return FMD_ERR_UNSUPPORTED; }
+        g = dim3(8u, L.tiles, per); L.xcd = 3u;
+        FdHot& H = L.hot;
+        H.iq = (uint64_t)(uintptr_t)L.iq; H.stride_w = L.stride_w; H.amat = (uint64_t)(uintptr_t)L.amat;
+        H.n_channels = L.n_channels; H.nt = L.P.nt; H.kt = r.kt;
+        H.Hw = L.Hw; H.NP = L.NP; H.half_M = L.half_M; H.wd_first = L.wd_first;
+        H.raw_bytes = L.raw_bytes; H.use_rows = L.use_rows;
+    }
     switch (f->plan.nku) {
         case 1: launch<1>(L, g, lds, stream); break;
         case 2: launch<2>(L, g, lds, stream); break;
@@ -882,17 +923,26 @@ int fmd_firdemod_new(const int16_t* taps, uint32_t n_taps, uint32_t decim, uint3
     // knobs: -DFMD_EXPERIMENT builds only (fmd_host.h); constants in the shipped library
     const uint32_t kt_env = fmd_knob_u32("FMD_FD_KT", 0);
     f->lds_budget = (size_t)fmd_knob_u32("FMD_FD_LDS", (uint32_t)f->lds_budget);
+    const bool lds_knob = fmd_knob("FMD_FD_LDS") != nullptr;
     f->no_rows = fmd_knob_u32("FMD_FD_ROWS", 1) == 0u;
     f->no_reuse = fmd_knob("FMD_FD_NOREUSE") != nullptr;
     f->reuse16 = fmd_knob("FMD_FD_REUSE16") != nullptr;
     f->int_disc = fmd_knob("FMD_FD_INT_DISC") != nullptr;
     f->dbg = fmd_knob_u32("FMD_DBG", 0);
-    // decimate 8 with the f32 discriminator and audio groups of at least 4 NG outputs: the register form (NG = 5: columns of 18
-    // outputs, 22 audio samples per tile at BASELINE config 4 instead of 17); FMD_FD_REG = 0 / 4 / 6 in the experiment build
+    // decimate 8 with the f32 discriminator and audio groups of at least 16 filter outputs: the register form, with the longest
+    // columns the audio groups admit (a lane's 4 NG - 3 consecutive outputs must not straddle more than one group boundary) up to
+    // NG = 8 -- columns of 30 outputs, 36 audio samples per tile, 5 tiles per CU at BASELINE config 4: measured best of NG = 4 ... 12
+    // (profiles/r04_experiments.md section 5).  FMD_FD_REG (experiment build): 0 = off, 4 ... 12 = that NG.
     f->reg_ng = 0;
     if (decim == 8u && f->plan.n_pass == 1u && f->lp_bound <= 2048u && !f->no_reuse && !f->int_disc) {
-        const uint32_t ng = fmd_knob_u32("FMD_FD_REG", 5);
-        if (ng >= 4u && ng <= 8u && fa >= 4ull * ng && (uint64_t)r.sr * (64u * (4u * ng - 2u)) < (1u << 24)) f->reg_ng = ng;
+        uint32_t ng = fmd_knob_u32("FMD_FD_REG", (uint32_t)(fa / 4 < 8 ? fa / 4 : 8));
+#ifndef FMD_EXPERIMENT
+        if (ng > 8u) ng = 8u;                                 // (9 ... 12 are instantiated in the experiment build only)
+#endif
+        if (ng >= 4u && ng <= 12u && ng != 9u && ng != 11u && fa >= 4ull * ng && (uint64_t)r.sr * (64u * (4u * ng - 2u)) < (1u << 24)) f->reg_ng = ng;
+        // tiles per CU that go with the column length: 8 (20 KB) up to 18 outputs per column, then 7, 6, 5
+        static const uint32_t budget[13] = {0, 0, 0, 0, 20480, 20480, 23400, 27300, 32700, 32700, 40900, 40900, 54600};
+        if (f->reg_ng && !lds_knob) f->lds_budget = budget[f->reg_ng];
     }
     for (uint32_t kt = 1; kt <= 1024; ++kt) {
         if ((uint64_t)r.sr * (kt + 2) >= (1u << 24)) break;
@@ -1027,7 +1077,7 @@ int fmd_firdemod_kernel_name(const fmd_firdemod* f, char* name, size_t cap)
     const uint32_t nku = f->plan.nku < 8u ? f->plan.nku : 8u;
     const bool reuse = f->M == 8u && f->plan.n_pass == 1u && !f->no_reuse;
     const int n = f->reg_ng ? snprintf(name, cap, "fmd_firdemod_reg_kernel<%u, %u>", nku, f->reg_ng)
-                            : snprintf(name, cap, "fmd_firdemod_kernel<%u, %u>", nku, reuse ? 1u : 0u);
+                            : snprintf(name, cap, "fmd_firdemod_kernel<%u, %u>", nku, reuse ? 1u : 0u);   // (the register form: + ", true>" with a tile table)
     return n < 0 || (size_t)n >= cap ? FMD_ERR_CAPACITY : FMD_OK;
 }
 

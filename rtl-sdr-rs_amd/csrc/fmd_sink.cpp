@@ -383,4 +383,19 @@ int fmd_sink_info(const fmd_sink* s, size_t* out_cap, uint32_t* n_devices, uint3
     return FMD_OK;
 }
 
+int fmd_sink_f64_stats(const fmd_sink* s, uint64_t* guarded, uint64_t* patched)
+{
+    if (!s) return FMD_ERR_INVALID_ARG;
+    uint64_t g = 0, p = 0;
+    for (const DevPart& part : s->parts) {                   // the parts' Demod banks hold the counters (fmd_internal_resolve_exc)
+        uint64_t gi = 0, pi = 0;
+        const int rc = fmd_demod_f64_stats(part.demod, &gi, &pi);
+        if (rc != FMD_OK) return rc;
+        g += gi; p += pi;
+    }
+    if (guarded) *guarded = g;
+    if (patched) *patched = p;
+    return FMD_OK;
+}
+
 }  // extern "C"

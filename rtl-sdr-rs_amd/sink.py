@@ -89,6 +89,11 @@ class Sink:
         check(lib().fmd_sink_info(self._h, C.byref(cap), C.byref(nd), C.byref(fl)))
         return {"out_cap": cap.value, "n_devices": nd.value, "in_flight": fl.value}
 
+    def f64_stats(self):
+        g, p = C.c_uint64(), C.c_uint64()
+        check(lib().fmd_sink_f64_stats(self._h, C.byref(g), C.byref(p)))
+        return {"guarded": g.value, "patched": p.value}
+
 
 def pump(sources, sink, max_buffers=None):
     """receive() of the example (simple_fm.rs:100-132) for many streams: every source fills its row of the next slot

@@ -138,6 +138,7 @@ extern "C" {
     pub fn fmd_sink_poll(s: *mut fmd_sink) -> c_int;
     pub fn fmd_sink_drain(s: *mut fmd_sink) -> c_int;
     pub fn fmd_sink_info(s: *const fmd_sink, out_cap: *mut usize, n_devices: *mut u32, in_flight: *mut u32) -> c_int;
+    pub fn fmd_sink_f64_stats(s: *const fmd_sink, guarded: *mut u64, patched: *mut u64) -> c_int;
     pub fn fmd_rtltcp_open(host: *const c_char, port: u16, timeout_ms: u32, out: *mut *mut fmd_rtltcp) -> c_int;
     pub fn fmd_rtltcp_close(s: *mut fmd_rtltcp);
     pub fn fmd_rtltcp_info(s: *const fmd_rtltcp, tuner_type: *mut u32, gain_count: *mut u32) -> c_int;

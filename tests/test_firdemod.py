@@ -101,9 +101,10 @@ def test_gpu_fused_register_form(fmd, oracle, T, M, fast, slow):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("ng", ["0", "4", "6"])
+@pytest.mark.parametrize("ng", ["0", "4", "6", "10"])
 def test_gpu_fused_register_form_variants(fmd, oracle, request, ng):
-    """The same shapes with 4 / 6 output groups per column (columns of 14 / 22 outputs) and with the form switched off (the
+    """The same shapes with 4 / 6 / 10 output groups per column (columns of 14 / 22 / 38 outputs; the default is the longest the
+    audio groups admit up to 8) and with the form switched off (the
     LDS-array kernel that every other decimation runs): knobs of the -DFMD_EXPERIMENT build."""
     from conftest import run_in_exp_child
     if run_in_exp_child(request, {"FMD_FD_REG": ng}):

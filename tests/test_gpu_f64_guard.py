@@ -81,6 +81,6 @@ def test_sink_settles_guarded_samples_in_its_host_copy(D, fast, slow):
     device, 9 buffers through 2 device parts and a ring of 3 are only right if each was patched in the slot's host copy.
     Run once without the skew too: then nothing needs a patch and the path must leave the audio alone."""
     r = run_child(["sink", D, fast, slow], guard_log2=-1)
-    assert r["bad"] == 0
+    assert r["bad"] == 0 and r["stats"]["patched"] == 0 and 0 < r["stats"]["guarded"] <= r["expected_guarded"]
     r = run_child(["sink", D, fast, slow], guard_log2=-1, skew=9)
-    assert r["bad"] == 0
+    assert r["bad"] == 0 and r["stats"]["patched"] == r["stats"]["guarded"] > 0      # measured by the sink, not assumed

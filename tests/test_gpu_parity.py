@@ -581,6 +581,25 @@ def test_downsample_129_to_512(fmd, oracle, D, fast, slow, kind):
         blocks.append(blk)
     check_stream(fmd, oracle, D, fast, slow, blocks, n_channels=nch)
     assert oracle.lib.fmo_would_panic() == panics0                    # the reference itself is defined on these inputs
+    if D == 512 and kind == "full":
+        # a state the handle itself produced must be restorable -- beyond downsample 128 `pcm as i16` of the wrapped
+        # arithmetic (simple_fm.rs:362) can lie anywhere in +-32768, so the carried partial sum exceeds the 16384-per-sample bound
+        # that set_state applies up to 128.  Full scale, checkpoint after every call, resume in a fresh bank, same audio.
+        cfg = mkcfg(fmd, D, fast, slow)
+        a, b = fmd.DemodBank(cfg, nch), fmd.DemodBank(cfg, nch)
+        big = 0
+        for blk in blocks:
+            want = a.demodulate_batch(blk)
+            got = b.demodulate_batch(blk)
+            assert all(np.array_equal(want[c], got[c]) for c in range(nch))
+            fresh = fmd.DemodBank(cfg, nch)
+            for c in range(nch):
+                st = a.get_state(c)
+                big = max(big, abs(st.as_dict()["now_lpr"]))
+                fresh.set_state(c, st)                                 # must not be FMD_ERR_BAD_STATE
+                assert fresh.get_state(c).as_dict() == st.as_dict()
+            b.close(); b = fresh
+        a.close(); b.close()
     if D == 512:
         with pytest.raises(fmd.FmdError) as ei:
             fmd.DemodBank(mkcfg(fmd, 513, fast, slow), 1)
