@@ -25,13 +25,13 @@ def summarize_firdemod(g, tag, rnd, out):
 
 
 tag = sys.argv[1]
-rnd = sys.argv[2] if len(sys.argv) > 2 else "r03"
+rnd = sys.argv[2] if len(sys.argv) > 2 else "r04"
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src, pmc, out = os.path.join(root, "gpurun_out", tag), os.path.join(root, "gpurun_out", tag + "_pmc"), os.path.join(root, "profiles")
 if "--firdemod-only" in sys.argv:      # a session that re-measured only the fused FIR kernel (its source is not one of the headline's)
     summarize_firdemod(os.path.join(root, "gpurun_out"), tag, rnd, out)
     sys.exit(0)
-KERNEL = "fmd_demod_tile_kernel<5, 256, 2>"
+KERNEL = "fmd_demod_tile_kernel<5, 2>"
 sys.path.insert(0, root)
 import bench as _bench   # kernel_source_hash(): ties the PMC summary to the sources it was measured on
 
@@ -122,4 +122,7 @@ if os.path.exists(cfgs):
 pc = os.path.join(g, tag + "_pmc_configs.jsonl")
 if os.path.exists(pc):
     shutil.copy(pc, os.path.join(out, rnd + "_pmc_configs.jsonl"))
+pr = os.path.join(g, tag + "_pmc_regions.jsonl")          # per-region instruction counts (scripts/gpu_pmc_regions.sh)
+if os.path.exists(pr):
+    shutil.copy(pr, os.path.join(out, rnd + "_pmc_regions.jsonl"))
 summarize_firdemod(g, tag, rnd, out)
