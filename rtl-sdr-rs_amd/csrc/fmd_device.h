@@ -220,11 +220,29 @@ __device__ __forceinline__ int disc_f32_xy(float xf, float yf)
     return fmd_cvt_i32_nan0(res);
 }
 
+// int -> f32 without v_cvt_f32_i32 (4 issue cycles): a sum accumulated ON TOP of the bit pattern of 1.5 * 2^23 -- the bias
+// rides in the accumulator's initial value, a v_mov either way -- reads as the f32 12582912 + v exactly for |v| < 2^22, and
+// one f32 subtract (2 cycles) takes the bias off.  Used for the window sums of the adjacent-window rounds (|lp| <= 128 * 14)
+// and, with BIAS, for the complex product of packed samples up to downsample 11 (|c| <= 2 (128 * 11)^2 < 2^22).
+#ifdef FMD_NO_BIAS
+constexpr int kSumBias = 0;
+__device__ __forceinline__ float sum_to_f32(int v) { return (float)v; }
+#else
+constexpr int kSumBias = 0x4B400000;
+__device__ __forceinline__ float sum_to_f32(int biased) { return u2f((uint32_t)biased) - 12582912.0f; }
+#endif
+
+template <bool BIAS = false>
 __device__ __forceinline__ int disc_f32(uint32_t a, uint32_t b)
 {
     const uint32_t a_sw = __builtin_amdgcn_alignbit(a, a, 16);          // (im, re)
     const uint32_t b_cj = (b & 0xFFFFu) | ((0u - (b >> 16)) << 16);      // (re, -im)
-    return disc_f32_xy((float)sdot2(a, b), (float)sdot2(a_sw, b_cj));    // c = a * conj(b), exact
+    if constexpr (BIAS) {                                                // c = a * conj(b), exact
+        const int cr = __builtin_amdgcn_sdot2(__builtin_bit_cast(fmd_s2, a), __builtin_bit_cast(fmd_s2, b), kSumBias, false);
+        const int ci = __builtin_amdgcn_sdot2(__builtin_bit_cast(fmd_s2, a_sw), __builtin_bit_cast(fmd_s2, b_cj), kSumBias, false);
+        return disc_f32_xy(sum_to_f32(cr), sum_to_f32(ci));
+    }
+    return disc_f32_xy((float)sdot2(a, b), (float)sdot2(a_sw, b_cj));
 }
 
 // The same with the samples' components already in f32 (exact integers): c = a * conj(b) by two multiplies and two

@@ -49,7 +49,22 @@ constexpr int kFirThreads = 256;
 constexpr int kFirGroupsPerWave = 4;                      // MFMA form: a wave accumulates up to 4 column groups (64 outputs each)
 typedef short fir_s2 __attribute__((ext_vector_type(2)));
 
+// What a fresh block of fmd_fir_mfma_kernel needs before its LDS-DMAs can go out, in the FIRST 64 bytes of the kernel
+// arguments (one s_load_dwordx16, one wait): a block holds its LDS from dispatch to exit, and hipcc waits for a block's scalar
+// loads before every branch -- the round-3 prologue had seven such round trips in front of the first DMA
+// (fmd_firdemod.hip FdHot, fmd_kernels.h FmdFastGeo).
+struct FirHot {
+    uint64_t iq;               // device address of the input
+    uint64_t stride_w;         // dwords per channel in this call
+    uint64_t amat;             // device address of the tap fragments
+    uint32_t n_channels, n_out, out_tile;
+    uint32_t Hw, NP, half_M, wd_first;
+    uint32_t pad[3];
+};
+static_assert(sizeof(FirHot) == 64, "one s_load_dwordx16");
+
 struct FirLaunch {
+    FirHot hot;                // matrix-core kernel (must stay the first member)
     const uint32_t* iq;        // [C][stride_w] dwords
     uint64_t stride_w;         // dwords per channel in this call (= nbytes / 4)
     const uint32_t* hist_in;   // [C][Hw]
@@ -75,7 +90,6 @@ struct FirLaunch {
     uint32_t col_bytes;        // 8 * decim: byte distance between consecutive columns
     int32_t mre[2], mim[2];    // additive constants (s8 domain) by window parity
     uint32_t dbg;              // ablation bits, honoured by -DFMD_EXPERIMENT builds only
-    uint32_t xcd_swizzle;      // 0 plain, 1 / 2: XCD-aware block -> (channel, tile) mapping
 };
 
 #ifdef FMD_EXPERIMENT
@@ -189,43 +203,39 @@ __global__ void __launch_bounds__(kFirThreads, 8) fmd_fir_mfma_kernel(const FirL
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     const uint32_t tid = threadIdx.x;
     __builtin_amdgcn_s_setprio(3);                                  // get the loads out first (see fmd_tile_body.h)
-    uint32_t c = blockIdx.y + 65535u * blockIdx.z, tix = blockIdx.x;
-    // XCD-aware block -> (channel, tile) mapping as in fmd_tile_body.h: XCD k works through its own contiguous
-    // eighth of the channels tile after tile (about -1 % per call here).
-    uint32_t ntiles = gridDim.x;
-    if (L.xcd_swizzle == 3u) {                                      // grid (8, tiles, ceil(C / 8)): blockIdx.x is the XCD
-        c = blockIdx.x * gridDim.z + blockIdx.z;
-        tix = blockIdx.y;
-        ntiles = gridDim.y;
-    } else if (L.xcd_swizzle && c < (L.n_channels & ~7u)) {
-        const uint32_t lin = blockIdx.x + gridDim.x * c, xcd = lin & 7u, idx = lin >> 3, q = idx / gridDim.x;
-        c = L.xcd_swizzle == 1u ? q * 8u + xcd : xcd * (L.n_channels >> 3) + q;
-        tix = idx - q * gridDim.x;
-    }
-    if (c >= L.n_channels) return;
-    const uint32_t o0 = tix * L.out_tile;
-    if (o0 >= L.n_out) return;
-    const uint32_t no = L.n_out - o0 < L.out_tile ? L.n_out - o0 : L.out_tile;
-    const uint32_t w0 = L.wd_first + o0 * L.half_M;                 // first virtual dword of the tile
+    // Grid (8, tiles, ceil(C / 8)) always: blockIdx.x IS the XCD, which works through its own contiguous eighth of the channels
+    // tile after tile (about -1 % per call against the plain mapping).  No branch in front of the LDS-DMAs: a surplus block
+    // of the grid (channel count not a multiple of 8) stages channel 0's first tile like any other and leaves behind its loads.
+    const FirHot H = L.hot;
+    const uint32_t gz = gridDim.z, ntiles = gridDim.y;
+    __builtin_amdgcn_sched_barrier(0);                              // both scalar loads go out before anything waits
+    const uint32_t c_grid = blockIdx.x * gz + blockIdx.z;
+    const bool surplus = c_grid >= H.n_channels || blockIdx.y * H.out_tile >= H.n_out;
+    const uint32_t c = surplus ? 0u : c_grid, tix = surplus ? 0u : blockIdx.y;
+    const uint32_t o0 = tix * H.out_tile;
+    const uint32_t no = H.n_out - o0 < H.out_tile ? H.n_out - o0 : H.out_tile;
+    const uint32_t w0 = H.wd_first + o0 * H.half_M;                 // first virtual dword of the tile
     // 16-byte slots the valid windows cover, in whole 64-byte chunks (the swizzle permutes within a chunk)
-    const uint32_t nq = ((((no - 1) * L.half_M + L.NP + 3u) >> 2) + 3u) & ~3u;
+    const uint32_t nq = ((((no - 1) * H.half_M + H.NP + 3u) >> 2) + 3u) & ~3u;
     // 16-byte global loads when this tile's chunks are 16-byte aligned in the caller's buffer
-    const bool fast = ((((uintptr_t)L.iq + ((uint64_t)c * L.stride_w + (uint64_t)w0 - L.Hw) * 4u)) & 15u) == 0u;
+    const bool fast = (((H.iq + ((uint64_t)c * H.stride_w + (uint64_t)w0 - H.Hw) * 4u)) & 15u) == 0u;
     const uint32_t lane = tid & 63u, wave = tid >> 6, j = lane & 15u, q = lane >> 4;
-    typedef const FMD_AS_GLOBAL fir_i4* gq;
-    const gq amat = (gq)(uintptr_t)L.amat + lane;
-    fir_i4 A[NKU];                                                  // first pass' tap fragments: in flight with the data
-#pragma unroll
-    for (int k = 0; k < NKU; ++k) A[k] = amat[k * 64];
 
     // Interior tiles (whole tile inside this call's buffer, 16-byte aligned): global_load_lds_dwordx4, 1 KiB per
     // wave-instruction straight into LDS, no VGPR round trip.  Tiles that touch the history, the end of the
     // stream or an unaligned buffer go through registers.
-    const bool whole = fast && w0 >= L.Hw && (uint64_t)(w0 - L.Hw) + 4ull * nq <= L.stride_w;
+    const bool whole = fast && w0 >= H.Hw && (uint64_t)(w0 - H.Hw) + 4ull * nq <= H.stride_w;
     fir_i4* lq = reinterpret_cast<fir_i4*>(lds);
+    // the tap fragments FIRST: five small L2-resident loads per lane whose latency then hides under the tile's own; issued
+    // behind the 16 KB of DMAs they queue behind them and every wave waits for them at the barrier (+2 % measured)
+    typedef const FMD_AS_GLOBAL fir_i4* gq;
+    const gq amat = (gq)(uintptr_t)H.amat + lane;
+    fir_i4 A[NKU];
+#pragma unroll
+    for (int k = 0; k < NKU; ++k) A[k] = amat[k * 64];
     if (FIR_ABLATE(1)) {
     } else if (whole) {
-        const unsigned char* src = reinterpret_cast<const unsigned char*>(L.iq + (uint64_t)c * L.stride_w + (w0 - L.Hw)) + 16u * (SWZ ? fir_swz_slot(tid) : tid);
+        const unsigned char* src = reinterpret_cast<const unsigned char*>(reinterpret_cast<const uint32_t*>((uintptr_t)H.iq) + (uint64_t)c * H.stride_w + (w0 - H.Hw)) + 16u * (SWZ ? fir_swz_slot(tid) : tid);
         unsigned char* dst = reinterpret_cast<unsigned char*>(lds) + 1024u * wave;
         const uint32_t nfull = nq / kFirThreads, ntail = nq - nfull * kFirThreads;
         for (uint32_t l = 0; l < nfull; ++l) fir_dma16(src + (16u * kFirThreads) * l, dst + (16u * kFirThreads) * l);
@@ -246,6 +256,10 @@ __global__ void __launch_bounds__(kFirThreads, 8) fmd_fir_mfma_kernel(const FirL
             if (i3 < nq) lq[SWZ ? fir_swz_slot(i3) : i3] = e;
             if (i4 < nq) lq[SWZ ? fir_swz_slot(i4) : i4] = h;
         }
+    }
+    if (surplus) {                                                  // (rare) behind the staging loads: they write this block's LDS
+        __builtin_amdgcn_s_waitcnt(0x0F70);
+        return;
     }
     __builtin_amdgcn_s_setprio(0);
     __builtin_amdgcn_s_waitcnt(0x0F70);                             // vmcnt(0): the LDS-DMAs (and the A fragments) have landed
@@ -348,7 +362,7 @@ struct fmd_fir {
     uint32_t* d_wre = nullptr; uint32_t* d_wim = nullptr;
     uint32_t* d_amat = nullptr;                           // MFMA form: banded tap matrix, fragment order
     uint32_t n_pass = 0, nku = 0, groups = 0;             // n_pass == 0: VALU kernel only
-    uint32_t xcd_swizzle = 2, dbg = 0;                    // knobs of the -DFMD_EXPERIMENT build (fmd_host.h), read at creation
+    uint32_t dbg = 0;                                     // ablation bits of the -DFMD_EXPERIMENT build (fmd_host.h), read at creation
     bool swz = false;
     int32_t mre[2] = {0, 0}, mim[2] = {0, 0};
     uint32_t* d_hist[2] = {nullptr, nullptr};
@@ -402,7 +416,6 @@ int fir_enqueue(fmd_fir* f, const void* d_iq, size_t nbytes, void* d_out, size_t
     L.out_tile = (uint32_t)ot;
     L.dbg = f->dbg;
     if (n_out && f->n_pass) {
-        L.xcd_swizzle = f->xcd_swizzle;                                                            // 0 = plain mapping (tuning)
         L.amat = f->d_amat; L.n_pass = f->n_pass; L.nku = f->nku; L.groups = f->groups; L.col_bytes = 8u * f->M;
         L.mre[0] = f->mre[0]; L.mre[1] = f->mre[1]; L.mim[0] = f->mim[0]; L.mim[1] = f->mim[1];
         L.out_tile = 64u * f->groups;
@@ -410,10 +423,13 @@ int fir_enqueue(fmd_fir* f, const void* d_iq, size_t nbytes, void* d_out, size_t
         const size_t staged = (((((size_t)(L.out_tile - 1) * L.half_M + L.NP + 3) / 4) + 3) & ~(size_t)3) * 16;
         const size_t touched = (size_t)16 * f->groups * L.col_bytes + (size_t)64 * f->n_pass * f->nku;
         const size_t lds = staged > touched ? staged : touched;
-        const uint32_t gy = f->C < 65535u ? f->C : 65535u, gz = (f->C + 65534u) / 65535u;
-        dim3 g((uint32_t)((n_out + L.out_tile - 1) / L.out_tile), gy, gz);
-        const uint32_t per = (f->C + 7u) / 8u;                      // XCD-aware grid without index arithmetic
-        if (L.xcd_swizzle && f->C >= 8u && g.x <= 65535u && per <= 65535u) { g = dim3(8u, g.x, per); L.xcd_swizzle = 3u; }
+        const uint32_t tiles = (uint32_t)((n_out + L.out_tile - 1) / L.out_tile), per = (f->C + 7u) / 8u;
+        if (tiles > 65535u || per > 65535u) { fmd_internal_set_err("call too large for the matrix-core FIR grid"); return FMD_ERR_UNSUPPORTED; }
+        const dim3 g(8u, tiles, per);                               // XCD-aware grid: blockIdx.x is the XCD (surplus blocks exit)
+        FirHot& H = L.hot;
+        H.iq = (uint64_t)(uintptr_t)L.iq; H.stride_w = L.stride_w; H.amat = (uint64_t)(uintptr_t)L.amat;
+        H.n_channels = L.n_channels; H.n_out = L.n_out; H.out_tile = L.out_tile;
+        H.Hw = L.Hw; H.NP = L.NP; H.half_M = L.half_M; H.wd_first = L.wd_first;
         switch (f->nku) {
             case 1: launch_mfma<1>(L, g, lds, stream, f->swz); break;
             case 2: launch_mfma<2>(L, g, lds, stream, f->swz); break;
@@ -499,7 +515,6 @@ int fmd_fir_new(const int16_t* taps, uint32_t n_taps, uint32_t decim, const fmd_
     std::vector<uint32_t> amat;
     // knobs: -DFMD_EXPERIMENT builds only (fmd_host.h); constants in the shipped library
     const char* env_mfma = fmd_knob("FMD_FIR_MFMA");
-    f->xcd_swizzle = fmd_knob_u32("FMD_XCD", 2);
     f->dbg = fmd_knob_u32("FMD_DBG", 0);
     f->swz = fmd_knob_u32("FMD_FIR_SWZ", 0) == 1u;
     FmdFirMfmaPlan plan;

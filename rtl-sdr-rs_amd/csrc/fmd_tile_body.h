@@ -209,7 +209,7 @@ __device__ __forceinline__ void tile_exc_flush(const FmdLaunch& L, const TileCtx
 // into 2 * NDW per-lane weight registers and the body is the same 3 VALU instructions per dword as the whole-dword
 // loop -- no run-time trip counts, no per-dword branches.  (Round 1 ran these through the run-time loop below:
 // downsample 7 sat at 57 % of the HBM spec against 70 % for 6 and 8.)
-template <int NDW>
+template <int NDW, bool BIAS>
 __device__ __forceinline__ void masked_rounds(const uint32_t* __restrict__ raw_w, int16_t* __restrict__ d16, int wofs, int s00,
                                               int D, int cnt, uint32_t lane, uint32_t wave, uint32_t wreA, uint32_t wreB,
                                               uint32_t wimA, uint32_t wimB, uint32_t mf, uint32_t ml, int cre, int cim, bool smallD)
@@ -236,8 +236,8 @@ __device__ __forceinline__ void masked_rounds(const uint32_t* __restrict__ raw_w
         const uint32_t pk1 = pack_lp_perm(re1, im1), pk2 = pack_lp_perm(re2, im2);
         const uint32_t prev1 = wave_shr1(pk1);
         const uint32_t prev2 = wave_shr1_old(wave_ror1(pk1), pk2);
-        if (lane > 0 && i1 < cnt) d16[i1] = (int16_t)(smallD ? disc_f32(pk1, prev1) : disc_nosel(pk1, prev1));   // smallD: wave-uniform
-        if (i2 < cnt) d16[i2] = (int16_t)(smallD ? disc_f32(pk2, prev2) : disc_nosel(pk2, prev2));
+        if (lane > 0 && i1 < cnt) d16[i1] = (int16_t)(smallD ? disc_f32<BIAS>(pk1, prev1) : disc_nosel(pk1, prev1));   // smallD: wave-uniform
+        if (i2 < cnt) d16[i2] = (int16_t)(smallD ? disc_f32<BIAS>(pk2, prev2) : disc_nosel(pk2, prev2));
     }
 }
 
@@ -310,7 +310,7 @@ __device__ __forceinline__ void stream_pair_rounds(const unsigned char* __restri
     };
     auto round = [&](const uint32_t (&w)[NDW], int b) {
         const int i1 = b + 2 * (int)lane, i2 = i1 + 1;
-        int re1 = DH, im1 = c1, re2 = DH, im2 = c2;
+        int re1 = kSumBias + DH, im1 = kSumBias + c1, re2 = kSumBias + DH, im2 = kSumBias + c2;
         uint32_t dead1 = 0, dead2 = 0;
 #pragma unroll
         for (int u = 0; u < DH; ++u) {
@@ -321,7 +321,7 @@ __device__ __forceinline__ void stream_pair_rounds(const unsigned char* __restri
             im2 = sdot4(wb, (u & 1) ? m2B : m2A, im2);
             dead1 = wa; dead2 = wb;
         }
-        const float ar1 = (float)re1, ai1 = (float)im1, ar2 = (float)re2, ai2 = (float)im2;
+        const float ar1 = sum_to_f32(re1), ai1 = sum_to_f32(im1), ar2 = sum_to_f32(re2), ai2 = sum_to_f32(im2);
         const float br1 = u2f(wave_shr1_dead(dead1, f2u(ar2))), bi1 = u2f(wave_shr1_dead(dead2, f2u(ai2)));   // second window of lane l - 1
         // (the discriminators sit INSIDE the predicated stores: two separately masked instruction streams, the form hipcc
         //  built by itself while the conversion at their end was a plain cast it could sink -- and the faster one)
@@ -415,7 +415,7 @@ __device__ __forceinline__ void tile_body(const FmdLaunch& L, const TileCtx& X, 
         for (int base = (int)wave * RS; base < last && !FMD_ABLATE(6); base += NW * RS) {
             const int i1 = base + 2 * (int)lane, i2 = i1 + 1;
             const uint32_t* __restrict__ pa = raw_w + (uint32_t)(wbase + DH * i1);
-            int re1 = DH, im1 = c1, re2 = DH, im2 = c2;
+            int re1 = kSumBias + DH, im1 = kSumBias + c1, re2 = kSumBias + DH, im2 = kSumBias + c2;
             uint32_t dead1 = 0, dead2 = 0;                   // the last sign-flipped dwords: dead after the dot products
             if constexpr (DH == 4) {                         // (aligned: checked above) one 16-byte read per window
                 const uint4 va = *reinterpret_cast<const uint4*>(pa), vb = *reinterpret_cast<const uint4*>(pa + 4);
@@ -440,7 +440,7 @@ __device__ __forceinline__ void tile_body(const FmdLaunch& L, const TileCtx& X, 
                     dead1 = wa; dead2 = wb;
                 }
             }
-            const float ar1 = (float)re1, ai1 = (float)im1, ar2 = (float)re2, ai2 = (float)im2;
+            const float ar1 = sum_to_f32(re1), ai1 = sum_to_f32(im1), ar2 = sum_to_f32(re2), ai2 = sum_to_f32(im2);
             const float br1 = u2f(wave_shr1_dead(dead1, f2u(ar2))), bi1 = u2f(wave_shr1_dead(dead2, f2u(ai2)));   // second window of lane l - 1
             // (:362); DH == 1 is downsample 2: no i32 wrap to emulate.  The discriminators sit INSIDE the predicated stores
             // (see stream_pair_rounds)
@@ -475,8 +475,9 @@ __device__ __forceinline__ void tile_body(const FmdLaunch& L, const TileCtx& X, 
             //  so that both discriminators run as one interleaved stream: +2 % at downsample 6 / 10, +7 % at 7.  The
             //  two separately masked regions the compiler builds here are the faster form.)
             // (:362); whole-dword windows: downsample <= 14 (<= FMD_DISC_F32_MAX_D)
-            if (lane > 0 && i1 < cnt) d16[i1] = (int16_t)(FMD_ABLATE(0) ? (int)(pk1 ^ prev1) : disc_f32(pk1, prev1));
-            if (i2 < cnt) d16[i2] = (int16_t)(FMD_ABLATE(0) ? (int)(pk2 ^ prev2) : disc_f32(pk2, prev2));
+            constexpr bool kBias = DH > 0 && 2 * DH <= 11;       // (this branch: downsample 8 at an unaligned tile)
+            if (lane > 0 && i1 < cnt) d16[i1] = (int16_t)(FMD_ABLATE(0) ? (int)(pk1 ^ prev1) : disc_f32<kBias>(pk1, prev1));
+            if (i2 < cnt) d16[i2] = (int16_t)(FMD_ABLATE(0) ? (int)(pk2 ^ prev2) : disc_f32<kBias>(pk2, prev2));
         }
     } else {
         // Any downsample, any phase: a window of D samples starting at call sample s covers the dwords
@@ -517,7 +518,9 @@ __device__ __forceinline__ void tile_body(const FmdLaunch& L, const TileCtx& X, 
             rot0 = 2u * ((((lane & 31u) * g) >> 5) % ((uint32_t)ndw >> 1));
         }
         // compile-time dword counts (see masked_rounds); anything else runs the general loop below
-#define FMD_MASKED(N) case N: masked_rounds<N>(raw_w, d16, wofs, s00, D, cnt, lane, wave, wreA, wreB, wimA, wimB, mf, ml, cre, cim, smallD); break
+        // (products of the packed samples stay below 2^22 up to downsample 11: the biased int -> f32 form of fmd_device.h)
+        constexpr bool kBiasOk = (DH < 0 && -DH <= 11) || (DH > 0 && 2 * DH <= 11);
+#define FMD_MASKED(N) case N: masked_rounds<N, kBiasOk>(raw_w, d16, wofs, s00, D, cnt, lane, wave, wreA, wreB, wimA, wimB, mf, ml, cre, cim, smallD); break
         bool done = false;
         // (the catch-all kernel, DH == 0, only sees downsample >= 16 once every smaller factor has a kernel of its own:
         //  windows of 9 dwords and more, none of the compile-time counts below)
