@@ -5,6 +5,9 @@ OUT=gpurun_out/$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
 ARGS="--steps 10 --warmup 2 --settle 20 --no-cpu --no-extra $@"
+# the hash of the kernel sources AS MEASURED (summarize_profiles.py ties the summary to it; bench.py quotes the traffic only
+# when its own sources hash the same)
+python3 -c "import bench; print(bench.kernel_source_hash())" > $OUT/kernel_source_sha16.txt
 run() { # name counters...
   n=$1; shift
   timeout 300 rocprofv3 --kernel-trace --pmc "$@" -d $OUT/$n -o pmc -f csv --kernel-include-regex "fmd_demod" -- python3 bench.py $ARGS > $OUT/$n.json 2> $OUT/$n.err || tail -5 $OUT/$n.err

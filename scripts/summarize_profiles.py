@@ -66,13 +66,19 @@ for f in glob.glob(os.path.join(pmc, "*", "*counter_collection.csv")):
         acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
     for k, v in acc.items():
         counters[k] = {"mean_per_launch": sum(v) / len(v), "launches": len(v)}
+# the hash written on the GPU box next to the counters (scripts/gpu_pmc.sh); a session without it cannot be tied to sources
+hash_file = os.path.join(pmc, "kernel_source_sha16.txt")
+measured_hash = open(hash_file).read().strip() if os.path.exists(hash_file) else None
+if measured_hash != _bench.kernel_source_hash():
+    print("WARNING: the kernel sources have changed since the PMC passes (%s measured, %s now): bench.py will not quote this traffic" % (
+        measured_hash, _bench.kernel_source_hash()))
 waves = counters["SQ_WAVES"]["mean_per_launch"]
 alg = bench["roofline"]["algorithmic_bytes_per_launch"]
 fetch_kb, write_kb = counters["FETCH_SIZE"]["mean_per_launch"], counters["WRITE_SIZE"]["mean_per_launch"]
 traffic = fetch_kb * 1024 * 2 + write_kb * 1024
 pm = {"command": "rocprofv3 --kernel-trace --pmc <set> -- python3 bench.py --steps 10 --warmup 2 --settle 20 --no-cpu --no-extra  (scripts/gpu_pmc.sh; "
                  "one pass per counter set; never combined with --sys-trace)",
-      "kernel": KERNEL, "kernel_source_sha16": _bench.kernel_source_hash(), "counters": counters,
+      "kernel": KERNEL, "kernel_source_sha16": measured_hash, "counters": counters,
       "per_wave": {"valu": counters["SQ_INSTS_VALU"]["mean_per_launch"] / waves, "salu": counters["SQ_INSTS_SALU"]["mean_per_launch"] / waves,
                    "lds": counters["SQ_INSTS_LDS"]["mean_per_launch"] / waves, "vmem_rd": counters["SQ_INSTS_VMEM_RD"]["mean_per_launch"] / waves},
       "hbm_traffic": {"fetch_size_kb": fetch_kb, "write_size_kb": write_kb,
