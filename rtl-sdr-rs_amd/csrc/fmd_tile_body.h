@@ -358,7 +358,9 @@ __device__ __forceinline__ void tile_body(const FmdLaunch& L, const TileCtx& X, 
     int16_t* const d16 = reinterpret_cast<int16_t*>(smem + (STREAM ? 0u : L.raw_cap));
 
     const uint32_t tid = threadIdx.x;
-    const uint32_t lane = tid & 63u, wave = tid >> 6;
+    // (the wave index as a SCALAR: the round loops' trip control then runs on the scalar unit -- s_cmp / s_cbranch -- instead of
+    //  a per-lane compare and an EXEC-mask update per round)
+    const uint32_t lane = tid & 63u, wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid >> 6));
     const uint32_t p0 = P.p0, c = X.c;
     const int jfirst = X.jfirst, cnt = X.cnt, wofs = STREAM ? 0 : X.wofs;
     // DH >= 8 (downsample 16, 32, 64 with kernels of their own): whole-dword windows too, but a multiple of 4 dwords long --
