@@ -29,6 +29,8 @@
 #include "fmd_device.h"
 #include "fmd_kernels.h"
 
+#include <type_traits>
+
 namespace fmd_tk {
 
 using namespace fmd_dev;
@@ -414,7 +416,10 @@ __device__ __forceinline__ void tile_body(const FmdLaunch& L, const TileCtx& X, 
         const uint32_t r2A = o2 ? FMD_W_RE_ODD : FMD_W_RE_EVEN, r2B = o2 ? FMD_W_RE_EVEN : FMD_W_RE_ODD;
         const uint32_t m2A = o2 ? FMD_W_IM_ODD : FMD_W_IM_EVEN, m2B = o2 ? FMD_W_IM_EVEN : FMD_W_IM_ODD;
         const int c1 = 2 * (o1 ? DH / 2 : (DH + 1) / 2), c2 = 2 * (o2 ? DH / 2 : (DH + 1) / 2);
-        for (int base = (int)wave * RS; base < last && !FMD_ABLATE(6); base += NW * RS) {
+        // One wave-round; FULL: all 128 windows of the round lie inside the tile (every round of a wave but its last), so the
+        // stores need no per-lane range test.
+        auto pair_round = [&](int base, auto full_c) {
+            constexpr bool FULL = decltype(full_c)::value;
             const int i1 = base + 2 * (int)lane, i2 = i1 + 1;
             const uint32_t* __restrict__ pa = raw_w + (uint32_t)(wbase + DH * i1);
             int re1 = kSumBias + DH, im1 = kSumBias + c1, re2 = kSumBias + DH, im2 = kSumBias + c2;
@@ -446,9 +451,12 @@ __device__ __forceinline__ void tile_body(const FmdLaunch& L, const TileCtx& X, 
             const float br1 = u2f(wave_shr1_dead(dead1, f2u(ar2))), bi1 = u2f(wave_shr1_dead(dead2, f2u(ai2)));   // second window of lane l - 1
             // (:362); DH == 1 is downsample 2: no i32 wrap to emulate.  The discriminators sit INSIDE the predicated stores
             // (see stream_pair_rounds)
-            if (lane > 0 && i1 < cnt) d16[i1] = (int16_t)disc_f32_c<DH == 1>(ar1, ai1, br1, bi1);
-            if (i2 < cnt) d16[i2] = (int16_t)disc_f32_c<DH == 1>(ar2, ai2, ar1, ai1);
-        }
+            if (lane > 0 && (FULL || i1 < cnt)) d16[i1] = (int16_t)disc_f32_c<DH == 1>(ar1, ai1, br1, bi1);
+            if (FULL || i2 < cnt) d16[i2] = (int16_t)disc_f32_c<DH == 1>(ar2, ai2, ar1, ai1);
+        };
+        int base = (int)wave * RS;
+        for (; base + 128 <= cnt && !FMD_ABLATE(6); base += NW * RS) pair_round(base, std::true_type{});
+        for (; base < last && !FMD_ABLATE(6); base += NW * RS) pair_round(base, std::false_type{});
     } else if (fastwin) {
         // Hot loop: no branches, no special cases.  Lanes whose window lies outside the tile (the two
         // call-start samples of tile 0, surplus lanes of the last round) read whatever LDS holds there --
