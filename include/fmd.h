@@ -228,7 +228,8 @@ int fmd_fir_filter_device(fmd_fir *f, const void *d_iq, size_t nbytes, void *d_o
  * (128 * sum|taps|) >> shift down to 2048 -- the boxcar's range at downsample 16 -- selects the kernel's f32 form of
  * the discriminator (same results, ~8 % faster); the Python mirror's auto_shift() picks that one by default.
  * A call that yields fewer than 2 filter outputs returns FMD_ERR_TOO_SHORT (assert at :356) and changes nothing.
- * All channels of a bank advance together (equal-sized buffers), so there is no per-channel set_state. */
+ * All channels of a bank advance together (equal-sized buffers), so there is no per-channel set_state; the bank as a
+ * whole is saved and restored with fmd_firdemod_checkpoint / fmd_firdemod_resume. */
 typedef struct fmd_firdemod fmd_firdemod;
 int fmd_firdemod_new(const int16_t *taps, uint32_t n_taps, uint32_t decim, uint32_t shift, uint32_t rate_out,
                      uint32_t rate_resample, const fmd_device_config *dev, fmd_firdemod **out);
@@ -246,6 +247,15 @@ int fmd_firdemod_demodulate_device(fmd_firdemod *f, const void *d_iq, size_t nby
 int fmd_firdemod_check(fmd_firdemod *f);
 /* demod_pre, now_lpr, prev_lpr_index of one channel (prev_index / lp_now are 0: the FIR owns the decimation). */
 int fmd_firdemod_get_state(fmd_firdemod *f, uint32_t channel, fmd_demod_state *state);
+/* Checkpoint / resume of the WHOLE bank (its channels advance together, so the unit is the bank, not a channel): the
+ * sample position, the resampler phase, and per channel now_lpr, demod_pre and the filter's history (the last
+ * n_taps - 1 samples).  A bank resumed from a checkpoint continues bit for bit as the one it was taken from would
+ * have; the blob is host memory, little-endian, and names the filter (taps, decim, shift, rates, channel count) it
+ * belongs to -- fmd_firdemod_resume on any other bank, or on a damaged blob, returns FMD_ERR_BAD_STATE and changes
+ * nothing.  Both calls synchronise the device first. */
+size_t fmd_firdemod_checkpoint_size(const fmd_firdemod *f);
+int fmd_firdemod_checkpoint(fmd_firdemod *f, void *blob, size_t cap);
+int fmd_firdemod_resume(fmd_firdemod *f, const void *blob, size_t size);
 int fmd_firdemod_f64_stats(const fmd_firdemod *f, uint64_t *guarded, uint64_t *patched);
 int fmd_firdemod_tiling(const fmd_firdemod *f, uint32_t *audio_per_tile, uint32_t *lds_bytes);
 /* Name of the kernel this handle launches, as `rocprofv3 --kernel-trace` prints it (see fmd_demod_last_kernel). */

@@ -101,6 +101,9 @@ PROTOTYPES = {
     "fmd_firdemod_demodulate_device": (C.c_int, [_vp, _vp, _sz, _vp, _sz, _szp, _vp]),
     "fmd_firdemod_check": (C.c_int, [_vp]),
     "fmd_firdemod_get_state": (C.c_int, [_vp, C.c_uint32, C.POINTER(DemodState)]),
+    "fmd_firdemod_checkpoint_size": (C.c_size_t, [_vp]),
+    "fmd_firdemod_checkpoint": (C.c_int, [_vp, _vp, _sz]),
+    "fmd_firdemod_resume": (C.c_int, [_vp, _vp, _sz]),
     "fmd_firdemod_f64_stats": (C.c_int, [_vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "fmd_firdemod_tiling": (C.c_int, [_vp, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
     "fmd_firdemod_kernel_name": (C.c_int, [_vp, C.c_char_p, C.c_size_t]),

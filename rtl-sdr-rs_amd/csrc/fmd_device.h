@@ -17,6 +17,17 @@ __device__ __forceinline__ int sdot4(uint32_t a, uint32_t b, int c)
     return __builtin_amdgcn_sdot4((int)a, (int)b, c, false);   // v_dot4_i32_i8
 }
 
+// The FIRST dot product of an accumulation whose start value is loop-invariant (a bias, a per-phase constant).  For the
+// plain intrinsic hipcc selects the two-address v_dot4c_i32_i8 and copies the start value into the accumulator first: one
+// v_mov per sum per round.  With the clamp bit set it has to take the three-address VOP3P v_dot4_i32_i8, which reads the
+// start value as a source; the clamp (saturation at the i32 range) never engages: |sum| <= 128 * 4 on top of a start value
+// below 2^31 - 2^23.  (An inline-asm v_dot4_i32_i8 does the same but hides the dot -> VALU wait states from hipcc's hazard
+// pass: wrong results at downsample 2, where the consumer follows directly.)
+__device__ __forceinline__ int sdot4_init(uint32_t a, uint32_t w, int init)
+{
+    return __builtin_amdgcn_sdot4((int)a, (int)w, init, true);
+}
+
 // Sum of the rotated + centred complex samples n in [n0, n1) of this channel-call (rotate_90 :276-299,
 // `as i16 - 127` :258, buf_to_complex :441-450, folded into signed-byte dot products), read from the
 // LDS image of the raw bytes.  `wofs`: LDS dword index of the call's dword 0 (may be negative).
@@ -238,8 +249,9 @@ __device__ __forceinline__ int disc_f32(uint32_t a, uint32_t b)
     const uint32_t a_sw = __builtin_amdgcn_alignbit(a, a, 16);          // (im, re)
     const uint32_t b_cj = (b & 0xFFFFu) | ((0u - (b >> 16)) << 16);      // (re, -im)
     if constexpr (BIAS) {                                                // c = a * conj(b), exact
-        const int cr = __builtin_amdgcn_sdot2(__builtin_bit_cast(fmd_s2, a), __builtin_bit_cast(fmd_s2, b), kSumBias, false);
-        const int ci = __builtin_amdgcn_sdot2(__builtin_bit_cast(fmd_s2, a_sw), __builtin_bit_cast(fmd_s2, b_cj), kSumBias, false);
+        // (clamp bit set: the three-address v_dot2_i32_i16 with the bias as a source, no v_mov of it first -- see sdot4_init)
+        const int cr = __builtin_amdgcn_sdot2(__builtin_bit_cast(fmd_s2, a), __builtin_bit_cast(fmd_s2, b), kSumBias, true);
+        const int ci = __builtin_amdgcn_sdot2(__builtin_bit_cast(fmd_s2, a_sw), __builtin_bit_cast(fmd_s2, b_cj), kSumBias, true);
         return disc_f32_xy(sum_to_f32(cr), sum_to_f32(ci));
     }
     return disc_f32_xy((float)sdot2(a, b), (float)sdot2(a_sw, b_cj));

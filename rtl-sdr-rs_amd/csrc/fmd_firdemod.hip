@@ -697,6 +697,7 @@ struct fmd_firdemod {
     FmdRates r{};
     uint32_t i0r = 0;                                     // resampler phase of every channel (host mirror)
     uint32_t last_K = 0;
+    uint32_t taps_hash = 0;                               // FNV-1a of the taps: a checkpoint names the filter it belongs to
     uint32_t lp_cap = 0, raw_bytes = 0;
     FmdExcBuf* d_exc = nullptr;
     double f64_guard = 0x1p-20;
@@ -907,6 +908,11 @@ int fmd_firdemod_new(const int16_t* taps, uint32_t n_taps, uint32_t decim, uint3
     fmd_firdemod* f = new (std::nothrow) fmd_firdemod();
     if (!f) return FMD_ERR_NOMEM;
     f->T = n_taps; f->M = decim; f->C = dev->n_channels; f->device = device; f->shift = shift;
+    f->taps_hash = 2166136261u;
+    for (uint32_t t = 0; t < n_taps; ++t) {
+        f->taps_hash = (f->taps_hash ^ (uint32_t)(taps[t] & 0xFF)) * 16777619u;
+        f->taps_hash = (f->taps_hash ^ (uint32_t)((taps[t] >> 8) & 0xFF)) * 16777619u;
+    }
     f->lp_bound = (uint32_t)((128ull * sum_abs) >> shift);
     f->NP = ((n_taps + 1) / 2 + 3u) & ~3u;
     const uint32_t H = n_taps - 1, Hp = H + (H & 1u);
@@ -1062,6 +1068,72 @@ int fmd_firdemod_get_state(fmd_firdemod* f, uint32_t channel, fmd_demod_state* s
     state->now_lpr = s.now_lpr;
     state->prev_lpr_index = (int32_t)(s.lpr_index_r * f->r.g);
     state->demod_pre_re = s.demod_pre_re; state->demod_pre_im = s.demod_pre_im;
+    return FMD_OK;
+}
+
+// ---- checkpoint / resume of a whole bank ---------------------------------------------------------------------------
+// What one call hands to the next: the sample position and the resampler phase (shared by all channels), and per
+// channel the resampler accumulator + last filter output (FmdChanState) and the FIR history (the last T - 1 samples).
+namespace {
+struct FdCkptHeader {
+    uint32_t magic, version;
+    uint32_t T, M, C, Hw, shift, taps_hash, fast, slow, i0r, last_K;
+    uint64_t pos;
+};
+constexpr uint32_t kFdCkptMagic = 0x4B434446u;            // "FDCK"
+size_t fd_ckpt_size(const fmd_firdemod* f)
+{
+    return sizeof(FdCkptHeader) + (size_t)f->C * sizeof(FmdChanState) + (size_t)f->C * f->Hw * 4;
+}
+}  // namespace
+
+size_t fmd_firdemod_checkpoint_size(const fmd_firdemod* f) { return f ? fd_ckpt_size(f) : 0; }
+
+int fmd_firdemod_checkpoint(fmd_firdemod* f, void* blob, size_t cap)
+{
+    if (!f || !blob) { fmd_internal_set_err("null argument"); return FMD_ERR_INVALID_ARG; }
+    if (cap < fd_ckpt_size(f)) { fmd_internal_set_err("checkpoint buffer smaller than fmd_firdemod_checkpoint_size"); return FMD_ERR_CAPACITY; }
+    FD_ON_DEVICE(f->device);
+    FD_TRY(hipDeviceSynchronize());
+    int rc = fmd_internal_resolve_exc(f->d_exc, f->r.R, f->seq, f->seq, f->d_state[f->cur], nullptr, 0, &f->f64_guarded, &f->f64_patched);
+    if (rc) return rc;
+    FdCkptHeader h{kFdCkptMagic, 1u, f->T, f->M, f->C, f->Hw, f->shift, f->taps_hash, f->r.fast, f->r.slow, f->i0r, f->last_K, f->pos};
+    uint8_t* p = static_cast<uint8_t*>(blob);
+    memcpy(p, &h, sizeof(h)); p += sizeof(h);
+    FD_TRY(hipMemcpy(p, f->d_state[f->cur], (size_t)f->C * sizeof(FmdChanState), hipMemcpyDeviceToHost));
+    p += (size_t)f->C * sizeof(FmdChanState);
+    if (f->Hw) FD_TRY(hipMemcpy(p, f->d_hist[f->cur], (size_t)f->C * f->Hw * 4, hipMemcpyDeviceToHost));
+    return FMD_OK;
+}
+
+int fmd_firdemod_resume(fmd_firdemod* f, const void* blob, size_t size)
+{
+    if (!f || !blob) { fmd_internal_set_err("null argument"); return FMD_ERR_INVALID_ARG; }
+    FdCkptHeader h;
+    if (size < sizeof(h)) { fmd_internal_set_err("checkpoint truncated"); return FMD_ERR_BAD_STATE; }
+    memcpy(&h, blob, sizeof(h));
+    if (h.magic != kFdCkptMagic || h.version != 1u) { fmd_internal_set_err("not a fused-bank checkpoint (magic / version)"); return FMD_ERR_BAD_STATE; }
+    if (h.T != f->T || h.M != f->M || h.C != f->C || h.Hw != f->Hw || h.shift != f->shift || h.taps_hash != f->taps_hash ||
+        h.fast != f->r.fast || h.slow != f->r.slow) {
+        fmd_internal_set_err("checkpoint was taken from a bank with other taps, decimation, shift, rates or channel count");
+        return FMD_ERR_BAD_STATE;
+    }
+    if (size != fd_ckpt_size(f)) { fmd_internal_set_err("checkpoint size does not match its header"); return FMD_ERR_BAD_STATE; }
+    if (h.i0r >= f->r.fr) { fmd_internal_set_err("checkpoint holds a resampler phase outside [0, rate_out / g)"); return FMD_ERR_BAD_STATE; }
+    const uint8_t* p = static_cast<const uint8_t*>(blob) + sizeof(h);
+    const FmdChanState* st = reinterpret_cast<const FmdChanState*>(p);
+    for (uint32_t c = 0; c < f->C; ++c) {
+        FmdChanState s; memcpy(&s, st + c, sizeof(s));
+        if (s.lpr_index_r != h.i0r) { fmd_internal_set_err("checkpoint channel disagrees with the bank's resampler phase"); return FMD_ERR_BAD_STATE; }
+    }
+    FD_ON_DEVICE(f->device);
+    FD_TRY(hipDeviceSynchronize());
+    FD_TRY(hipMemcpy(f->d_state[f->cur], p, (size_t)f->C * sizeof(FmdChanState), hipMemcpyHostToDevice));
+    p += (size_t)f->C * sizeof(FmdChanState);
+    if (f->Hw) FD_TRY(hipMemcpy(f->d_hist[f->cur], p, (size_t)f->C * f->Hw * 4, hipMemcpyHostToDevice));
+    FD_TRY(hipMemset(f->d_exc, 0, 16));
+    FD_TRY(hipDeviceSynchronize());
+    f->pos = h.pos; f->i0r = h.i0r; f->last_K = h.last_K;
     return FMD_OK;
 }
 

@@ -89,6 +89,11 @@ __device__ __forceinline__ uint32_t wave_ror1(uint32_t v)
 {
     return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x13C /* wave_ror:1 */, 0xf, 0xf, false);
 }
+// The same into a register that is dead at the call site (every lane is written: `old` only names the destination).
+__device__ __forceinline__ uint32_t wave_ror1_dead(uint32_t dead, uint32_t v)
+{
+    return (uint32_t)__builtin_amdgcn_update_dpp((int)dead, (int)v, 0x13C /* wave_ror:1 */, 0xf, 0xf, false);
+}
 
 // Sum of one audio group: FA samples plus one optional (low_pass_real, :411-415).
 // (hipcc merges the FA + 1 int16_t loads into ONE ds_read_b64 / b96 / b128 at a 2-byte aligned address.  Round 4 measured
@@ -224,23 +229,38 @@ __device__ __forceinline__ void masked_rounds(const uint32_t* __restrict__ raw_w
         wi[u] = ((u & 1) ? wimB : wimA) & m;
     }
     const int last = cnt - 1;
-    for (int base = (int)wave * RS; base < last; base += NW * RS) {
+    // A lane's window moves D * NW * RS samples = D * NW * RS / 2 dwords per round (NW * RS is even), and its second window
+    // lies 64 D samples = 32 D dwords behind the first: one pointer, advanced by a constant, and a constant offset.
+    const uint32_t* __restrict__ pa = raw_w + (uint32_t)(wofs + ((s00 + D * ((int)wave * RS + (int)lane)) >> 1));
+    // One wave-round; FULL: all 128 windows of the round lie inside the tile, so the stores need no per-lane range test.
+    auto round = [&](int base, auto full_c) {
+        constexpr bool FULL = decltype(full_c)::value;
         const int i1 = base + (int)lane, i2 = i1 + 64;
-        const uint32_t* __restrict__ pa = raw_w + (uint32_t)(wofs + ((s00 + D * i1) >> 1));
-        const uint32_t* __restrict__ pb = raw_w + (uint32_t)(wofs + ((s00 + D * i2) >> 1));
+        const uint32_t* __restrict__ pb = pa + 32 * D;
         int re1 = cre, im1 = cim, re2 = cre, im2 = cim;
+        uint32_t dead1 = 0, dead2 = 0;                       // the last sign-flipped dwords: dead after the dot products
 #pragma unroll
         for (int u = 0; u < NDW; ++u) {
             const uint32_t wa = pa[u] ^ 0x80808080u, wb = pb[u] ^ 0x80808080u;           // u8 -> s8 (b - 128)
-            re1 = sdot4(wa, wr[u], re1); im1 = sdot4(wa, wi[u], im1);
-            re2 = sdot4(wb, wr[u], re2); im2 = sdot4(wb, wi[u], im2);
+            if (u == 0) {
+                re1 = sdot4_init(wa, wr[0], cre); im1 = sdot4_init(wa, wi[0], cim);
+                re2 = sdot4_init(wb, wr[0], cre); im2 = sdot4_init(wb, wi[0], cim);
+            } else {
+                re1 = sdot4(wa, wr[u], re1); im1 = sdot4(wa, wi[u], im1);
+                re2 = sdot4(wb, wr[u], re2); im2 = sdot4(wb, wi[u], im2);
+            }
+            dead1 = wa; dead2 = wb;
         }
         const uint32_t pk1 = pack_lp_perm(re1, im1), pk2 = pack_lp_perm(re2, im2);
-        const uint32_t prev1 = wave_shr1(pk1);
-        const uint32_t prev2 = wave_shr1_old(wave_ror1(pk1), pk2);
-        if (lane > 0 && i1 < cnt) d16[i1] = (int16_t)(smallD ? disc_f32<BIAS>(pk1, prev1) : disc_nosel(pk1, prev1));   // smallD: wave-uniform
-        if (i2 < cnt) d16[i2] = (int16_t)(smallD ? disc_f32<BIAS>(pk2, prev2) : disc_nosel(pk2, prev2));
-    }
+        const uint32_t prev1 = wave_shr1_dead(dead1, pk1);                                  // lane 0's is never used
+        const uint32_t prev2 = wave_shr1_old(wave_ror1_dead(dead2, pk1), pk2);               // lane 0 <- first window of lane 63
+        if (lane > 0 && (FULL || i1 < cnt)) d16[i1] = (int16_t)(smallD ? disc_f32<BIAS>(pk1, prev1) : disc_nosel(pk1, prev1));   // smallD: wave-uniform
+        if (FULL || i2 < cnt) d16[i2] = (int16_t)(smallD ? disc_f32<BIAS>(pk2, prev2) : disc_nosel(pk2, prev2));
+        pa += D * (NW * RS / 2);
+    };
+    int base = (int)wave * RS;
+    for (; base + 128 <= cnt; base += NW * RS) round(base, std::true_type{});
+    for (; base < last; base += NW * RS) round(base, std::false_type{});
 }
 
 // ---- register-streaming rounds (fmd_demod_stream_kernel) ------------------------------------------------------------
@@ -317,10 +337,15 @@ __device__ __forceinline__ void stream_pair_rounds(const unsigned char* __restri
 #pragma unroll
         for (int u = 0; u < DH; ++u) {
             const uint32_t wa = w[u] ^ 0x80808080u, wb = w[u + DH] ^ 0x80808080u;    // u8 -> s8 (b - 128)
-            re1 = sdot4(wa, (u & 1) ? r1B : r1A, re1);
-            im1 = sdot4(wa, (u & 1) ? m1B : m1A, im1);
-            re2 = sdot4(wb, (u & 1) ? r2B : r2A, re2);
-            im2 = sdot4(wb, (u & 1) ? m2B : m2A, im2);
+            if (u == 0) {
+                re1 = sdot4_init(wa, r1A, re1); im1 = sdot4_init(wa, m1A, im1);
+                re2 = sdot4_init(wb, r2A, re2); im2 = sdot4_init(wb, m2A, im2);
+            } else {
+                re1 = sdot4(wa, (u & 1) ? r1B : r1A, re1);
+                im1 = sdot4(wa, (u & 1) ? m1B : m1A, im1);
+                re2 = sdot4(wb, (u & 1) ? r2B : r2A, re2);
+                im2 = sdot4(wb, (u & 1) ? m2B : m2A, im2);
+            }
             dead1 = wa; dead2 = wb;
         }
         const float ar1 = sum_to_f32(re1), ai1 = sum_to_f32(im1), ar2 = sum_to_f32(re2), ai2 = sum_to_f32(im2);
@@ -430,20 +455,30 @@ __device__ __forceinline__ void tile_body(const FmdLaunch& L, const TileCtx& X, 
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
                     const uint32_t wa = a4[u] ^ 0x80808080u, wb = b4[u] ^ 0x80808080u;    // u8 -> s8 (b - 128)
-                    re1 = sdot4(wa, (u & 1) ? r1B : r1A, re1);
-                    im1 = sdot4(wa, (u & 1) ? m1B : m1A, im1);
-                    re2 = sdot4(wb, (u & 1) ? r2B : r2A, re2);
-                    im2 = sdot4(wb, (u & 1) ? m2B : m2A, im2);
+                    if (u == 0) {
+                        re1 = sdot4_init(wa, r1A, re1); im1 = sdot4_init(wa, m1A, im1);
+                        re2 = sdot4_init(wb, r2A, re2); im2 = sdot4_init(wb, m2A, im2);
+                    } else {
+                        re1 = sdot4(wa, (u & 1) ? r1B : r1A, re1);
+                        im1 = sdot4(wa, (u & 1) ? m1B : m1A, im1);
+                        re2 = sdot4(wb, (u & 1) ? r2B : r2A, re2);
+                        im2 = sdot4(wb, (u & 1) ? m2B : m2A, im2);
+                    }
                     dead1 = wa; dead2 = wb;
                 }
             } else {
 #pragma unroll
                 for (int u = 0; u < (DH > 0 ? DH : 1); ++u) {
                     const uint32_t wa = pa[u] ^ 0x80808080u, wb = pa[u + DH] ^ 0x80808080u;   // u8 -> s8 (b - 128)
-                    re1 = sdot4(wa, (u & 1) ? r1B : r1A, re1);
-                    im1 = sdot4(wa, (u & 1) ? m1B : m1A, im1);
-                    re2 = sdot4(wb, (u & 1) ? r2B : r2A, re2);
-                    im2 = sdot4(wb, (u & 1) ? m2B : m2A, im2);
+                    if (u == 0) {
+                        re1 = sdot4_init(wa, r1A, re1); im1 = sdot4_init(wa, m1A, im1);
+                        re2 = sdot4_init(wb, r2A, re2); im2 = sdot4_init(wb, m2A, im2);
+                    } else {
+                        re1 = sdot4(wa, (u & 1) ? r1B : r1A, re1);
+                        im1 = sdot4(wa, (u & 1) ? m1B : m1A, im1);
+                        re2 = sdot4(wb, (u & 1) ? r2B : r2A, re2);
+                        im2 = sdot4(wb, (u & 1) ? m2B : m2A, im2);
+                    }
                     dead1 = wa; dead2 = wb;
                 }
             }
@@ -472,10 +507,15 @@ __device__ __forceinline__ void tile_body(const FmdLaunch& L, const TileCtx& X, 
 #pragma unroll
                 for (int u = 0; u < (DH > 0 ? DH : 1); ++u) {
                     const uint32_t wa = pa[u] ^ 0x80808080u, wb = pb[u] ^ 0x80808080u;   // u8 -> s8 (b - 128)
-                    re1 = sdot4(wa, (u & 1) ? wreB : wreA, re1);
-                    im1 = sdot4(wa, (u & 1) ? wimB : wimA, im1);
-                    re2 = sdot4(wb, (u & 1) ? wreB : wreA, re2);
-                    im2 = sdot4(wb, (u & 1) ? wimB : wimA, im2);
+                    if (u == 0) {
+                        re1 = sdot4_init(wa, wreA, DH); im1 = sdot4_init(wa, wimA, im0);
+                        re2 = sdot4_init(wb, wreA, DH); im2 = sdot4_init(wb, wimA, im0);
+                    } else {
+                        re1 = sdot4(wa, (u & 1) ? wreB : wreA, re1);
+                        im1 = sdot4(wa, (u & 1) ? wimB : wimA, im1);
+                        re2 = sdot4(wb, (u & 1) ? wreB : wreA, re2);
+                        im2 = sdot4(wb, (u & 1) ? wimB : wimA, im2);
+                    }
                 }
             }
             const uint32_t pk1 = pack_lp_perm(re1, im1), pk2 = pack_lp_perm(re2, im2);

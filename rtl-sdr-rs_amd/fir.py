@@ -112,6 +112,18 @@ class FirDemodBank:
         check(lib().fmd_firdemod_get_state(self._h, channel, C.byref(s)))
         return s
 
+    def checkpoint(self):
+        """The whole bank's carried state (position, resampler phase, per-channel accumulator / last output / filter history)
+        as bytes; `resume` on a bank with the same taps, decimation, shift, rates and channel count continues bit for bit."""
+        n = lib().fmd_firdemod_checkpoint_size(self._h)
+        buf = C.create_string_buffer(n)
+        check(lib().fmd_firdemod_checkpoint(self._h, buf, n))
+        return buf.raw
+
+    def resume(self, blob):
+        blob = bytes(blob)
+        check(lib().fmd_firdemod_resume(self._h, blob, len(blob)))
+
     def f64_stats(self):
         g, p = C.c_uint64(), C.c_uint64()
         check(lib().fmd_firdemod_f64_stats(self._h, C.byref(g), C.byref(p)))

@@ -127,6 +127,9 @@ extern "C" {
     pub fn fmd_firdemod_demodulate_device(f: *mut fmd_firdemod, d_iq: *const c_void, nbytes: usize, d_out: *mut c_void, out_cap: usize, out_len_each: *mut usize, stream: *mut c_void) -> c_int;
     pub fn fmd_firdemod_check(f: *mut fmd_firdemod) -> c_int;
     pub fn fmd_firdemod_get_state(f: *mut fmd_firdemod, channel: u32, state: *mut DemodState) -> c_int;
+    pub fn fmd_firdemod_checkpoint_size(f: *const fmd_firdemod) -> usize;
+    pub fn fmd_firdemod_checkpoint(f: *mut fmd_firdemod, blob: *mut c_void, cap: usize) -> c_int;
+    pub fn fmd_firdemod_resume(f: *mut fmd_firdemod, blob: *const c_void, size: usize) -> c_int;
     pub fn fmd_firdemod_f64_stats(f: *const fmd_firdemod, guarded: *mut u64, patched: *mut u64) -> c_int;
     pub fn fmd_firdemod_tiling(f: *const fmd_firdemod, audio_per_tile: *mut u32, lds_bytes: *mut u32) -> c_int;
     pub fn fmd_firdemod_kernel_name(f: *const fmd_firdemod, name: *mut c_char, cap: usize) -> c_int;

@@ -225,3 +225,55 @@ def test_gpu_fused_fuzz(fmd, oracle):
             assert state_tuple(fd.get_state(c).as_dict()) == state_tuple(oracle.firdemod_state(hs[c])), (case, c)
             oracle.lib.fmo_firdemod_free(hs[c])
         fd.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("T,M,fast,slow", [(127, 8, 2500000, 48000), (33, 4, 250000, 48000), (64, 16, 1000000, 44100), (1, 2, 48000, 48000)])
+def test_gpu_fused_checkpoint_resume(fmd, oracle, T, M, fast, slow):
+    """The bank as a whole is the unit of checkpoint / resume (its channels advance together): a fresh bank resumed from
+    the blob continues bit for bit as the original and as the oracle fed the uninterrupted stream; a blob from another
+    filter, a truncated or a damaged one is refused (FMD_ERR_BAD_STATE = -7) and leaves the bank as it was."""
+    rng = np.random.default_rng(T * 7 + M)
+    taps = rng.integers(-2047, 2048, T).astype(np.int16)
+    shift = fmd.auto_shift(taps, 2048)
+    nch = 9
+    a = fmd.FirDemodBank(taps, M, fast, slow, nch, shift=shift)
+    hs = [oracle.firdemod_new(taps, M, shift, fast, slow) for _ in range(nch)]
+    sizes = [8 * int(rng.integers(T // 4 + 2 * M + 4, 900)) for _ in range(5)]
+    blocks = [rng.integers(0, 256, (nch, n), dtype=np.uint8) for n in sizes]
+    for iq in blocks[:2]:
+        got = a.demodulate_batch(iq)
+        for c in range(nch):
+            assert np.array_equal(got[c], oracle.firdemod(hs[c], iq[c])), c
+    blob = a.checkpoint()
+    assert len(blob) == 56 + nch * 32 + nch * 4 * ((T - 1 + ((T - 1) & 1)) // 2)   # header + FmdChanState + history words
+    b = fmd.FirDemodBank(taps, M, fast, slow, nch, shift=shift)
+    b.resume(blob)
+    for c in range(nch):
+        assert b.get_state(c).as_dict() == a.get_state(c).as_dict()
+    for iq in blocks[2:]:
+        ga, gb = a.demodulate_batch(iq), b.demodulate_batch(iq)
+        for c in range(nch):
+            exp = oracle.firdemod(hs[c], iq[c])
+            assert np.array_equal(ga[c], exp) and np.array_equal(gb[c], exp), c
+    for c in range(nch):
+        assert state_tuple(b.get_state(c).as_dict()) == state_tuple(oracle.firdemod_state(hs[c]))
+        oracle.lib.fmo_firdemod_free(hs[c])
+    assert b.checkpoint() == a.checkpoint()
+
+    # refusals: nothing of the bank changes
+    before = b.checkpoint()
+    other = fmd.FirDemodBank(np.where(taps > 0, taps - 1, taps + 1).astype(np.int16), M, fast, slow, nch, shift=shift)
+    fewer = fmd.FirDemodBank(taps, M, fast, slow, nch - 1, shift=shift)
+    bad_magic = b"\0" + blob[1:]
+    bad_phase = bytearray(blob); bad_phase[56 + 4] ^= 1                  # channel 0's lpr_index_r
+    for target, data in [(other, blob), (fewer, blob), (b, blob[:-4]), (b, blob + b"\0\0\0\0"), (b, blob[:20]), (b, bad_magic),
+                         (b, bytes(bad_phase))]:
+        with pytest.raises(fmd.FmdError) as ei:
+            target.resume(data)
+        assert ei.value.status == -7, ei.value
+    assert b.checkpoint() == before
+    # a resumed-then-reset bank is a fresh one
+    b.reset()
+    c0 = fmd.FirDemodBank(taps, M, fast, slow, nch, shift=shift)
+    assert b.checkpoint() == c0.checkpoint()
