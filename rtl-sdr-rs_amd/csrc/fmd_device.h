@@ -235,13 +235,8 @@ __device__ __forceinline__ int disc_f32_xy(float xf, float yf)
 // rides in the accumulator's initial value, a v_mov either way -- reads as the f32 12582912 + v exactly for |v| < 2^22, and
 // one f32 subtract (2 cycles) takes the bias off.  Used for the window sums of the adjacent-window rounds (|lp| <= 128 * 14)
 // and, with BIAS, for the complex product of packed samples up to downsample 11 (|c| <= 2 (128 * 11)^2 < 2^22).
-#ifdef FMD_NO_BIAS
-constexpr int kSumBias = 0;
-__device__ __forceinline__ float sum_to_f32(int v) { return (float)v; }
-#else
 constexpr int kSumBias = 0x4B400000;
 __device__ __forceinline__ float sum_to_f32(int biased) { return u2f((uint32_t)biased) - 12582912.0f; }
-#endif
 
 template <bool BIAS = false>
 __device__ __forceinline__ int disc_f32(uint32_t a, uint32_t b)

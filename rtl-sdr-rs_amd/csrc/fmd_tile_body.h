@@ -231,12 +231,15 @@ __device__ __forceinline__ void masked_rounds(const uint32_t* __restrict__ raw_w
     const int last = cnt - 1;
     // A lane's window moves D * NW * RS samples = D * NW * RS / 2 dwords per round (NW * RS is even), and its second window
     // lies 64 D samples = 32 D dwords behind the first: one pointer, advanced by a constant, and a constant offset.
+    // (`ds_read2_b32` carries dword offsets up to 255: beyond downsample 7 the second window gets a pointer of its own.)
     const uint32_t* __restrict__ pa = raw_w + (uint32_t)(wofs + ((s00 + D * ((int)wave * RS + (int)lane)) >> 1));
+    const bool far = 32 * D + NDW > 256;
+    const uint32_t* __restrict__ pb_far = pa + 32 * D;
     // One wave-round; FULL: all 128 windows of the round lie inside the tile, so the stores need no per-lane range test.
     auto round = [&](int base, auto full_c) {
         constexpr bool FULL = decltype(full_c)::value;
         const int i1 = base + (int)lane, i2 = i1 + 64;
-        const uint32_t* __restrict__ pb = pa + 32 * D;
+        const uint32_t* __restrict__ pb = far ? pb_far : pa + 32 * D;
         int re1 = cre, im1 = cim, re2 = cre, im2 = cim;
         uint32_t dead1 = 0, dead2 = 0;                       // the last sign-flipped dwords: dead after the dot products
 #pragma unroll
@@ -257,6 +260,7 @@ __device__ __forceinline__ void masked_rounds(const uint32_t* __restrict__ raw_w
         if (lane > 0 && (FULL || i1 < cnt)) d16[i1] = (int16_t)(smallD ? disc_f32<BIAS>(pk1, prev1) : disc_nosel(pk1, prev1));   // smallD: wave-uniform
         if (FULL || i2 < cnt) d16[i2] = (int16_t)(smallD ? disc_f32<BIAS>(pk2, prev2) : disc_nosel(pk2, prev2));
         pa += D * (NW * RS / 2);
+        if (far) pb_far += D * (NW * RS / 2);
     };
     int base = (int)wave * RS;
     for (; base + 128 <= cnt; base += NW * RS) round(base, std::true_type{});
