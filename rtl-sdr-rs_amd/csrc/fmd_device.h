@@ -176,10 +176,12 @@ __device__ __forceinline__ int disc_nosel(uint32_t a, uint32_t b)
 //     multiple of 2^20 -- never a tie, s is an integer -- and subtracting it again leaves k * 2^20, k = floor(s / 2^20 + 1/2).
 //     THIS step sets the limit: s + 0.5 must be representable, i.e. |s| <= 2^23 (downsample 18 fails here: an odd
 //     multiple of 2^19 above 2^23 loses its + 0.5 and the big add becomes a tie)
-//   q = floor(4096 |sp| / den): the estimate uses 4096 (1 - 2^-21) so that rcp's ulp and two roundings (2^-22 in all)
-//     can only make it too SMALL, by < 0.004: floor() is q or q - 1; the remainder n4 - qf * den lies in [0, 2 den) and
-//     ONE fma returns it exactly while it is below 2^24 -- which covers every remainder < den -- and rounded but still
-//     >= 2^24 > den - 1 otherwise; a clamped subtract turns `remainder >= den` into the +1
+//   q = floor(Q), Q = 4096 |sp| / den <= 4096: m = 4096 |sp| is exact (<= 2^31, a power-of-two scale); m * rcp(den) is within
+//     2^-10 of Q (rcp's ulp + one rounding, 2^-22 relative), so its NEAREST integer k is floor(Q) or floor(Q) + 1, and
+//     which one shows in the sign of the integer k * den - m (in (-den, 0] for floor(Q), in [1, den] for one too
+//     large): ONE fma with the clamp modifier returns exactly that 0 / 1 (the product is exact inside the fma; a result
+//     rounded above 2^24 keeps its sign and stays >= 1), and q = k - it.  (Rounds 1 - 3 biased the estimate low, took
+//     floor() and compared the remainder with den: three instructions more.)
 //   the sign of the truncating quotient is sp's, the base angle is 8192 - (+-4096) by the sign of x, the result takes
 //     y's sign; (0, 0) -> den = 0 -> the final factor clamp(den + den) is 0 (:388), 1 otherwise.
 // tests/test_disc_f32_model.py replays this sequence in numpy f32 with the reciprocal pushed to both ends of its
@@ -217,14 +219,13 @@ __device__ __forceinline__ int disc_f32_xy(float xf, float yf)
     const float s = u2f(f2u(t) ^ sx);
     const float big = 13194139533312.0f;                                 // 1.5 * 2^43
     const float sp = NOWRAP ? s : s - (((s + 0.5f) + big) - big);        // s mod 2^20, signed
-    // (0, 0): den = 0 -> rcp = inf, |sp| * inf = 0 * inf = NaN, and NaN runs through floor / fma / the clamped subtract /
-    // the sign xors to the final conversion, where v_cvt_i32_f32 turns it into 0 -- exactly fast_atan2's `(0, 0) -> 0`
-    // (:388).  Three instructions fewer than guarding the reciprocal and multiplying by a 0 / 1 factor
-    // (tests: test_near_silence, test_gpu_fuzz silence cases, tests/test_disc_f32_model.py for den >= 1).
-    const float c = __builtin_amdgcn_rcpf(den) * 4095.998046875f;
-    const float qf = __builtin_floorf(__builtin_fabsf(sp) * c);
-    const float r = __builtin_fmaf(-qf, den, __builtin_fabsf(sp) * 4096.0f);
-    const float q = qf + clamp01(r - (den - 1.0f));
+    // (0, 0): den = 0 -> rcp = inf, m * inf = 0 * inf = NaN, and NaN runs through the rounding / the subtract (whatever the
+    // clamped fma makes of it) / the sign xors to the final conversion, where v_cvt_i32_f32 turns it into 0 -- exactly
+    // fast_atan2's `(0, 0) -> 0` (:388).  Three instructions fewer than guarding the reciprocal and multiplying by a
+    // 0 / 1 factor (tests: test_near_silence, test_gpu_fuzz silence cases, tests/test_disc_f32_model.py for den >= 1).
+    const float m = __builtin_fabsf(sp) * 4096.0f;
+    const float k = __builtin_rintf(m * __builtin_amdgcn_rcpf(den));
+    const float q = k - clamp01(__builtin_fmaf(k, den, -m));
     const float qs = u2f(f2u(q) ^ (f2u(sp) & 0x80000000u));
     const float base = 8192.0f - u2f(0x45800000u ^ sx);                  // 4096 or 12288 (:395,400)
     const float res = u2f(f2u(base - qs) ^ (f2u(yf) & 0x80000000u));
@@ -252,21 +253,24 @@ __device__ __forceinline__ int disc_f32(uint32_t a, uint32_t b)
     return disc_f32_xy((float)sdot2(a, b), (float)sdot2(a_sw, b_cj));
 }
 
-// The same with the samples' components already in f32 (exact integers): c = a * conj(b) by two multiplies and two
-// fmas -- every product is below 2^22 and every sum below 2^23 for downsample <= 16, so nothing rounds -- instead of
-// pack, swap, conjugate, two dot products and two conversions.
+// The same with the samples' components already in f32 (exact integers): c = a * conj(b) by four fmas -- every product
+// is below 2^22 and every sum below 2^23 for downsample <= 16, so nothing rounds -- instead of pack, swap, conjugate, two
+// dot products and two conversions.
 template <bool NOWRAP = false>
 __device__ __forceinline__ int disc_f32_c(float ar, float ai, float br, float bi)
 {
-    // + 0.0f: a product such as 0 * -5 is -0, and (-0) + (-0) stays -0; fast_atan2 takes its signs from x < 0 / y < 0,
-    // where zero is not negative, and disc_f32_xy reads sign BITS (tests/test_gpu_parity.py::test_near_silence)
+    // A product such as 0 * -5 is -0, and (-0) + (-0) stays -0; fast_atan2 takes its signs from x < 0 / y < 0, where zero
+    // is not negative, and disc_f32_xy reads sign BITS (tests/test_gpu_parity.py::test_near_silence)
     // (x too: with x = -0 the sign-bit form takes fast_atan2's "x < 0" branch, which agrees with the "x >= 0" one at x = 0 only
     //  while `(4096 * s) as i32` does not wrap: (x, y) = (-0, 2^19) -- a = (0, -768), b = (-768, 0) at downsample 6 -- would
     //  come out as 16384 instead of 8192.)
-    // (Round 4 measured the product as two v_pk_fma_f32 -- t = (ar br + 0, -ar bi + 0), c = (ai bi, ai br) + t, the + 0 inside
-    //  the first fma doing the canonicalisation: 4 instructions instead of 6, bit-exact, and equal to 1 % slower: not adopted.)
-    const float xf = __builtin_fmaf(ai, bi, ar * br) + 0.0f;        // ar*br + ai*bi
-    const float yf = __builtin_fmaf(ai, br, -(ar * bi)) + 0.0f;     // ai*br - ar*bi
+    // So the first product of each component is an fma onto +0.0: (-0) + (+0) = +0, the second fma then adds to a value
+    // that is never -0, and an exact cancellation gives +0 in round-to-nearest.  Four instructions; rounds 2 - 3 had
+    // mul, fma, mul, fma and `+ 0.0f` twice (session r04r: -0.3 % at downsample 6, -1.3 % at 4, -1.6 % at 2).
+    // (Round 4 also measured two v_pk_fma_f32 -- t = (ar br + 0, -ar bi + 0), c = (ai bi, ai br) + t: bit-exact, equal to
+    //  1 % slower than the six-instruction form: not adopted.)
+    const float xf = __builtin_fmaf(ai, bi, __builtin_fmaf(ar, br, 0.0f));       // ar*br + ai*bi
+    const float yf = __builtin_fmaf(ai, br, __builtin_fmaf(-ar, bi, 0.0f));      // ai*br - ar*bi
     return disc_f32_xy<NOWRAP>(xf, yf);
 }
 

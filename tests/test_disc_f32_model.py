@@ -44,15 +44,14 @@ def disc_f32_model(x, y, rcp_ulps):
     rc = (1.0 / d.astype(np.float64)).astype(F)
     for _ in range(abs(rcp_ulps)):
         rc = np.nextafter(rc, F(np.inf) if rcp_ulps > 0 else F(0))
-    c = rc * F(4095.998046875)
-    qf = np.floor(np.abs(sp) * c)
-    n4 = np.abs(sp) * F(4096.0)
-    r_exact = n4.astype(np.float64) - qf.astype(np.float64) * den.astype(np.float64)
-    r = r_exact.astype(F)                                       # one fma: exact product and sum, one rounding
-    small = r_exact < 2.0 ** 24                                 # every remainder below den (< 2^24) comes back exactly
-    assert np.all(r.astype(np.float64)[small] == r_exact[small]), "fma not exact below 2^24"
-    assert np.all(r[~small] >= F(2.0 ** 24))                    # the rounded ones are still >= den
-    q = qf + np.clip(r - (den - F(1.0)), F(0), F(1))
+    m = np.abs(sp) * F(4096.0)                                  # exact: a power-of-two scale, <= 2^31
+    k = np.rint(m * rc)                                         # v_rndne_f32 of one f32 product
+    nz = den > 0
+    assert np.all(np.abs(k.astype(np.float64)[nz] - m.astype(np.float64)[nz] / den.astype(np.float64)[nz]) < 0.5 + 4096 * (abs(rcp_ulps) + 2) * 2.0 ** -23)
+    d_exact = k.astype(np.float64) * den.astype(np.float64) - m.astype(np.float64)   # integer, |.| <= den < 2^24.5: exact in f64
+    d = d_exact.astype(F)                                       # one fma: exact product and sum, one rounding
+    assert np.all((d >= F(1)) == (d_exact >= 1)) and np.all((d <= F(0)) == (d_exact <= 0))
+    q = k - np.clip(d, F(0), F(1))                              # the fma's clamp modifier
     qs = (q.view(np.uint32) ^ (sp.view(np.uint32) & np.uint32(0x80000000))).view(F)
     base = F(8192.0) - (np.uint32(0x45800000) ^ sx).view(F)
     res = ((base - qs).view(np.uint32) ^ (yf.view(np.uint32) & np.uint32(0x80000000))).view(F)
@@ -112,7 +111,7 @@ def test_reference_formula_matches_oracle(oracle):
     assert oracle.lib.fmo_fast_atan2(0, 524288) == 8192 and oracle.lib.fmo_fast_atan2(0, 524287) == 0
 
 
-@pytest.mark.parametrize("rcp_ulps", [-2, -1, 0, 1, 2])     # v_rcp_f32 is specified to 1 ulp; 2 shows the margin
+@pytest.mark.parametrize("rcp_ulps", [-64, -2, -1, 0, 1, 2, 64])     # v_rcp_f32 is specified to 1 ulp; the nearest-integer form has margin to spare
 def test_f32_discriminator_is_exact(rcp_ulps):
     x, y = cases()
     assert x.size > 800000
