@@ -239,7 +239,7 @@ __device__ __forceinline__ int disc_f32_xy(float xf, float yf)
 constexpr int kSumBias = 0x4B400000;
 __device__ __forceinline__ float sum_to_f32(int biased) { return u2f((uint32_t)biased) - 12582912.0f; }
 
-template <bool BIAS = false>
+template <bool BIAS = false, bool NOWRAP = false>
 __device__ __forceinline__ int disc_f32(uint32_t a, uint32_t b)
 {
     const uint32_t a_sw = __builtin_amdgcn_alignbit(a, a, 16);          // (im, re)
@@ -248,9 +248,9 @@ __device__ __forceinline__ int disc_f32(uint32_t a, uint32_t b)
         // (clamp bit set: the three-address v_dot2_i32_i16 with the bias as a source, no v_mov of it first -- see sdot4_init)
         const int cr = __builtin_amdgcn_sdot2(__builtin_bit_cast(fmd_s2, a), __builtin_bit_cast(fmd_s2, b), kSumBias, true);
         const int ci = __builtin_amdgcn_sdot2(__builtin_bit_cast(fmd_s2, a_sw), __builtin_bit_cast(fmd_s2, b_cj), kSumBias, true);
-        return disc_f32_xy(sum_to_f32(cr), sum_to_f32(ci));
+        return disc_f32_xy<NOWRAP>(sum_to_f32(cr), sum_to_f32(ci));
     }
-    return disc_f32_xy((float)sdot2(a, b), (float)sdot2(a_sw, b_cj));
+    return disc_f32_xy<NOWRAP>((float)sdot2(a, b), (float)sdot2(a_sw, b_cj));
 }
 
 // The same with the samples' components already in f32 (exact integers): c = a * conj(b) by four fmas -- every product

@@ -216,7 +216,7 @@ __device__ __forceinline__ void tile_exc_flush(const FmdLaunch& L, const TileCtx
 // into 2 * NDW per-lane weight registers and the body is the same 3 VALU instructions per dword as the whole-dword
 // loop -- no run-time trip counts, no per-dword branches.  (Round 1 ran these through the run-time loop below:
 // downsample 7 sat at 57 % of the HBM spec against 70 % for 6 and 8.)
-template <int NDW, bool BIAS>
+template <int NDW, bool BIAS, bool NOWRAP>
 __device__ __forceinline__ void masked_rounds(const uint32_t* __restrict__ raw_w, int16_t* __restrict__ d16, int wofs, int s00,
                                               int D, int cnt, uint32_t lane, uint32_t wave, uint32_t wreA, uint32_t wreB,
                                               uint32_t wimA, uint32_t wimB, uint32_t mf, uint32_t ml, int cre, int cim, bool smallD)
@@ -257,8 +257,8 @@ __device__ __forceinline__ void masked_rounds(const uint32_t* __restrict__ raw_w
         const uint32_t pk1 = pack_lp_perm(re1, im1), pk2 = pack_lp_perm(re2, im2);
         const uint32_t prev1 = wave_shr1_dead(dead1, pk1);                                  // lane 0's is never used
         const uint32_t prev2 = wave_shr1_old(wave_ror1_dead(dead2, pk1), pk2);               // lane 0 <- first window of lane 63
-        if (lane > 0 && (FULL || i1 < cnt)) d16[i1] = (int16_t)(smallD ? disc_f32<BIAS>(pk1, prev1) : disc_nosel(pk1, prev1));   // smallD: wave-uniform
-        if (FULL || i2 < cnt) d16[i2] = (int16_t)(smallD ? disc_f32<BIAS>(pk2, prev2) : disc_nosel(pk2, prev2));
+        if (lane > 0 && (FULL || i1 < cnt)) d16[i1] = (int16_t)(smallD ? disc_f32<BIAS, NOWRAP>(pk1, prev1) : disc_nosel(pk1, prev1));   // smallD: wave-uniform
+        if (FULL || i2 < cnt) d16[i2] = (int16_t)(smallD ? disc_f32<BIAS, NOWRAP>(pk2, prev2) : disc_nosel(pk2, prev2));
         pa += D * (NW * RS / 2);
         if (far) pb_far += D * (NW * RS / 2);
     };
@@ -573,8 +573,10 @@ __device__ __forceinline__ void tile_body(const FmdLaunch& L, const TileCtx& X, 
         }
         // compile-time dword counts (see masked_rounds); anything else runs the general loop below
         // (products of the packed samples stay below 2^22 up to downsample 11: the biased int -> f32 form of fmd_device.h)
+        // (downsample <= 3: |s| <= 2 (128 * 3)^2 < 2^19, `(4096 * s) as i32` cannot wrap: four instructions fewer per sample)
         constexpr bool kBiasOk = (DH < 0 && -DH <= 11) || (DH > 0 && 2 * DH <= 11);
-#define FMD_MASKED(N) case N: masked_rounds<N, kBiasOk>(raw_w, d16, wofs, s00, D, cnt, lane, wave, wreA, wreB, wimA, wimB, mf, ml, cre, cim, smallD); break
+        constexpr bool kNoWrap = (DH < 0 && -DH <= 3) || DH == 1;
+#define FMD_MASKED(N) case N: masked_rounds<N, kBiasOk, kNoWrap>(raw_w, d16, wofs, s00, D, cnt, lane, wave, wreA, wreB, wimA, wimB, mf, ml, cre, cim, smallD); break
         bool done = false;
         // (the catch-all kernel, DH == 0, only sees downsample >= 16 once every smaller factor has a kernel of its own:
         //  windows of 9 dwords and more, none of the compile-time counts below)
