@@ -180,14 +180,12 @@ __device__ __forceinline__ fir_i4 virt_chunk(const FirLaunch& L, uint32_t c, uin
 
 // Cache policy of the staging loads (aux of global_load_lds): 2 = nt -- the stream is read once.  Measured on
 // config 4: 0.1369 ms vs 0.1440 ms with the default policy (-5 %); nontemporal output stores on top of it: +1.4 %.
-#ifndef FIR_DMA_AUX
-#define FIR_DMA_AUX 2
-#endif
+constexpr int kFirDmaAux = 2;
 
 __device__ __forceinline__ void fir_dma16(const unsigned char* g, unsigned char* lds_wave_base)
 {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
-                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, FIR_DMA_AUX);
+                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, kFirDmaAux);
 }
 
 // SWZ (decim == 8, columns 64 bytes apart): a fragment read puts lanes (j, q) at 64*j + 16*q, and the four
