@@ -210,7 +210,7 @@ __device__ __forceinline__ uint32_t f2u(float f) { return __builtin_bit_cast(uin
 
 // fast_atan2 (:383-405) of the exact f32 product (xf, yf) = a * conj(b); see above.
 // NOWRAP: the caller guarantees |s| < 2^19 (downsample <= 3: 2 (128 * 3)^2 = 294 912), where `(4096 * s) as i32` cannot wrap.
-template <bool NOWRAP = false>
+template <bool NOWRAP = false, bool LO16 = false>
 __device__ __forceinline__ int disc_f32_xy(float xf, float yf)
 {
     const float den = __builtin_fabsf(xf) + __builtin_fabsf(yf);
@@ -229,6 +229,10 @@ __device__ __forceinline__ int disc_f32_xy(float xf, float yf)
     const float qs = u2f(f2u(q) ^ (f2u(sp) & 0x80000000u));
     const float base = 8192.0f - u2f(0x45800000u ^ sx);                  // 4096 or 12288 (:395,400)
     const float res = u2f(f2u(base - qs) ^ (f2u(yf) & 0x80000000u));
+    // LO16: the caller stores the result as i16 and nothing else: adding 1.5 * 2^23 leaves the integer in the low mantissa
+    // bits (two's complement, |res| <= 16384) -- a 2-cycle add where the conversion takes 4.  The NaN of (0, 0) keeps the
+    // payload the hardware gave it (0x..C00000: low 16 bits zero) through the add, so it still stores 0.
+    if constexpr (LO16) return (int)f2u(res + 12582912.0f);
     return fmd_cvt_i32_nan0(res);
 }
 
@@ -239,7 +243,7 @@ __device__ __forceinline__ int disc_f32_xy(float xf, float yf)
 constexpr int kSumBias = 0x4B400000;
 __device__ __forceinline__ float sum_to_f32(int biased) { return u2f((uint32_t)biased) - 12582912.0f; }
 
-template <bool BIAS = false, bool NOWRAP = false>
+template <bool BIAS = false, bool NOWRAP = false, bool LO16 = false>
 __device__ __forceinline__ int disc_f32(uint32_t a, uint32_t b)
 {
     const uint32_t a_sw = __builtin_amdgcn_alignbit(a, a, 16);          // (im, re)
@@ -248,15 +252,15 @@ __device__ __forceinline__ int disc_f32(uint32_t a, uint32_t b)
         // (clamp bit set: the three-address v_dot2_i32_i16 with the bias as a source, no v_mov of it first -- see sdot4_init)
         const int cr = __builtin_amdgcn_sdot2(__builtin_bit_cast(fmd_s2, a), __builtin_bit_cast(fmd_s2, b), kSumBias, true);
         const int ci = __builtin_amdgcn_sdot2(__builtin_bit_cast(fmd_s2, a_sw), __builtin_bit_cast(fmd_s2, b_cj), kSumBias, true);
-        return disc_f32_xy<NOWRAP>(sum_to_f32(cr), sum_to_f32(ci));
+        return disc_f32_xy<NOWRAP, LO16>(sum_to_f32(cr), sum_to_f32(ci));
     }
-    return disc_f32_xy<NOWRAP>((float)sdot2(a, b), (float)sdot2(a_sw, b_cj));
+    return disc_f32_xy<NOWRAP, LO16>((float)sdot2(a, b), (float)sdot2(a_sw, b_cj));
 }
 
 // The same with the samples' components already in f32 (exact integers): c = a * conj(b) by four fmas -- every product
 // is below 2^22 and every sum below 2^23 for downsample <= 16, so nothing rounds -- instead of pack, swap, conjugate, two
 // dot products and two conversions.
-template <bool NOWRAP = false>
+template <bool NOWRAP = false, bool LO16 = false>
 __device__ __forceinline__ int disc_f32_c(float ar, float ai, float br, float bi)
 {
     // A product such as 0 * -5 is -0, and (-0) + (-0) stays -0; fast_atan2 takes its signs from x < 0 / y < 0, where zero
@@ -271,7 +275,7 @@ __device__ __forceinline__ int disc_f32_c(float ar, float ai, float br, float bi
     //  1 % slower than the six-instruction form: not adopted.)
     const float xf = __builtin_fmaf(ai, bi, __builtin_fmaf(ar, br, 0.0f));       // ar*br + ai*bi
     const float yf = __builtin_fmaf(ai, br, __builtin_fmaf(-ar, bi, 0.0f));      // ai*br - ar*bi
-    return disc_f32_xy<NOWRAP>(xf, yf);
+    return disc_f32_xy<NOWRAP, LO16>(xf, yf);
 }
 
 // Decimated samples travel packed: re in the low, im in the high 16 bits (|lp| <= 128 * D <= 16384).

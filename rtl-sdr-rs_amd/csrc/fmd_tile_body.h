@@ -257,8 +257,8 @@ __device__ __forceinline__ void masked_rounds(const uint32_t* __restrict__ raw_w
         const uint32_t pk1 = pack_lp_perm(re1, im1), pk2 = pack_lp_perm(re2, im2);
         const uint32_t prev1 = wave_shr1_dead(dead1, pk1);                                  // lane 0's is never used
         const uint32_t prev2 = wave_shr1_old(wave_ror1_dead(dead2, pk1), pk2);               // lane 0 <- first window of lane 63
-        if (lane > 0 && (FULL || i1 < cnt)) d16[i1] = (int16_t)(smallD ? disc_f32<BIAS, NOWRAP>(pk1, prev1) : disc_nosel(pk1, prev1));   // smallD: wave-uniform
-        if (FULL || i2 < cnt) d16[i2] = (int16_t)(smallD ? disc_f32<BIAS, NOWRAP>(pk2, prev2) : disc_nosel(pk2, prev2));
+        if (lane > 0 && (FULL || i1 < cnt)) d16[i1] = (int16_t)(smallD ? disc_f32<BIAS, NOWRAP, true>(pk1, prev1) : disc_nosel(pk1, prev1));   // smallD: wave-uniform
+        if (FULL || i2 < cnt) d16[i2] = (int16_t)(smallD ? disc_f32<BIAS, NOWRAP, true>(pk2, prev2) : disc_nosel(pk2, prev2));
         pa += D * (NW * RS / 2);
         if (far) pb_far += D * (NW * RS / 2);
     };
@@ -356,8 +356,8 @@ __device__ __forceinline__ void stream_pair_rounds(const unsigned char* __restri
         const float br1 = u2f(wave_shr1_dead(dead1, f2u(ar2))), bi1 = u2f(wave_shr1_dead(dead2, f2u(ai2)));   // second window of lane l - 1
         // (the discriminators sit INSIDE the predicated stores: two separately masked instruction streams, the form hipcc
         //  built by itself while the conversion at their end was a plain cast it could sink -- and the faster one)
-        if (lane > 0 && i1 < cnt) d16[i1] = (int16_t)disc_f32_c<DH == 1>(ar1, ai1, br1, bi1);
-        if (i2 < cnt) d16[i2] = (int16_t)disc_f32_c<DH == 1>(ar2, ai2, ar1, ai1);
+        if (lane > 0 && i1 < cnt) d16[i1] = (int16_t)disc_f32_c<DH == 1, true>(ar1, ai1, br1, bi1);
+        if (i2 < cnt) d16[i2] = (int16_t)disc_f32_c<DH == 1, true>(ar2, ai2, ar1, ai1);
     };
     // Straight-line code for up to FMD_STREAM_MAX_ROUNDS rounds per wave (the host sizes the tiles accordingly): in a
     // loop hipcc's wait-count pass gives up at the back edge and waits for EVERY outstanding load (vmcnt(0)) once per trip,
@@ -490,8 +490,8 @@ __device__ __forceinline__ void tile_body(const FmdLaunch& L, const TileCtx& X, 
             const float br1 = u2f(wave_shr1_dead(dead1, f2u(ar2))), bi1 = u2f(wave_shr1_dead(dead2, f2u(ai2)));   // second window of lane l - 1
             // (:362); DH == 1 is downsample 2: no i32 wrap to emulate.  The discriminators sit INSIDE the predicated stores
             // (see stream_pair_rounds)
-            if (lane > 0 && (FULL || i1 < cnt)) d16[i1] = (int16_t)disc_f32_c<DH == 1>(ar1, ai1, br1, bi1);
-            if (FULL || i2 < cnt) d16[i2] = (int16_t)disc_f32_c<DH == 1>(ar2, ai2, ar1, ai1);
+            if (lane > 0 && (FULL || i1 < cnt)) d16[i1] = (int16_t)disc_f32_c<DH == 1, true>(ar1, ai1, br1, bi1);
+            if (FULL || i2 < cnt) d16[i2] = (int16_t)disc_f32_c<DH == 1, true>(ar2, ai2, ar1, ai1);
         };
         int base = (int)wave * RS;
         for (; base + 128 <= cnt && !FMD_ABLATE(6); base += NW * RS) pair_round(base, std::true_type{});
@@ -530,8 +530,8 @@ __device__ __forceinline__ void tile_body(const FmdLaunch& L, const TileCtx& X, 
             //  two separately masked regions the compiler builds here are the faster form.)
             // (:362); whole-dword windows: downsample <= 14 (<= FMD_DISC_F32_MAX_D)
             constexpr bool kBias = DH > 0 && 2 * DH <= 11;       // (this branch: downsample 8 at an unaligned tile)
-            if (lane > 0 && i1 < cnt) d16[i1] = (int16_t)(FMD_ABLATE(0) ? (int)(pk1 ^ prev1) : disc_f32<kBias>(pk1, prev1));
-            if (i2 < cnt) d16[i2] = (int16_t)(FMD_ABLATE(0) ? (int)(pk2 ^ prev2) : disc_f32<kBias>(pk2, prev2));
+            if (lane > 0 && i1 < cnt) d16[i1] = (int16_t)(FMD_ABLATE(0) ? (int)(pk1 ^ prev1) : disc_f32<kBias, false, true>(pk1, prev1));
+            if (i2 < cnt) d16[i2] = (int16_t)(FMD_ABLATE(0) ? (int)(pk2 ^ prev2) : disc_f32<kBias, false, true>(pk2, prev2));
         }
     } else {
         // Any downsample, any phase: a window of D samples starting at call sample s covers the dwords

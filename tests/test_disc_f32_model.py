@@ -139,3 +139,12 @@ def test_kernel_limit_matches_this_model():
     import os, re
     hdr = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "rtl-sdr-rs_amd", "csrc", "fmd_device.h")).read()
     assert int(re.search(r"#define FMD_DISC_F32_MAX_D (\d+)", hdr).group(1)) * 128 == LIM
+
+
+def test_low_16_bits_of_the_biased_result_are_the_i16():
+    """disc_f32_xy<.., LO16>: the kernels store `res + 1.5 * 2^23` truncated to 16 bits instead of converting res to i32 first."""
+    res = np.arange(-16384, 16385, dtype=np.int64).astype(F)
+    bits = (res + F(12582912.0)).view(np.uint32)
+    assert np.array_equal((bits & np.uint32(0xFFFF)).astype(np.uint16).view(np.int16), res.astype(np.int16))
+    nan = np.array([0x7FC00000, 0xFFC00000], dtype=np.uint32).view(F)          # the (0, 0) case: the hardware's quiet NaN, either sign
+    assert np.array_equal((nan + F(12582912.0)).view(np.uint32) & np.uint32(0xFFFF), np.zeros(2, np.uint32))
