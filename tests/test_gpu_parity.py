@@ -417,6 +417,16 @@ def test_last_kernel_and_tiling_report_what_ran(fmd):
     wide.close()
 
 
+def test_streaming_kernel_falls_back_bit_exactly(fmd, oracle):
+    """The same two calls as above against the oracle: a 3 MiB call (more tiles than the table holds: the streaming kernel
+    declines and the LDS-DMA kernel with the general prologue runs), then a read_sync buffer through the streaming kernel
+    on the state the fallback left -- audio and state of every channel after each."""
+    rng = np.random.default_rng(12)
+    blocks = [rng.integers(0, 256, (9, 3 << 20), dtype=np.uint8), rng.integers(0, 256, (9, fmd.DEFAULT_BUF_LENGTH), dtype=np.uint8),
+              fmd.synth.synth_iq(9, fmd.DEFAULT_BUF_LENGTH, sample_offset=77, amplitude=120)]
+    check_stream(fmd, oracle, 4, 256000, 48000, blocks, n_channels=9)
+
+
 def test_large_single_channel_call(fmd, oracle):
     """Config 2 throughput shape: one channel, 16 MiB in one call (time-tiled inside the channel)."""
     N = 16 << 20
