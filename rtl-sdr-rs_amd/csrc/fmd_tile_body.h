@@ -717,7 +717,14 @@ __device__ __forceinline__ void tile_body(const FmdLaunch& L, const TileCtx& X, 
     // (it continues the previous call's partial sum, :410-417): one lane redoes it below.
     const uint32_t nk = FMD_ABLATE(7) ? 0u : T.k1 - T.k0;
     int16_t* const outc = L.out + (uint64_t)c * L.out_stride;
-    for (uint32_t q = tid; q < nk; q += kThreads) {
+    // rate_out == rate_resample (fr == sr == 1, divisor 1): every decimated sample IS an audio sample -- a copy, not a pass of
+    // group sums and divisions (at downsample 1, 48 k -> 48 k, that pass was 60 % of the kernel's vector instructions)
+    const bool copy_through = r.fr == 1u;
+    for (uint32_t q = tid; q < nk && copy_through; q += kThreads) {
+        const int s = (int)(T.eq + T.er + q);
+        outc[T.k0 + q] = d16[(s > 0 ? s : 0) - jfirst];
+    }
+    for (uint32_t q = tid; q < nk && !copy_through; q += kThreads) {
         if (FMD_ABLATE(2)) { outc[T.k0 + q] = d16[q + 1]; continue; }           // ablation: no resampler
         const uint32_t x = T.er + q * L.fb;
         // sr (the reduced resample rate) is a power of two at the reference's rates (170 k -> 32 k: 16) and at the

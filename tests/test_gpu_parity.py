@@ -99,7 +99,7 @@ def test_demod_single_stream_api(fmd, oracle):
 
 @pytest.mark.parametrize("D,fast,slow", [CFG_REF, CFG_24, (7, 166666, 32000), (1, 48000, 48000), (5, 250000, 44100),
                                          (8, 128000, 32000), (3, 340000, 48000), (128, 8000, 8000), (21, 50000, 32000),
-                                         (2, 1000000, 8000)])
+                                         (2, 1000000, 8000), (4, 60000, 60000), (10, 24000, 24000), (6, 32000, 32000)])
 def test_configs_batched_random(fmd, oracle, D, fast, slow):
     rng = np.random.default_rng(D * 13 + 1)
     nch = 9
