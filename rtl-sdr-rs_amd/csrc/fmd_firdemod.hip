@@ -700,6 +700,7 @@ struct fmd_firdemod {
     uint32_t taps_hash = 0;                               // FNV-1a of the taps: a checkpoint names the filter it belongs to
     uint32_t lp_cap = 0, raw_bytes = 0;
     FmdExcBuf* d_exc = nullptr;
+    uint32_t* h_head = nullptr;                           // page-locked copy of the report head (fmd_firdemod_check, see fmd_demod_check)
     double f64_guard = 0x1p-20;
     int32_t f64_skew = 0;
     uint32_t seq = 0;
@@ -977,6 +978,7 @@ int fmd_firdemod_new(const int16_t* taps, uint32_t n_taps, uint32_t decim, uint3
         if (hipMalloc(&f->d_state[i], sb) != hipSuccess || hipMemset(f->d_state[i], 0, sb) != hipSuccess) return fail("hipMalloc(state)");
     }
     if (hipMalloc(&f->d_exc, sizeof(FmdExcBuf)) != hipSuccess || hipMemset(f->d_exc, 0, sizeof(FmdExcBuf)) != hipSuccess) return fail("hipMalloc(reports)");
+    if (hipHostMalloc(reinterpret_cast<void**>(&f->h_head), 16, hipHostMallocDefault) != hipSuccess) return fail("hipHostMalloc(report head)");
     if (hipStreamCreateWithFlags(&f->stream, hipStreamNonBlocking) != hipSuccess) return fail("hipStreamCreate");
     if (hipDeviceSynchronize() != hipSuccess) return fail("hipDeviceSynchronize");
     *out = f;
@@ -992,6 +994,7 @@ void fmd_firdemod_free(fmd_firdemod* f)
     if (f->d_amat) (void)hipFree(f->d_amat);
     for (int i = 0; i < 2; ++i) { if (f->d_hist[i]) (void)hipFree(f->d_hist[i]); if (f->d_state[i]) (void)hipFree(f->d_state[i]); }
     if (f->d_exc) (void)hipFree(f->d_exc);
+    if (f->h_head) (void)hipHostFree(f->h_head);
     if (f->d_iq) (void)hipFree(f->d_iq);
     if (f->d_out) (void)hipFree(f->d_out);
     if (f->stream) (void)hipStreamDestroy(f->stream);
@@ -1024,6 +1027,13 @@ int fmd_firdemod_check(fmd_firdemod* f)
 {
     if (!f) { fmd_internal_set_err("null argument"); return FMD_ERR_INVALID_ARG; }
     FD_ON_DEVICE(f->device);
+    if (f->order.have_last && f->h_head) {                   // one stream synchronisation in the common case (see fmd_demod_check)
+        f->h_head[0] = f->h_head[1] = ~0u;
+        hipError_t e = hipMemcpyAsync(f->h_head, f->d_exc, 16, hipMemcpyDeviceToHost, f->order.last);
+        if (e == hipSuccess) e = hipStreamSynchronize(f->order.last);
+        if (e == hipSuccess && f->h_head[0] == 0u && f->h_head[1] == 0u) return FMD_OK;
+        if (e != hipSuccess) (void)hipGetLastError();
+    }
     FD_TRY(hipDeviceSynchronize());
     return fmd_internal_resolve_exc(f->d_exc, f->r.R, f->seq, f->seq, f->d_state[f->cur], nullptr, 0, &f->f64_guarded, &f->f64_patched);
 }
