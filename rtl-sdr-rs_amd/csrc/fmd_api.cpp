@@ -651,7 +651,10 @@ int fmd_demod_demodulate_batch(fmd_demod* d, const uint8_t* iq, size_t nbytes, i
         HIP_TRY(hipMemcpy2DAsync(out, out_cap * sizeof(int16_t), d->d_out, out_cap * sizeof(int16_t),
                                  (size_t)kmax * sizeof(int16_t), d->C, hipMemcpyDeviceToHost, d->stream));
     }
+    const bool head = d->h_head && !d->exc_override;           // the report head rides behind the output copy (see fmd_demod_check)
+    if (head) { d->h_head[0] = d->h_head[1] = ~0u; HIP_TRY(hipMemcpyAsync(d->h_head, d->d_exc, 16, hipMemcpyDeviceToHost, d->stream)); }
     HIP_TRY(hipStreamSynchronize(d->stream));
+    if (head && d->h_head[0] == 0u && d->h_head[1] == 0u) return FMD_OK;
     return resolve_device_reports(d, out, out_cap);   // device assertions + guarded f64 samples (patched in `out`)
 }
 
