@@ -210,8 +210,10 @@ __device__ __forceinline__ uint32_t f2u(float f) { return __builtin_bit_cast(uin
 
 // fast_atan2 (:383-405) of the exact f32 product (xf, yf) = a * conj(b); see above.
 // NOWRAP: the caller guarantees |s| < 2^19 (downsample <= 3: 2 (128 * 3)^2 = 294 912), where `(4096 * s) as i32` cannot wrap.
+// k4096: 4096.0f; straight-line callers (the register-streaming rounds) pass it in a register they keep for the whole
+// function -- hipcc otherwise re-materialises it with a v_mov in front of every v_bfi.
 template <bool NOWRAP = false, bool LO16 = false>
-__device__ __forceinline__ int disc_f32_xy(float xf, float yf)
+__device__ __forceinline__ int disc_f32_xy(float xf, float yf, float k4096 = 4096.0f)
 {
     const float den = __builtin_fabsf(xf) + __builtin_fabsf(yf);
     const float t = __builtin_fabsf(xf) - __builtin_fabsf(yf);
@@ -227,7 +229,7 @@ __device__ __forceinline__ int disc_f32_xy(float xf, float yf)
     const float k = __builtin_rintf(m * __builtin_amdgcn_rcpf(den));
     const float q = k - clamp01(__builtin_fmaf(k, den, -m));
     const float qs = u2f(f2u(q) ^ (f2u(sp) & 0x80000000u));
-    const float base = 8192.0f - u2f(0x45800000u ^ sx);                  // 4096 or 12288 (:395,400)
+    const float base = 8192.0f - u2f(f2u(k4096) ^ sx);                   // 4096 or 12288 (:395,400)
     const float res = u2f(f2u(base - qs) ^ (f2u(yf) & 0x80000000u));
     // LO16: the caller stores the result as i16 and nothing else: adding 1.5 * 2^23 leaves the integer in the low mantissa
     // bits (two's complement, |res| <= 16384) -- a 2-cycle add where the conversion takes 4.  The NaN of (0, 0) keeps the
@@ -261,7 +263,7 @@ __device__ __forceinline__ int disc_f32(uint32_t a, uint32_t b)
 // is below 2^22 and every sum below 2^23 for downsample <= 16, so nothing rounds -- instead of pack, swap, conjugate, two
 // dot products and two conversions.
 template <bool NOWRAP = false, bool LO16 = false>
-__device__ __forceinline__ int disc_f32_c(float ar, float ai, float br, float bi)
+__device__ __forceinline__ int disc_f32_c(float ar, float ai, float br, float bi, float k4096 = 4096.0f)
 {
     // A product such as 0 * -5 is -0, and (-0) + (-0) stays -0; fast_atan2 takes its signs from x < 0 / y < 0, where zero
     // is not negative, and disc_f32_xy reads sign BITS (tests/test_gpu_parity.py::test_near_silence)
@@ -275,7 +277,7 @@ __device__ __forceinline__ int disc_f32_c(float ar, float ai, float br, float bi
     //  1 % slower than the six-instruction form: not adopted.)
     const float xf = __builtin_fmaf(ai, bi, __builtin_fmaf(ar, br, 0.0f));       // ar*br + ai*bi
     const float yf = __builtin_fmaf(ai, br, __builtin_fmaf(-ar, bi, 0.0f));      // ai*br - ar*bi
-    return disc_f32_xy<NOWRAP, LO16>(xf, yf);
+    return disc_f32_xy<NOWRAP, LO16>(xf, yf, k4096);
 }
 
 // Decimated samples travel packed: re in the low, im in the high 16 bits (|lp| <= 128 * D <= 16384).

@@ -330,13 +330,23 @@ __device__ __forceinline__ void stream_pair_rounds(const unsigned char* __restri
     int fbase = base;                                        // round the next fetch belongs to
     auto fetch = [&](uint32_t (&w)[NDW]) {
         const int32_t lim = fbase < last ? maxoff : 0;       // wave-uniform: beyond the last round -> the channel's first bytes
-        const int32_t o = off < 0 ? 0 : (off > lim ? lim : off);   // (v_med3_i32)
+        int32_t o;                                           // clamp(off, 0, lim) as ONE instruction (hipcc: min, compare, VCC select)
+        asm("v_med3_i32 %0, %1, 0, %2" : "=v"(o) : "v"(off), "s"(lim));
         stream_load<NDW>(chan + (uint32_t)o, w);
         off += STRIDE; fbase += NW * RS;
     };
-    auto round = [&](const uint32_t (&w)[NDW], int b) {
-        const int i1 = b + 2 * (int)lane, i2 = i1 + 1;
-        int re1 = kSumBias + DH, im1 = kSumBias + c1, re2 = kSumBias + DH, im2 = kSumBias + c2;
+    // Per lane: where its two samples of round 0 go, and how many samples are left from there.  Round k is then a compile-time
+    // offset (the rounds are unrolled) and ONE compare against a literal per store instead of index arithmetic per round.
+    int16_t* const dl = d16 + base + 2 * (int)lane;
+    // the sums' start values in registers of their own for the whole (straight-line) function: left to itself hipcc
+    // re-materialises them with a v_mov in every round
+    int bre = kSumBias + DH, bim1 = kSumBias + c1, bim2 = kSumBias + c2;
+    float k4096 = 4096.0f;
+    asm volatile("" : "+v"(bre), "+v"(bim1), "+v"(bim2), "+v"(k4096));
+    const int rem = cnt - base - 2 * (int)lane;              // sample i1 of round k is inside the tile iff k * NW * RS < rem
+    auto round = [&](const uint32_t (&w)[NDW], auto kc) {
+        constexpr int KO = decltype(kc)::value * NW * RS;
+        int re1 = bre, im1 = bim1, re2 = bre, im2 = bim2;
         uint32_t dead1 = 0, dead2 = 0;
 #pragma unroll
         for (int u = 0; u < DH; ++u) {
@@ -356,8 +366,8 @@ __device__ __forceinline__ void stream_pair_rounds(const unsigned char* __restri
         const float br1 = u2f(wave_shr1_dead(dead1, f2u(ar2))), bi1 = u2f(wave_shr1_dead(dead2, f2u(ai2)));   // second window of lane l - 1
         // (the discriminators sit INSIDE the predicated stores: two separately masked instruction streams, the form hipcc
         //  built by itself while the conversion at their end was a plain cast it could sink -- and the faster one)
-        if (lane > 0 && i1 < cnt) d16[i1] = (int16_t)disc_f32_c<DH == 1, true>(ar1, ai1, br1, bi1);
-        if (i2 < cnt) d16[i2] = (int16_t)disc_f32_c<DH == 1, true>(ar2, ai2, ar1, ai1);
+        if (lane > 0 && KO < rem) dl[KO] = (int16_t)disc_f32_c<DH == 1, true>(ar1, ai1, br1, bi1, k4096);
+        if (KO + 1 < rem) dl[KO + 1] = (int16_t)disc_f32_c<DH == 1, true>(ar2, ai2, ar1, ai1, k4096);
     };
     // Straight-line code for up to FMD_STREAM_MAX_ROUNDS rounds per wave (the host sizes the tiles accordingly): in a
     // loop hipcc's wait-count pass gives up at the back edge and waits for EVERY outstanding load (vmcnt(0)) once per trip,
@@ -365,13 +375,11 @@ __device__ __forceinline__ void stream_pair_rounds(const unsigned char* __restri
     uint32_t w[P][NDW];
 #pragma unroll
     for (int p = 0; p < P; ++p) fetch(w[p]);
-#pragma unroll
-    for (int k = 0; k < FMD_STREAM_MAX_ROUNDS; ++k) {
-        round(w[k % P], base);
-        base += NW * RS;
-        if (base >= last) break;                             // wave-uniform
-        fetch(w[k % P]);
-    }
+    static_assert(FMD_STREAM_MAX_ROUNDS == 12, "the unrolled rounds below");
+#define FMD_SR(K) round(w[(K) % P], std::integral_constant<int, (K)>{}); base += NW * RS; if (base >= last) return; fetch(w[(K) % P])
+    FMD_SR(0); FMD_SR(1); FMD_SR(2); FMD_SR(3); FMD_SR(4); FMD_SR(5); FMD_SR(6); FMD_SR(7); FMD_SR(8); FMD_SR(9); FMD_SR(10);
+    round(w[11 % P], std::integral_constant<int, 11>{});
+#undef FMD_SR
 }
 
 // Everything after the tile's bytes are visible in LDS.  Contains one __syncthreads().
