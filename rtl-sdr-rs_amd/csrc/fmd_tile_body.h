@@ -267,6 +267,48 @@ __device__ __forceinline__ void masked_rounds(const uint32_t* __restrict__ raw_w
     for (; base < last; base += NW * RS) round(base, std::false_type{});
 }
 
+// Downsample 1: a "window" is one sample, half a dword.  Lane l of a round owns the ADJACENT samples base + 2 l and
+// base + 2 l + 1 -- one dword of the tile image, or the high half of one and the low half of the next (`v_alignbit`) when the
+// round starts at an odd sample; which of the two is the same for every lane and round of a wave (a round advances by an even
+// number of samples).  The rotation phase of a lane's samples is (s + 2 l) mod 4, so the byte weights and the additive
+// constants (+1 where the weight is +1: the `255 - x` negation has none) are per-lane registers, set up once per wave; the
+// rest is the adjacent-window form of the even factors: components in f32 off biased sums, the second sample's predecessor
+// the lane's own first one, the first one's from lane l - 1 by DPP.  (The masked-window rounds did this factor with two
+// dword reads, two packs and three DPP moves per lane-pair and the packed complex product: 31 instead of 26 vector
+// instructions per sample.)
+__device__ __forceinline__ void d1_pair_rounds(const uint32_t* __restrict__ raw_w, int16_t* __restrict__ d16, int wofs, int s00, int cnt,
+                                               uint32_t lane, uint32_t wave)
+{
+    const int last = cnt - 1;
+    int base = (int)wave * RS;
+    const int s_w = s00 + base;                              // call sample of window `base` (wave-uniform; may be negative in tile 0)
+    const bool odd = (s_w & 1) != 0;                         // wave-uniform
+    const uint32_t ph1 = (uint32_t)(s_w + 2 * (int)lane) & 3u, ph2 = (ph1 + 1u) & 3u;
+    // 16-bit weight pairs (I byte, Q byte) by phase: re = +I, -Q, -I, +Q; im = +Q, +I, -Q, -I
+    auto w_re = [](uint32_t ph) { return ph == 0u ? 0x0001u : ph == 1u ? 0xFF00u : ph == 2u ? 0x00FFu : 0x0100u; };
+    auto w_im = [](uint32_t ph) { return ph == 0u ? 0x0100u : ph == 1u ? 0x0001u : ph == 2u ? 0xFF00u : 0x00FFu; };
+    const uint32_t r1 = w_re(ph1), m1 = w_im(ph1), r2 = w_re(ph2) << 16, m2 = w_im(ph2) << 16;
+    const int bre1 = kSumBias + (int)(ph1 == 0u || ph1 == 3u), bim1 = kSumBias + (int)(ph1 <= 1u);
+    const int bre2 = kSumBias + (int)(ph2 == 0u || ph2 == 3u), bim2 = kSumBias + (int)(ph2 <= 1u);
+    const uint32_t* __restrict__ pa = raw_w + (uint32_t)(wofs + (s_w >> 1) + (int)lane);
+    auto round = [&](int b, auto full_c) {
+        constexpr bool FULL = decltype(full_c)::value;
+        const int i1 = b + 2 * (int)lane, i2 = i1 + 1;
+        uint32_t w = pa[0];
+        if (odd) w = __builtin_amdgcn_alignbit(pa[1], w, 16);    // (high half of pa[0], low half of pa[1])
+        w ^= 0x80808080u;                                    // u8 -> s8 (b - 128)
+        const int re1 = sdot4_init(w, r1, bre1), im1 = sdot4_init(w, m1, bim1);
+        const int re2 = sdot4_init(w, r2, bre2), im2 = sdot4_init(w, m2, bim2);
+        const float ar1 = sum_to_f32(re1), ai1 = sum_to_f32(im1), ar2 = sum_to_f32(re2), ai2 = sum_to_f32(im2);
+        const float br1 = u2f(wave_shr1_dead(w, f2u(ar2))), bi1 = u2f(wave_shr1(f2u(ai2)));   // second sample of lane l - 1
+        if (lane > 0 && (FULL || i1 < cnt)) d16[i1] = (int16_t)disc_f32_c<true, true>(ar1, ai1, br1, bi1);   // (no i32 wrap at this factor)
+        if (FULL || i2 < cnt) d16[i2] = (int16_t)disc_f32_c<true, true>(ar2, ai2, ar1, ai1);
+        pa += NW * RS / 2;
+    };
+    for (; base + 128 <= cnt; base += NW * RS) round(base, std::true_type{});
+    for (; base < last; base += NW * RS) round(base, std::false_type{});
+}
+
 // ---- register-streaming rounds (fmd_demod_stream_kernel) ------------------------------------------------------------
 // The adjacent-window rounds with the raw bytes going global memory -> registers, never through LDS: lane l of a round
 // owns windows base + 2 l and base + 2 l + 1, 8 DH CONTIGUOUS bytes of the channel, and the 64 lanes of a wave read
@@ -541,6 +583,8 @@ __device__ __forceinline__ void tile_body(const FmdLaunch& L, const TileCtx& X, 
             if (lane > 0 && i1 < cnt) d16[i1] = (int16_t)(FMD_ABLATE(0) ? (int)(pk1 ^ prev1) : disc_f32<kBias, false, true>(pk1, prev1));
             if (i2 < cnt) d16[i2] = (int16_t)(FMD_ABLATE(0) ? (int)(pk2 ^ prev2) : disc_f32<kBias, false, true>(pk2, prev2));
         }
+    } else if (DH == -1) {
+        d1_pair_rounds(raw_w, d16, wofs, jfirst - (int)p0, cnt, lane, wave);
     } else {
         // Any downsample, any phase: a window of D samples starting at call sample s covers the dwords
         // s/2 .. (s + D - 1)/2; the half dwords at its ends are masked out of the byte weights.  s mod 4 (the

@@ -427,6 +427,19 @@ def test_streaming_kernel_falls_back_bit_exactly(fmd, oracle):
     check_stream(fmd, oracle, 4, 256000, 48000, blocks, n_channels=9)
 
 
+@pytest.mark.parametrize("fast,slow", [(48000, 48000), (250000, 48000), (1024000, 32000), (96000, 44100)])
+def test_downsample_1_adjacent_samples(fmd, oracle, fast, slow):
+    """Downsample 1 has a round form of its own (one dword = two samples per lane, waves starting at even and at odd samples,
+    per-lane rotation phases): random, full-scale square, silent and synthetic FM calls of many sizes, one channel and nine."""
+    rng = np.random.default_rng(fast // 1000 + 7)
+    for nch in (1, 9):
+        blocks = [rng.integers(0, 256, (nch, 8 * int(rng.integers(3, 5000))), dtype=np.uint8) for _ in range(5)]
+        blocks.append(np.where(rng.integers(0, 2, (nch, 8 * 777)) > 0, 255, 0).astype(np.uint8))
+        blocks.append(np.full((nch, 8 * 300), 127, np.uint8))
+        blocks.append(fmd.synth.synth_iq(nch, fmd.DEFAULT_BUF_LENGTH, amplitude=120))
+        check_stream(fmd, oracle, 1, fast, slow, blocks, n_channels=nch)
+
+
 def test_large_single_channel_call(fmd, oracle):
     """Config 2 throughput shape: one channel, 16 MiB in one call (time-tiled inside the channel)."""
     N = 16 << 20
