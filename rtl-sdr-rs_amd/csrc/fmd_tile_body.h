@@ -309,6 +309,92 @@ __device__ __forceinline__ void d1_pair_rounds(const uint32_t* __restrict__ raw_
     for (; base < last; base += NW * RS) round(base, std::false_type{});
 }
 
+// Odd downsample 3 ... 15 in the adjacent-window form.  Lane l of a round owns windows base + 2 l and base + 2 l + 1: 2 D
+// consecutive samples.  Where the pair starts at an even sample that is D whole dwords, the middle one shared -- its low half
+// closes the first window, its high half opens the second; at an odd sample it is D + 1 dwords with half a dword at either
+// end.  Which of the two is the same for every lane and round of a wave (a lane's pairs are 2 D samples apart, a round 508 D),
+// and so is the rotation phase up to the lane's parity ((s + 2 D l) mod 4): the byte weights -- the A / B pair of an aligned
+// dword, two masked copies for the half dwords -- and the additive constants are per-lane registers set up once per wave.
+// From there on it is the even factors' loop: biased sums read as f32, the second window's predecessor the lane's own
+// first, the first one's from lane l - 1 by DPP, the complex product as four fmas.  (The masked-window rounds this replaces
+// for these factors read D + 1 dwords per lane-pair too, but pack each sum, move three values by DPP and take the packed
+// complex product: 81 against 75 vector instructions per round at downsample 5; the lane stride of D dwords is odd, so the
+// LDS reads are conflict-free.)
+template <int D, bool NOWRAP>
+__device__ __forceinline__ void odd_pair_rounds(const uint32_t* __restrict__ raw_w, int16_t* __restrict__ d16, int wofs, int s00, int cnt,
+                                                uint32_t lane, uint32_t wave)
+{
+    static_assert((D & 1) == 1 && D >= 3 && D <= 15, "odd factors with the f32 discriminator");
+    constexpr int H = (D - 1) / 2;                           // whole dwords per window
+    const int last = cnt - 1;
+    int base = (int)wave * RS;
+    const int s_w = s00 + D * base;                          // call sample where window `base` starts (wave-uniform)
+    const bool odd = (s_w & 1) != 0;                         // wave-uniform: the pair starts in the high half of a dword
+    const int s_l = s_w + 2 * D * (int)lane;                 // ... of this lane's first window
+    const uint32_t sm1 = (uint32_t)s_l & 3u, sm2 = (uint32_t)(s_l + D) & 3u;
+    // dword 0 of the lane's span is call dword (s_l >> 1): its weights are the EVEN pair when that index is even
+    const bool podd = ((s_l >> 1) & 1) != 0;
+    const uint32_t wrA = podd ? FMD_W_RE_ODD : FMD_W_RE_EVEN, wrB = podd ? FMD_W_RE_EVEN : FMD_W_RE_ODD;   // dword u: A for even u, B for odd u
+    const uint32_t wiA = podd ? FMD_W_IM_ODD : FMD_W_IM_EVEN, wiB = podd ? FMD_W_IM_EVEN : FMD_W_IM_ODD;
+    // the half dwords: even start -> dword H (low half: window 1, high half: window 2); odd start -> dword 0 (high half,
+    // window 1) and dword D (low half, window 2)
+    const uint32_t wrH = (H & 1) ? wrB : wrA, wiH = (H & 1) ? wiB : wiA;     // weights of dword H
+    const uint32_t wrD = wrB, wiD = wiB;                                      // ... of dword D (D is odd)
+    const uint32_t r1h = odd ? (wrA & 0xFFFF0000u) : (wrH & 0x0000FFFFu), i1h = odd ? (wiA & 0xFFFF0000u) : (wiH & 0x0000FFFFu);
+    const uint32_t r2h = odd ? (wrD & 0x0000FFFFu) : (wrH & 0xFFFF0000u), i2h = odd ? (wiD & 0x0000FFFFu) : (wiH & 0xFFFF0000u);
+    const int bre1 = kSumBias + fmd_const_re((int)sm1 + D) - fmd_const_re((int)sm1), bim1 = kSumBias + fmd_const_im((int)sm1 + D) - fmd_const_im((int)sm1);
+    const int bre2 = kSumBias + fmd_const_re((int)sm2 + D) - fmd_const_re((int)sm2), bim2 = kSumBias + fmd_const_im((int)sm2 + D) - fmd_const_im((int)sm2);
+    const uint32_t* __restrict__ pa = raw_w + (uint32_t)(wofs + (s_l >> 1));
+    auto round = [&](int b, auto full_c, auto odd_c) {
+        constexpr bool FULL = decltype(full_c)::value, ODD = decltype(odd_c)::value;
+        const int i1 = b + 2 * (int)lane, i2 = i1 + 1;
+        int re1, im1, re2, im2;
+        uint32_t dead1 = 0, dead2 = 0;
+        if constexpr (!ODD) {
+            // dwords 0 .. H-1: window 1; dword H: both (halves); dwords H+1 .. D-1: window 2
+            {
+                const uint32_t w = pa[H] ^ 0x80808080u;
+                re1 = sdot4_init(w, r1h, bre1); im1 = sdot4_init(w, i1h, bim1);
+                re2 = sdot4_init(w, r2h, bre2); im2 = sdot4_init(w, i2h, bim2);
+                dead1 = w;
+            }
+#pragma unroll
+            for (int u = 0; u < H; ++u) {
+                const uint32_t wa = pa[u] ^ 0x80808080u, wb = pa[H + 1 + u] ^ 0x80808080u;
+                re1 = sdot4(wa, (u & 1) ? wrB : wrA, re1); im1 = sdot4(wa, (u & 1) ? wiB : wiA, im1);
+                re2 = sdot4(wb, ((H + 1 + u) & 1) ? wrB : wrA, re2); im2 = sdot4(wb, ((H + 1 + u) & 1) ? wiB : wiA, im2);
+                dead2 = wb;
+            }
+        } else {
+            // dword 0 (high half) + dwords 1 .. H: window 1; dwords H+1 .. D-1 + dword D (low half): window 2
+            {
+                const uint32_t wa = pa[0] ^ 0x80808080u, wb = pa[D] ^ 0x80808080u;
+                re1 = sdot4_init(wa, r1h, bre1); im1 = sdot4_init(wa, i1h, bim1);
+                re2 = sdot4_init(wb, r2h, bre2); im2 = sdot4_init(wb, i2h, bim2);
+                dead1 = wa; dead2 = wb;
+            }
+#pragma unroll
+            for (int u = 0; u < H; ++u) {
+                const uint32_t wa = pa[1 + u] ^ 0x80808080u, wb = pa[H + 1 + u] ^ 0x80808080u;
+                re1 = sdot4(wa, ((1 + u) & 1) ? wrB : wrA, re1); im1 = sdot4(wa, ((1 + u) & 1) ? wiB : wiA, im1);
+                re2 = sdot4(wb, ((H + 1 + u) & 1) ? wrB : wrA, re2); im2 = sdot4(wb, ((H + 1 + u) & 1) ? wiB : wiA, im2);
+            }
+        }
+        const float ar1 = sum_to_f32(re1), ai1 = sum_to_f32(im1), ar2 = sum_to_f32(re2), ai2 = sum_to_f32(im2);
+        const float br1 = u2f(wave_shr1_dead(dead1, f2u(ar2))), bi1 = u2f(wave_shr1_dead(dead2, f2u(ai2)));   // second window of lane l - 1
+        if (lane > 0 && (FULL || i1 < cnt)) d16[i1] = (int16_t)disc_f32_c<NOWRAP, true>(ar1, ai1, br1, bi1);
+        if (FULL || i2 < cnt) d16[i2] = (int16_t)disc_f32_c<NOWRAP, true>(ar2, ai2, ar1, ai1);
+        pa += D * (NW * RS / 2);                             // 508 windows = 508 D samples = 254 D dwords
+    };
+    if (odd) {
+        for (; base + 128 <= cnt; base += NW * RS) round(base, std::true_type{}, std::true_type{});
+        for (; base < last; base += NW * RS) round(base, std::false_type{}, std::true_type{});
+    } else {
+        for (; base + 128 <= cnt; base += NW * RS) round(base, std::true_type{}, std::false_type{});
+        for (; base < last; base += NW * RS) round(base, std::false_type{}, std::false_type{});
+    }
+}
+
 // ---- register-streaming rounds (fmd_demod_stream_kernel) ------------------------------------------------------------
 // The adjacent-window rounds with the raw bytes going global memory -> registers, never through LDS: lane l of a round
 // owns windows base + 2 l and base + 2 l + 1, 8 DH CONTIGUOUS bytes of the channel, and the 64 lanes of a wave read
@@ -585,6 +671,8 @@ __device__ __forceinline__ void tile_body(const FmdLaunch& L, const TileCtx& X, 
         }
     } else if (DH == -1) {
         d1_pair_rounds(raw_w, d16, wofs, jfirst - (int)p0, cnt, lane, wave);
+    } else if (DH < -1 && DH >= -15) {
+        if constexpr (DH < -1 && DH >= -15) odd_pair_rounds<-DH, (-DH <= 3)>(raw_w, d16, wofs, -DH * jfirst - (int)p0, cnt, lane, wave);
     } else {
         // Any downsample, any phase: a window of D samples starting at call sample s covers the dwords
         // s/2 .. (s + D - 1)/2; the half dwords at its ends are masked out of the byte weights.  s mod 4 (the
