@@ -633,6 +633,7 @@ def main():
         fence()
         own = time.perf_counter() - t0
         n_done += args.steps
+        bank.check()        # outside the bracket: settles and drains the guarded-f64 report buffer (1024 records: a minute of launches fills it)
         return max_over_ranks(own), own, ev0.elapsed_time(ev1) / args.steps
 
     regions = [timed_region()]
