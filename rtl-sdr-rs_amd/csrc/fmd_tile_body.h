@@ -962,10 +962,13 @@ __device__ __forceinline__ FastAddr fast_addr(const FmdLaunch& L)
         A.lo2 = (uint32_t)(lo > 0 ? lo : 0);
         A.hi2 = A.t + 1u == g.nt ? g.ns2 : (uint32_t)hi;
     }
+    // (the host admits the fast prologues only for 16-byte aligned channel bases and call lengths -- fmd_fast_geometry --
+    //  so the staged range is 32-bit arithmetic on the row and always lies inside the buffer)
     A.gbase = g.iq + (uint64_t)A.c * g.chan_stride;
-    A.a0 = (A.gbase + A.lo2) & ~15ull;
-    A.nchunks = (uint32_t)((A.gbase + A.hi2 - A.a0 + 15) >> 4);
-    A.whole = A.a0 + 16ull * A.nchunks <= g.iq_end;
+    const uint32_t lo2a = A.lo2 & ~15u;
+    A.a0 = A.gbase + lo2a;
+    A.nchunks = (A.hi2 - lo2a + 15u) >> 4;
+    A.whole = true;
     return A;
 }
 
@@ -978,7 +981,7 @@ __device__ __forceinline__ TileCtx fast_ctx(const FmdLaunch& L, const FastAddr& 
     TileCtx X;
     X.c = A.c; X.cls = 0u; X.valid = true; X.whole = A.whole;
     X.a0 = A.a0; X.nchunks = A.nchunks; X.gbase = A.gbase;
-    X.wofs = (int)((int64_t)(A.gbase - A.a0) >> 2);
+    X.wofs = -(int)((A.lo2 & ~15u) >> 2);
     FmdTile& T = X.T;
     const uint32_t t = A.t;
     T.last = t + 1u == g.nt;
@@ -1004,10 +1007,13 @@ __device__ __forceinline__ void issue_dma(uint64_t a0, uint32_t nchunks, unsigne
     // global_load_lds_dwordx4: 1 KiB per wave-instruction straight into the tile image, destination =
     // wave-uniform base (M0) + lane * 16; no VGPR round trip, no ds_write pass, one wait for all.
     const unsigned char* src = reinterpret_cast<const unsigned char*>((uintptr_t)a0) + 16u * tid;
-    unsigned char* dst = smem + 1024u * (tid >> 6);
+    // (the wave index as a scalar: the LDS destination -- M0 -- then advances by an s_add per DMA instead of a
+    //  v_readfirstlane + s_mov of a per-lane expression)
+    unsigned char* dst = smem + 1024u * (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid >> 6));
     const uint32_t nfull = nchunks / kThreads, ntail = nchunks - nfull * kThreads;
-    for (uint32_t l = 0; l < nfull; ++l) lds_dma16(src + (16u * kThreads) * l, dst + (16u * kThreads) * l);
-    if (tid < ntail) lds_dma16(src + (16u * kThreads) * nfull, dst + (16u * kThreads) * nfull);
+#pragma unroll 1
+    for (uint32_t l = 0; l < nfull; ++l) { lds_dma16(src, dst); src += 16u * kThreads; dst += 16u * kThreads; }
+    if (tid < ntail) lds_dma16(src, dst);
 }
 
 // ---- one block per tile, LDS-DMA staging ------------------------------------------------------------
@@ -1025,12 +1031,8 @@ __global__ void __launch_bounds__(kThreads) fmd_demod_tile_kernel(const FmdLaunc
         // checked the LDS sizing of every tile of this launch (fmd_fast_geometry), so there is nothing to assert.
         const FastAddr A = fast_addr<FAST>(L);
         if (A.c >= L.fg.n_channels) return;
-        if (FMD_ABLATE(4)) {
-        } else if (A.whole) {
-            issue_dma(A.a0, A.nchunks, smem, tid);
-        }
+        if (!FMD_ABLATE(4)) issue_dma(A.a0, A.nchunks, smem, tid);
         const TileCtx X = fast_ctx<FAST>(L, A);              // scalar work under the load latency
-        if (!A.whole && !FMD_ABLATE(4)) stage_slow(L, X, smem, tid);
         if (FMD_ABLATE(3)) {                                 // ablation: staging skeleton only
             __syncthreads();
             if (tid == 0) L.out[(uint64_t)X.c * L.out_stride + X.T.k0] = (int16_t)reinterpret_cast<uint32_t*>(smem)[blockIdx.y & 63u];

@@ -37,6 +37,10 @@ static uint32_t fmd_fast_geometry(FmdLaunch& L, uint32_t per)
     const FmdTiling& tl = L.tl;
     const uint64_t ns2 = 2ull * L.ns;
     if (ns2 >= (1ull << 31)) return 0u;
+    // The fast prologues take every channel base and the call length as multiples of 16 bytes: a tile's staged range is then
+    // 32-bit arithmetic on its row and never runs past the buffer (the scalar unit is the kernels' co-bottleneck:
+    // profiles/r04_experiments.md 28).  Anything else takes the general prologue.
+    if (((uint64_t)(uintptr_t)L.iq | L.chan_stride | ns2) & 15u) return 0u;
     FmdFastGeo& g = L.fg;
     g.iq = (uint64_t)(uintptr_t)L.iq; g.iq_end = g.iq + L.total_bytes; g.chan_stride = L.chan_stride;
     g.n_channels = L.n_channels; g.per = per; g.nt = P.nt; g.ns2 = (uint32_t)ns2; g.Qt = tl.Qt;
