@@ -857,45 +857,56 @@ __device__ __forceinline__ void tile_body(const FmdLaunch& L, const TileCtx& X, 
     // (it continues the previous call's partial sum, :410-417): one lane redoes it below.
     const uint32_t nk = FMD_ABLATE(7) ? 0u : T.k1 - T.k0;
     int16_t* const outc = L.out + (uint64_t)c * L.out_stride;
-    // rate_out == rate_resample (fr == sr == 1, divisor 1): every decimated sample IS an audio sample -- a copy, not a pass of
-    // group sums and divisions (at downsample 1, 48 k -> 48 k, that pass was 60 % of the kernel's vector instructions)
-    const bool copy_through = r.fr == 1u;
-    for (uint32_t q = tid; q < nk && copy_through; q += kThreads) {
-        const int s = (int)(T.eq + T.er + q);
-        outc[T.k0 + q] = d16[(s > 0 ? s : 0) - jfirst];
-    }
-    for (uint32_t q = tid; q < nk && !copy_through; q += kThreads) {
-        if (FMD_ABLATE(2)) { outc[T.k0 + q] = d16[q + 1]; continue; }           // ablation: no resampler
-        const uint32_t x = T.er + q * L.fb;
-        // sr (the reduced resample rate) is a power of two at the reference's rates (170 k -> 32 k: 16) and at the
-        // bench configuration (240 k -> 32 k: 2): shift and mask instead of the exact small divide (wave-uniform)
-        uint32_t u, xrem;
-        if (L.sr_shift < 32u) { u = x >> L.sr_shift; xrem = x & (r.sr - 1u); }
-        else { u = fmd_udiv_small(x, r.sr, L.inv_sr); xrem = x - u * r.sr; }
-        const bool extra = xrem < L.fb;
-        const int e = (int)(T.eq + q * L.fa + u);
-        int s = e - (int)L.fa + (extra ? 0 : 1);
-        s = s > 0 ? s : 0;                                   // the call's first group starts at 0
-        const int16_t* dp = d16 + (s - jfirst);
-        int sum;
-        switch (L.fa) {                                      // wave-uniform: fa unconditional terms + one optional
-            case 1: sum = group_sum<1>(dp, extra); break;
-            case 2: sum = group_sum<2>(dp, extra); break;
-            case 3: sum = group_sum<3>(dp, extra); break;
-            case 4: sum = group_sum<4>(dp, extra); break;
-            case 5: sum = group_sum<5>(dp, extra); break;
-            case 6: sum = group_sum<6>(dp, extra); break;
-            case 7: sum = group_sum<7>(dp, extra); break;
-            case 8: sum = group_sum<8>(dp, extra); break;
-            default: {
-                sum = 0;
+    // The pass is one loop per group length, chosen by ONE block-uniform switch in front of it: with the switch inside the
+    // loop (its exit is per lane) hipcc's structurizer turned the dispatch into forty scalar flag moves and tests per pass --
+    // and the scalar unit is what these kernels run out of (profiles/r04_experiments.md 28).
+    // FA = 0: any group length (run-time loop); FA = -1: rate_out == rate_resample (fr == sr == 1, divisor 1), every decimated
+    // sample IS an audio sample -- a copy (at downsample 1, 48 k -> 48 k, the general pass was 60 % of the kernel's vector
+    // instructions).
+    auto resample = [&](auto fa_c) {
+        constexpr int FA = decltype(fa_c)::value;
+#pragma clang loop unroll(disable) vectorize(disable)
+        for (uint32_t q = tid; q < nk; q += kThreads) {
+            if (FMD_ABLATE(2)) { outc[T.k0 + q] = d16[q + 1]; continue; }       // ablation: no resampler
+            if constexpr (FA < 0) {
+                const int s = (int)(T.eq + T.er + q);
+                outc[T.k0 + q] = d16[(s > 0 ? s : 0) - jfirst];
+            } else {
+                const uint32_t x = T.er + q * L.fb;
+                // sr (the reduced resample rate) is a power of two at the reference's rates (170 k -> 32 k: 16) and at the
+                // bench configuration (240 k -> 32 k: 2): shift and mask instead of the exact small divide (wave-uniform)
+                uint32_t u, xrem;
+                if (L.sr_shift < 32u) { u = x >> L.sr_shift; xrem = x & (r.sr - 1u); }
+                else { u = fmd_udiv_small(x, r.sr, L.inv_sr); xrem = x - u * r.sr; }
+                const bool extra = xrem < L.fb;
+                const int e = (int)(T.eq + q * L.fa + u);
+                int s = e - (int)L.fa + (extra ? 0 : 1);
+                s = s > 0 ? s : 0;                               // the call's first group starts at 0
+                const int16_t* dp = d16 + (s - jfirst);
+                int sum;
+                if constexpr (FA > 0) sum = group_sum<FA>(dp, extra);          // FA unconditional terms + one optional
+                else {
+                    sum = 0;
 #pragma clang loop vectorize(disable)
-                for (int i = 0; i < (int)L.fa; ++i) sum += dp[i];
-                const int v = dp[L.fa];
-                sum += extra ? v : 0;
+                    for (int i = 0; i < (int)L.fa; ++i) sum += dp[i];
+                    const int v = dp[L.fa];
+                    sum += extra ? v : 0;
+                }
+                outc[T.k0 + q] = (int16_t)fmd_sdiv_magic(sum, L.magic_R);
             }
         }
-        outc[T.k0 + q] = (int16_t)fmd_sdiv_magic(sum, L.magic_R);
+    };
+    if (r.fr == 1u) resample(std::integral_constant<int, -1>{});
+    else switch (L.fa) {                                     // block-uniform
+        case 1: resample(std::integral_constant<int, 1>{}); break;
+        case 2: resample(std::integral_constant<int, 2>{}); break;
+        case 3: resample(std::integral_constant<int, 3>{}); break;
+        case 4: resample(std::integral_constant<int, 4>{}); break;
+        case 5: resample(std::integral_constant<int, 5>{}); break;
+        case 6: resample(std::integral_constant<int, 6>{}); break;
+        case 7: resample(std::integral_constant<int, 7>{}); break;
+        case 8: resample(std::integral_constant<int, 8>{}); break;
+        default: resample(std::integral_constant<int, 0>{}); break;
     }
     if (T.k0 == 0 && tid == 0 && nk > 0) {                   // same lane as the loop's store to outc[0]: this one wins
         const int e = (int)(T.eq + fmd_udiv_small(T.er, r.sr, L.inv_sr));
