@@ -125,7 +125,17 @@ int fmd_demod_demodulate_batch(fmd_demod *d, const uint8_t *iq, size_t nbytes,
  * device pointers on the handle's GPU with the layouts above (d_iq 16-byte aligned;
  * d_out_len uint32, may be NULL).  Enqueues on `stream` (a hipStream_t; NULL = the
  * default stream) and returns without synchronising; the per-channel counts are also
- * available on the host, without a sync, from fmd_demod_last_out_len. */
+ * available on the host, without a sync, from fmd_demod_last_out_len.
+ * Stream lifetime: the library orders a handle's consecutive launches itself, also across different
+ * streams, and fmd_demod_check completes behind the most recent launch ON ITS STREAM -- so the `stream`
+ * of a handle's most recent _device call must stay alive until the handle's next _device call or
+ * completion point (fmd_demod_check, _get_state, _set_state, a host entry point) has returned.  The
+ * same rule holds for fmd_fir_filter_device and fmd_firdemod_demodulate_device.
+ * Fast path: nbytes % 16 == 0 (every read_sync buffer: DEFAULT_BUF_LENGTH = 262144) and a bank whose
+ * channels share one phase (banks fed equal-length buffers always do) take the kernels' short
+ * prologues.  nbytes % 16 == 8 is legal (the reference only demands % 8, :284) and bit-exact, but runs the
+ * general prologue -- a few percent slower, and for downsample 2 / 4 the LDS kernel instead of the
+ * register-streaming one; fmd_demod_last_kernel reports which kernel a launch ran. */
 int fmd_demod_demodulate_device(fmd_demod *d, const void *d_iq, size_t nbytes,
                                 void *d_out, size_t out_cap, void *d_out_len, void *stream);
 

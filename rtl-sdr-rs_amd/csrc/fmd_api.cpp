@@ -721,7 +721,7 @@ int fmd_demod_check(fmd_demod* d)
         hipError_t e = hipMemcpyAsync(d->h_head, d->d_exc, 16, hipMemcpyDeviceToHost, d->order.last);
         if (e == hipSuccess) e = hipStreamSynchronize(d->order.last);
         if (e == hipSuccess && d->h_head[0] == 0u && d->h_head[1] == 0u) return FMD_OK;
-        if (e != hipSuccess) (void)hipGetLastError();        // (a stream the caller has destroyed since: fall through)
+        if (e != hipSuccess) (void)hipGetLastError();
     }
     HIP_TRY(hipDeviceSynchronize());
     return resolve_device_reports(d, nullptr, 0);

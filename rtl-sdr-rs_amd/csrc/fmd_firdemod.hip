@@ -686,7 +686,7 @@ void launch(const FirDemodLaunch& L, dim3 g, size_t lds, hipStream_t s)
 
 struct fmd_firdemod {
     uint32_t T = 0, M = 0, C = 0, NP = 0, Hw = 0, shift = 0;
-    uint32_t lp_bound = 0;                                // (128 * sum|taps|) >> shift: the largest |lp| component
+    uint32_t lp_bound = 0;                                // ceil(128 * sum|taps| / 2^shift): the largest |lp| component
     int device = 0;
     uint64_t pos = 0;                                     // samples consumed per channel
     FmdFirMfmaPlan plan;
@@ -710,6 +710,7 @@ struct fmd_firdemod {
     bool no_rows = false;                                 // FMD_FD_ROWS=0: geometry on the device (A/B)
     bool reuse16 = false;                                 // FMD_FD_REUSE16 (experiment build): fragment reuse at decim 16 too
     bool no_reuse = false, int_disc = false;              // FMD_FD_NOREUSE / FMD_FD_INT_DISC: plain MFMA mapping / integer discriminator (A/B), read at creation
+    int last_rows = -1;                                   // the most recent launch's `use_rows` (-1: none yet) -- part of the kernel's name
     uint32_t reg_ng = 0;                                  // > 0: fmd_firdemod_reg_kernel with this many output groups per column (decimate 8, f32 discriminator)
     size_t lds_budget = 20480;                            // LDS per tile (8 tiles per CU); FMD_FD_LDS (tuning)
     hipStream_t stream = nullptr;
@@ -859,6 +860,7 @@ int fd_enqueue(fmd_firdemod* f, const void* d_iq, size_t nbytes, void* d_out, si
     f->i0r = fmd_next_lpr_index_r(r, f->i0r, L.P.M, L.P.K);
     f->pos += ns;
     f->last_K = L.P.K;
+    f->last_rows = (int)L.use_rows;
     if (n_each) *n_each = L.P.K;
     return FMD_OK;
 }
@@ -914,7 +916,9 @@ int fmd_firdemod_new(const int16_t* taps, uint32_t n_taps, uint32_t decim, uint3
         f->taps_hash = (f->taps_hash ^ (uint32_t)(taps[t] & 0xFF)) * 16777619u;
         f->taps_hash = (f->taps_hash ^ (uint32_t)((taps[t] >> 8) & 0xFF)) * 16777619u;
     }
-    f->lp_bound = (uint32_t)((128ull * sum_abs) >> shift);
+    // (rounded UP: lp = floor(y / 2^shift) of a negative y reaches -ceil(128 sum|h| / 2^shift) when every tap is negative, and the
+    //  f32 discriminator's exactness argument -- fmd_device.h: |s| <= 2^23 -- needs the true bound, not the truncated one)
+    f->lp_bound = (uint32_t)((128ull * sum_abs + ((1ull << shift) - 1ull)) >> shift);
     f->NP = ((n_taps + 1) / 2 + 3u) & ~3u;
     const uint32_t H = n_taps - 1, Hp = H + (H & 1u);
     f->Hw = Hp / 2;
@@ -1089,8 +1093,22 @@ struct FdCkptHeader {
     uint32_t magic, version;
     uint32_t T, M, C, Hw, shift, taps_hash, fast, slow, i0r, last_K;
     uint64_t pos;
+    uint64_t checksum;                                    // FNV-1a 64 of the header (this field as 0) followed by the payload
 };
+static_assert(sizeof(FdCkptHeader) == 64, "blob layout (little-endian, no padding)");
 constexpr uint32_t kFdCkptMagic = 0x4B434446u;            // "FDCK"
+constexpr uint32_t kFdCkptVersion = 2u;                   // 2: checksum (round 5; version 1 never left the repository)
+uint64_t fd_fnv64(uint64_t h, const void* data, size_t n)
+{
+    const uint8_t* p = static_cast<const uint8_t*>(data);
+    for (size_t i = 0; i < n; ++i) { h ^= p[i]; h *= 0x100000001B3ull; }
+    return h;
+}
+uint64_t fd_ckpt_checksum(FdCkptHeader h, const void* payload, size_t n)
+{
+    h.checksum = 0;
+    return fd_fnv64(fd_fnv64(0xCBF29CE484222325ull, &h, sizeof(h)), payload, n);
+}
 size_t fd_ckpt_size(const fmd_firdemod* f)
 {
     return sizeof(FdCkptHeader) + (size_t)f->C * sizeof(FmdChanState) + (size_t)f->C * f->Hw * 4;
@@ -1107,12 +1125,14 @@ int fmd_firdemod_checkpoint(fmd_firdemod* f, void* blob, size_t cap)
     FD_TRY(hipDeviceSynchronize());
     int rc = fmd_internal_resolve_exc(f->d_exc, f->r.R, f->seq, f->seq, f->d_state[f->cur], nullptr, 0, &f->f64_guarded, &f->f64_patched);
     if (rc) return rc;
-    FdCkptHeader h{kFdCkptMagic, 1u, f->T, f->M, f->C, f->Hw, f->shift, f->taps_hash, f->r.fast, f->r.slow, f->i0r, f->last_K, f->pos};
-    uint8_t* p = static_cast<uint8_t*>(blob);
-    memcpy(p, &h, sizeof(h)); p += sizeof(h);
+    FdCkptHeader h{kFdCkptMagic, kFdCkptVersion, f->T, f->M, f->C, f->Hw, f->shift, f->taps_hash, f->r.fast, f->r.slow, f->i0r, f->last_K, f->pos, 0ull};
+    uint8_t* const payload = static_cast<uint8_t*>(blob) + sizeof(h);
+    uint8_t* p = payload;
     FD_TRY(hipMemcpy(p, f->d_state[f->cur], (size_t)f->C * sizeof(FmdChanState), hipMemcpyDeviceToHost));
     p += (size_t)f->C * sizeof(FmdChanState);
     if (f->Hw) FD_TRY(hipMemcpy(p, f->d_hist[f->cur], (size_t)f->C * f->Hw * 4, hipMemcpyDeviceToHost));
+    h.checksum = fd_ckpt_checksum(h, payload, fd_ckpt_size(f) - sizeof(h));
+    memcpy(blob, &h, sizeof(h));
     return FMD_OK;
 }
 
@@ -1122,27 +1142,41 @@ int fmd_firdemod_resume(fmd_firdemod* f, const void* blob, size_t size)
     FdCkptHeader h;
     if (size < sizeof(h)) { fmd_internal_set_err("checkpoint truncated"); return FMD_ERR_BAD_STATE; }
     memcpy(&h, blob, sizeof(h));
-    if (h.magic != kFdCkptMagic || h.version != 1u) { fmd_internal_set_err("not a fused-bank checkpoint (magic / version)"); return FMD_ERR_BAD_STATE; }
+    if (h.magic != kFdCkptMagic || h.version != kFdCkptVersion) { fmd_internal_set_err("not a fused-bank checkpoint (magic / version)"); return FMD_ERR_BAD_STATE; }
     if (h.T != f->T || h.M != f->M || h.C != f->C || h.Hw != f->Hw || h.shift != f->shift || h.taps_hash != f->taps_hash ||
         h.fast != f->r.fast || h.slow != f->r.slow) {
         fmd_internal_set_err("checkpoint was taken from a bank with other taps, decimation, shift, rates or channel count");
         return FMD_ERR_BAD_STATE;
     }
     if (size != fd_ckpt_size(f)) { fmd_internal_set_err("checkpoint size does not match its header"); return FMD_ERR_BAD_STATE; }
+    const uint8_t* const payload = static_cast<const uint8_t*>(blob) + sizeof(h);
+    if (h.checksum != fd_ckpt_checksum(h, payload, size - sizeof(h))) { fmd_internal_set_err("checkpoint damaged (checksum)"); return FMD_ERR_BAD_STATE; }
+    // A blob with a valid checksum can still be hand-made: every field the kernels take on trust is range-checked, as
+    // fmd_demod_set_state does for a boxcar bank.  |demod_pre| beyond the filter's own bound would take the f32 discriminator
+    // out of the range in which it is exact (silently wrong audio, no status); |now_lpr| is at most one full audio group of
+    // discriminator samples.
     if (h.i0r >= f->r.fr) { fmd_internal_set_err("checkpoint holds a resampler phase outside [0, rate_out / g)"); return FMD_ERR_BAD_STATE; }
-    const uint8_t* p = static_cast<const uint8_t*>(blob) + sizeof(h);
-    const FmdChanState* st = reinterpret_cast<const FmdChanState*>(p);
+    const int64_t lim_pre = f->lp_bound, lim_lpr = 16384ll * ((f->r.fr + f->r.sr - 1) / f->r.sr);
+    auto within = [](int64_t v, int64_t lim) { return v >= -lim && v <= lim; };
     for (uint32_t c = 0; c < f->C; ++c) {
-        FmdChanState s; memcpy(&s, st + c, sizeof(s));
+        FmdChanState s; memcpy(&s, payload + (size_t)c * sizeof(FmdChanState), sizeof(s));
         if (s.lpr_index_r != h.i0r) { fmd_internal_set_err("checkpoint channel disagrees with the bank's resampler phase"); return FMD_ERR_BAD_STATE; }
+        if (s.prev_index != 0u || s.lp_now_re != 0 || s.lp_now_im != 0 || s.reserved != 0 || !within(s.demod_pre_re, lim_pre) ||
+            !within(s.demod_pre_im, lim_pre) || !within(s.now_lpr, lim_lpr)) {
+            fmd_internal_set_err("checkpoint channel state not reachable by this bank (demod_pre / now_lpr out of range)");
+            return FMD_ERR_BAD_STATE;
+        }
     }
     FD_ON_DEVICE(f->device);
     FD_TRY(hipDeviceSynchronize());
-    FD_TRY(hipMemcpy(f->d_state[f->cur], p, (size_t)f->C * sizeof(FmdChanState), hipMemcpyHostToDevice));
-    p += (size_t)f->C * sizeof(FmdChanState);
-    if (f->Hw) FD_TRY(hipMemcpy(f->d_hist[f->cur], p, (size_t)f->C * f->Hw * 4, hipMemcpyHostToDevice));
+    // Both arrays go into the INACTIVE halves of the ping-pong; `cur` flips only once both copies have succeeded, so a
+    // failing second copy cannot leave the channels' state restored and their filter history not.
+    const int nxt = f->cur ^ 1;
+    FD_TRY(hipMemcpy(f->d_state[nxt], payload, (size_t)f->C * sizeof(FmdChanState), hipMemcpyHostToDevice));
+    if (f->Hw) FD_TRY(hipMemcpy(f->d_hist[nxt], payload + (size_t)f->C * sizeof(FmdChanState), (size_t)f->C * f->Hw * 4, hipMemcpyHostToDevice));
     FD_TRY(hipMemset(f->d_exc, 0, 16));
     FD_TRY(hipDeviceSynchronize());
+    f->cur = nxt;
     f->pos = h.pos; f->i0r = h.i0r; f->last_K = h.last_K;
     return FMD_OK;
 }
@@ -1160,8 +1194,12 @@ int fmd_firdemod_kernel_name(const fmd_firdemod* f, char* name, size_t cap)
     if (!f || !name || cap == 0) return FMD_ERR_INVALID_ARG;
     const uint32_t nku = f->plan.nku < 8u ? f->plan.nku : 8u;
     const bool reuse = f->M == 8u && f->plan.n_pass == 1u && !f->no_reuse;
-    const int n = f->reg_ng ? snprintf(name, cap, "fmd_firdemod_reg_kernel<%u, %u>", nku, f->reg_ng)
-                            : snprintf(name, cap, "fmd_firdemod_kernel<%u, %u>", nku, reuse ? 1u : 0u);   // (the register form: + ", true>" with a tile table)
+    // The kernels live in this file's anonymous namespace, and the register form carries a third template argument -- whether
+    // the launch had a per-tile table (every call of at most kFdRows tiles: a 2 MiB config-4 buffer has 26) -- so the name is
+    // that of the most recent launch; before the first one, of a launch with a table.
+    const bool rows = f->last_rows < 0 ? !f->no_rows : f->last_rows != 0;
+    const int n = f->reg_ng ? snprintf(name, cap, "(anonymous namespace)::fmd_firdemod_reg_kernel<%u, %u, %s>", nku, f->reg_ng, rows ? "true" : "false")
+                            : snprintf(name, cap, "(anonymous namespace)::fmd_firdemod_kernel<%u, %u>", nku, reuse ? 1u : 0u);
     return n < 0 || (size_t)n >= cap ? FMD_ERR_CAPACITY : FMD_OK;
 }
 

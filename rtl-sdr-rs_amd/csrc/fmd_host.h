@@ -52,6 +52,11 @@ private:
 // Launches of one handle are ordered by the stream they go to.  A handle's double-buffered state (st_in / st_out,
 // FIR history) makes launch n+1 read what launch n wrote, so when consecutive calls use DIFFERENT streams the new
 // stream first waits for everything the handle enqueued on the previous one.  Free in the common case (same stream).
+// LIFETIME RULE (include/fmd.h): the stream of a handle's most recent `_device` call must stay alive until the handle's next
+// `_device` call or completion point (`*_check`, `get_state`, a host entry) has returned -- those are the only places the
+// remembered handle is used again.  Round 5 measured the alternative that needs no such rule -- an event recorded behind
+// EVERY launch, later waits on the event only: +2.4 ... +3.2 % per launch at the headline and the reference's rates (the
+// record is a barrier packet between back-to-back kernels), +8 % on launch + check per buffer (profiles/r05_experiments.md).
 struct FmdStreamOrder {
     hipStream_t last = nullptr;
     bool have_last = false;
@@ -64,11 +69,10 @@ struct FmdStreamOrder {
         if (!ev) { hipError_t e = hipEventCreateWithFlags(&ev, hipEventDisableTiming); if (e != hipSuccess) return e; }
         hipError_t e = hipEventRecord(ev, last);           // everything submitted to the old stream so far
         if (e == hipSuccess) e = hipStreamWaitEvent(stream, ev, 0);
-        if (e != hipSuccess) { (void)hipGetLastError(); e = hipDeviceSynchronize(); }   // old stream gone: be safe
+        if (e != hipSuccess) { (void)hipGetLastError(); e = hipDeviceSynchronize(); }   // be safe
         return e;
     }
     void after(hipStream_t stream) { last = stream; have_last = true; }
     void reset() { have_last = false; }
     void destroy() { if (ev) (void)hipEventDestroy(ev); ev = nullptr; have_last = false; }
 };
-

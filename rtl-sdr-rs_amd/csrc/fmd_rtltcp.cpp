@@ -184,6 +184,9 @@ int fmd_rtltcp_read_many(fmd_rtltcp* const* sources, uint32_t n, uint8_t* base, 
         if (r < 0) { if (errno == EINTR) continue; err("poll"); return FMD_ERR_IO; }
         if (r == 0) { errno = ETIMEDOUT; err("read"); return FMD_ERR_IO; }   // no byte on ANY open stream for a whole timeout
         for (nfds_t k = 0; k < m; ++k) {
+            // POLLNVAL (the descriptor is not open: a source closed behind the library's back) makes poll() return at once on
+            // every pass without ever delivering a byte or an end of stream -- without this test the loop would spin forever
+            if (pf[k].revents & POLLNVAL) { errno = EBADF; err("read"); return FMD_ERR_IO; }
             if (!(pf[k].revents & (POLLIN | POLLHUP | POLLERR))) continue;
             const uint32_t c = who[k];
             const ssize_t g = recv(pf[k].fd, base + (size_t)c * row_stride + n_read[c], nbytes - n_read[c], MSG_DONTWAIT);

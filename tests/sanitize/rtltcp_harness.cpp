@@ -6,11 +6,15 @@
 // usage: rtltcp_harness <port> <timeout_ms> <nbytes per read> <reads> [<opcode> <param>]...
 //        rtltcp_harness many <timeout_ms> <nbytes per row> <reads> <port>...      (fmd_rtltcp_read_many over all the ports:
 //                       many <status> <rows full> <rows short> <sum of all bytes read>)
+//        rtltcp_harness nval <timeout_ms> <nbytes per row> <port> <port>       (two sources; the second one's descriptor is closed
+//                       behind the library's back before fmd_rtltcp_read_many: poll() reports POLLNVAL -> nval <status>)
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
 #include <string>
 #include <vector>
+
+#include <unistd.h>
 
 #include "../../include/fmd.h"
 
@@ -42,10 +46,31 @@ static int many(int argc, char** argv)
     return 0;
 }
 
+static int nval(int argc, char** argv)
+{
+    if (argc < 6) return 2;
+    const uint32_t timeout_ms = (uint32_t)strtoul(argv[2], nullptr, 10);
+    const size_t nbytes = (size_t)strtoul(argv[3], nullptr, 10);
+    fmd_rtltcp* src[2] = {nullptr, nullptr};
+    if (fmd_rtltcp_open("127.0.0.1", (uint16_t)atoi(argv[4]), timeout_ms, &src[0]) != FMD_OK) { printf("open 0 failed %s\n", g_err.c_str()); return 0; }
+    const int probe = dup(0);                               // the lowest free descriptor: the one the next socket() will get
+    close(probe);
+    if (fmd_rtltcp_open("127.0.0.1", (uint16_t)atoi(argv[5]), timeout_ms, &src[1]) != FMD_OK) { printf("open 1 failed %s\n", g_err.c_str()); return 0; }
+    close(probe);                                           // the second source's socket, closed behind the library's back
+    std::vector<uint8_t> buf(2 * nbytes);
+    size_t got[2] = {0, 0};
+    const int st = fmd_rtltcp_read_many(src, 2, buf.data(), nbytes, nbytes, got);
+    printf("nval %d %zu %s\n", st, got[1], g_err.c_str());
+    fmd_rtltcp_close(src[0]);
+    fmd_rtltcp_close(src[1]);                                // (close() of an already closed descriptor: EBADF, harmless)
+    return 0;
+}
+
 int main(int argc, char** argv)
 {
     if (argc < 5) return 2;
     if (std::string(argv[1]) == "many") return many(argc, argv);
+    if (std::string(argv[1]) == "nval") return nval(argc, argv);
     const uint16_t port = (uint16_t)atoi(argv[1]);
     const uint32_t timeout_ms = (uint32_t)strtoul(argv[2], nullptr, 10);
     const size_t nbytes = (size_t)strtoul(argv[3], nullptr, 10);

@@ -5,6 +5,8 @@ resample fused").  No reference counterpart exists for a tapped FIR, so the anch
   * GPU: the fused kernel == that composition for arbitrary taps / shifts / rates / ragged streaming calls, and therefore
     == the boxcar kernel == the reference for all-ones taps (checked directly too), incl. BASELINE configs[3] at its full
     size (127 taps, decimate 8, 256 channels x 2 MiB) with every channel compared."""
+import math
+
 import numpy as np
 import pytest
 
@@ -97,7 +99,7 @@ def test_gpu_fused_register_form(fmd, oracle, T, M, fast, slow):
     the discriminator straight out of the matrix-core result registers (fmd_firdemod_reg_kernel): tiny first calls, many
     tiles per channel, full scale, state carried over six calls."""
     kn = fused_case(fmd, oracle, T, M, fast, slow, f32_only=True)
-    assert kn.startswith("fmd_firdemod_reg_kernel<"), kn
+    assert kn.startswith("(anonymous namespace)::fmd_firdemod_reg_kernel<") and kn.endswith(", true>"), kn
 
 
 @pytest.mark.gpu
@@ -112,7 +114,7 @@ def test_gpu_fused_register_form_variants(fmd, oracle, request, ng):
     for T, M, fast, slow in REG_SHAPES[:4]:
         kn = fused_case(fmd, oracle, T, M, fast, slow, f32_only=True)
         want_reg = ng != "0" and fast // slow >= 4 * int(ng)         # an audio group must hold a lane's 4 ng - 3 consecutive outputs
-        assert kn.startswith("fmd_firdemod_reg_kernel<") == want_reg and (not want_reg or kn.endswith(", %s>" % ng)), kn
+        assert kn.startswith("(anonymous namespace)::fmd_firdemod_reg_kernel<") == want_reg and (not want_reg or kn.endswith(", %s, true>" % ng)), kn
 
 
 def fused_case(fmd, oracle, T, M, fast, slow, f32_only=False):
@@ -246,7 +248,7 @@ def test_gpu_fused_checkpoint_resume(fmd, oracle, T, M, fast, slow):
         for c in range(nch):
             assert np.array_equal(got[c], oracle.firdemod(hs[c], iq[c])), c
     blob = a.checkpoint()
-    assert len(blob) == 56 + nch * 32 + nch * 4 * ((T - 1 + ((T - 1) & 1)) // 2)   # header + FmdChanState + history words
+    assert len(blob) == 64 + nch * 32 + nch * 4 * ((T - 1 + ((T - 1) & 1)) // 2)   # header + FmdChanState + history words
     b = fmd.FirDemodBank(taps, M, fast, slow, nch, shift=shift)
     b.resume(blob)
     for c in range(nch):
@@ -266,12 +268,44 @@ def test_gpu_fused_checkpoint_resume(fmd, oracle, T, M, fast, slow):
     other = fmd.FirDemodBank(np.where(taps > 0, taps - 1, taps + 1).astype(np.int16), M, fast, slow, nch, shift=shift)
     fewer = fmd.FirDemodBank(taps, M, fast, slow, nch - 1, shift=shift)
     bad_magic = b"\0" + blob[1:]
-    bad_phase = bytearray(blob); bad_phase[56 + 4] ^= 1                  # channel 0's lpr_index_r
-    for target, data in [(other, blob), (fewer, blob), (b, blob[:-4]), (b, blob + b"\0\0\0\0"), (b, blob[:20]), (b, bad_magic),
-                         (b, bytes(bad_phase))]:
+
+    def resealed(edit):
+        """A hand-made blob: `edit` changes bytes, then the checksum (FNV-1a 64 of the header with that field zeroed + the
+        payload, the last 8 header bytes) is recomputed -- so only the range checks stand between it and the kernels."""
+        d = bytearray(blob)
+        edit(d)
+        d[56:64] = bytes(8)
+        h = 0xCBF29CE484222325
+        for x in d:
+            h = ((h ^ x) * 0x100000001B3) & 0xFFFFFFFFFFFFFFFF
+        d[56:64] = h.to_bytes(8, "little")
+        return bytes(d)
+
+    def poke_i32(off, v):
+        return lambda d: d.__setitem__(slice(off, off + 4), int(v).to_bytes(4, "little", signed=True))
+
+    ch0 = 64                                                           # FmdChanState of channel 0: prev_index, lpr_index_r, now_lpr,
+    bound = -(-128 * int(np.abs(taps.astype(np.int64)).sum()) // (1 << shift))    # lp_now_re, lp_now_im, demod_pre_re, demod_pre_im, reserved
+    group = 16384 * -(-(fast // math.gcd(fast, slow)) // (slow // math.gcd(fast, slow)))
+    assert resealed(lambda d: None) == blob                            # the checksum restated here is the library's
+    flipped = bytearray(blob); flipped[-1] ^= 0x40                     # one bit of the last channel's filter history
+    flipped_state = bytearray(blob); flipped_state[ch0 + 20] ^= 1      # channel 0's demod_pre_re, checksum left alone
+    refused = [(other, blob), (fewer, blob), (b, blob[:-4]), (b, blob + b"\0\0\0\0"), (b, blob[:20]), (b, bad_magic),
+               (b, bytes(flipped)), (b, bytes(flipped_state)),
+               (b, resealed(poke_i32(ch0 + 4, 1 + int.from_bytes(blob[ch0 + 4:ch0 + 8], "little")))),   # a channel off the bank's phase
+               (b, resealed(poke_i32(ch0 + 20, bound + 1))), (b, resealed(poke_i32(ch0 + 24, -bound - 1))),   # |demod_pre| beyond the filter's range
+               (b, resealed(poke_i32(ch0 + 32 * (nch - 1) + 8, group + 1))),                              # |now_lpr| beyond one audio group
+               (b, resealed(poke_i32(ch0 + 28, 1))), (b, resealed(poke_i32(ch0 + 0, 1))),                  # reserved / prev_index must be 0
+               (b, resealed(poke_i32(40, fast // math.gcd(fast, slow))))]                                  # header i0r >= fr
+    for target, data in refused:
         with pytest.raises(fmd.FmdError) as ei:
             target.resume(data)
         assert ei.value.status == -7, ei.value
+    # the extremes themselves are legal states
+    b.resume(resealed(lambda d: (poke_i32(ch0 + 20, bound)(d), poke_i32(ch0 + 8, -group)(d))))
+    st = b.get_state(0).as_dict()
+    assert st["demod_pre"][0] == bound and st["now_lpr"] == -group
+    b.resume(before)
     assert b.checkpoint() == before
     # a resumed-then-reset bank is a fresh one
     b.reset()

@@ -228,3 +228,17 @@ def test_read_many_64_streams_one_poll_loop(harness):
     assert p.returncode == 0 and not any(r in p.stderr for r in REPORT), p.stderr[-3000:]
     st = [l.split() for l in p.stdout.splitlines() if l.startswith("many")][0]
     assert st[1] in (str(FMD_ERR_IO), "0") and int(st[2]) <= 1          # the reset row never completes (RST may surface as an error or as an early end)
+
+
+def test_read_many_descriptor_closed_behind_the_library(harness):
+    """a source whose descriptor is no longer open makes poll() report POLLNVAL at once on every pass -- no byte, no
+    end of stream, no timeout -- and fmd_rtltcp_read_many used to spin on it at 100 % CPU forever.  Now it is a socket error:
+    FMD_ERR_IO, promptly, with the other source's row untouched by the failure."""
+    servers = [Server(lambda c: (c.sendall(HS), time.sleep(2.0))), Server(lambda c: (c.sendall(HS), time.sleep(2.0)))]   # both silent after the handshake
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=1", UBSAN_OPTIONS="print_stacktrace=1:halt_on_error=1")
+    t0 = time.time()
+    p = subprocess.run([harness, "nval", "30000", "4096"] + [str(s.port) for s in servers], capture_output=True, text=True, timeout=20, env=env)
+    assert p.returncode == 0 and not any(r in p.stderr for r in REPORT), p.stderr[-3000:]
+    st = [l.split(" ", 3) for l in p.stdout.splitlines() if l.startswith("nval")][0]
+    assert st[1] == str(FMD_ERR_IO) and st[2] == "0" and "Bad file descriptor" in st[3], st
+    assert time.time() - t0 < 10.0                                                    # far inside the 30 s timeout: not a spin, not a wait
