@@ -44,7 +44,8 @@ struct FmdExcBuf {
     FmdF64Exc rec[FMD_EXC_CAP];
 };
 
-// Fast tile geometry.  When a bank is one phase class and the tile length is a multiple of the reduced resample
+// Fast tile geometry, closed form (calls of more than FMD_FAST_ROWS tiles per channel: long block_len launches; everything
+// else takes the table below).  When a bank is one phase class and the tile length is a multiple of the reduced resample
 // rate (kt * fr % sr == 0: true for the reference's rates and for the 2.4 Msps configuration), tile t of every
 // channel is tile 0 shifted by t * Qt decimated samples, so where a tile's bytes are is a multiply-add of host
 // constants.  They sit in the FIRST 64 bytes of the kernel arguments: a fresh block fetches them with one scalar
@@ -66,20 +67,54 @@ struct FmdFastGeo {
 };
 static_assert(sizeof(FmdFastGeo) == 64, "one s_load_dwordx16");
 
-// The same per tile as a table, for rates whose tile length is NOT a multiple of the reduced resample rate (44.1 kHz
-// audio, 166 666 Hz ...: tile t then needs a division) when a channel-call has at most FMD_FAST_ROWS tiles -- which a
-// read_sync buffer always does.  The row sits in the kernel arguments right behind FmdFastGeo: one more scalar load.
+// The same per tile as a table -- what every launch of at most FMD_FAST_ROWS tiles per channel-call runs (a read_sync buffer
+// always is), whatever the rates.  Round 5: the row carries EVERYTHING a block derives from its tile index -- staged range,
+// LDS offsets, sample counts, resampler start, flags -- so that a block does one 64-byte scalar load and no index arithmetic
+// (the scalar unit is the kernels' co-bottleneck: profiles/r04_experiments.md 28; the round-4 row held six numbers and the
+// block rebuilt the rest with ~60 scalar instructions per wave).
 struct FmdTileRow {
-    uint32_t lo2, hi2;        // byte range of the channel-call the tile reads
-    int32_t  jA, jB;          // decimated samples the tile owns
+    uint32_t lo2a;            // first staged byte of the channel-call (multiple of 16)
+    uint32_t nchunks;         // 16-byte chunks staged
+    int32_t  wofs;            // LDS dword index of the call's dword 0: -(lo2a / 4)
+    int32_t  jfirst;          // jA - 1: decimated samples jfirst .. jB are formed (-1: demod_pre)
+    uint32_t cnt;             // jB - jfirst + 1
     uint32_t eq, er;          // (k0 + 1) fr - i0r - 1 = eq sr + er
+    uint32_t k0, nk;          // audio samples [k0, k0 + nk) of the call
+    int32_t  jA, jB;          // decimated samples the tile owns
+    uint32_t flags;           // FMD_ROW_*
+    int32_t  wbase;           // whole-dword windows: LDS dword index of the tile's window 0 = wofs - p0 / 2 + (D / 2) jfirst
+    int32_t  s00;             // any window: call sample where the tile's window 0 starts = D jfirst - p0
+    uint32_t par;             // rotation parity of window 0: (D / 2 odd ? jfirst : 0) ^ (p0 / 2), bit 0
+    uint32_t pad;
 };
+static_assert(sizeof(FmdTileRow) == 64, "one s_load_dwordx16");
+#define FMD_ROW_LAST  1u      /* the channel-call's last tile: writes the next state */
+#define FMD_ROW_STATE 2u      /* the tile reads the channel's state (call start, first audio sample, last tile) */
 #define FMD_FAST_ROWS 32
 
+// First 64 bytes of the kernel arguments in the table form (FmdLaunch::fast == 2): what a fresh block needs beside its row.
+struct FmdRowGeo {
+    uint64_t iq;              // device address of the input
+    uint64_t out;             // device address of the output
+    uint64_t chan_stride;     // input bytes per channel
+    uint32_t n_channels;      // (same offsets as FmdFastGeo::n_channels / per)
+    uint32_t per;
+    uint32_t out_stride;      // output samples per channel (the host admits the form only while n_channels * out_stride * 2 < 2^32)
+    uint32_t raw_cap;         // LDS bytes of the tile image: the discriminator samples sit behind it
+    uint32_t p0;              // boxcar phase of the launch's one phase class
+    uint32_t nt;              // tiles per channel-call
+    uint64_t st_in;           // channel states read by this launch
+    uint32_t pad[2];
+};
+static_assert(sizeof(FmdRowGeo) == 64, "one s_load_dwordx16");
+
 struct FmdLaunch {
-    FmdFastGeo fg;            // valid when `fast` (must stay the first member)
-    uint32_t fast;            // 0: general prologue; 1: closed-form geometry (fg alone); 2: fg + rows[tile]
-    uint32_t pad0;
+    union {                   // (must stay the first member)
+        FmdFastGeo fg;        // fast == 1
+        FmdRowGeo rg;         // fast == 2
+    };
+    uint32_t fast;            // 0: general prologue; 1: closed-form geometry (fg alone); 2: rg + rows[tile]
+    uint32_t pad0[15];        // rows start on a 64-byte line of the kernel arguments
     FmdTileRow rows[FMD_FAST_ROWS];
     const uint8_t* iq;        // [n_channels][chan_stride] interleaved u8 IQ, 16-byte aligned base
     uint64_t chan_stride;     // bytes per channel (= nbytes of the call)

@@ -132,6 +132,12 @@ struct TileCtx {
     uint32_t c, cls;
     bool valid;         // false: empty grid slot (t >= the class's tile count)
     bool whole;         // every staged chunk lies inside the input array
+    // Table form (FAST == 2, fast_ctx<2>): the row's ready-made values.  `rich` is a compile-time fact of each kernel
+    // instantiation after inlining, so every `X.rich ? row value : expression` below folds to one side.
+    bool rich = false;
+    int wbase = 0, s00 = 0;     // FmdTileRow::wbase, ::s00
+    uint32_t par = 0, nk = 0;   // FmdTileRow::par, ::nk
+    bool need_state = false;    // FMD_ROW_STATE
 };
 
 __device__ __forceinline__ TileCtx tile_setup(const FmdLaunch& L, uint32_t c, uint32_t t)
@@ -522,24 +528,29 @@ __device__ __forceinline__ void tile_body(const FmdLaunch& L, const TileCtx& X, 
     const FmdClassPlan& P = L.cls[X.cls];
     const FmdTile& T = X.T;
     const uint32_t* const raw_w = STREAM ? reinterpret_cast<const uint32_t*>((uintptr_t)X.gbase) : reinterpret_cast<const uint32_t*>(smem);
-    int16_t* const d16 = reinterpret_cast<int16_t*>(smem + (STREAM ? 0u : L.raw_cap));
+    int16_t* const d16 = reinterpret_cast<int16_t*>(smem + (STREAM ? 0u : X.rich ? L.rg.raw_cap : L.raw_cap));
 
     const uint32_t tid = threadIdx.x;
     // (the wave index as a SCALAR: the round loops' trip control then runs on the scalar unit -- s_cmp / s_cbranch -- instead of
     //  a per-lane compare and an EXEC-mask update per round)
     const uint32_t lane = tid & 63u, wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid >> 6));
-    const uint32_t p0 = P.p0, c = X.c;
+    const uint32_t p0 = X.rich ? L.rg.p0 : P.p0, c = X.c;
     const int jfirst = X.jfirst, cnt = X.cnt, wofs = STREAM ? 0 : X.wofs;
     // DH >= 8 (downsample 16, 32, 64 with kernels of their own): whole-dword windows too, but a multiple of 4 dwords long --
     // those take the wrap-around walk below, with the window length a compile-time constant
     const bool fastwin = DH > 0 && DH < 8 && (p0 & 1u) == 0u;   // windows are DH whole dwords
-    FmdChanState st{};
-    if (jfirst <= 0 || T.k0 == 0 || T.last) {                // only call-start and call-end tiles need the state
-        // st_in is read-only for the whole launch (st_out is the other buffer): constant address space ->
-        // one s_load_dwordx8 on the scalar path, which does not touch vmcnt (the prefetch stays in flight).
-        typedef const FMD_AS_CONSTANT FmdChanState* cptr_t;
-        st = *((cptr_t)(uintptr_t)L.st_in + c);
-    }
+    // Only call-start and call-end tiles need the channel's state, each in one-lane regions of its own.  st_in is read-only
+    // for the whole launch (st_out is the other buffer): constant address space -> one s_load_dwordx8 on the scalar path, which
+    // does not touch vmcnt.  Table form: the load sits INSIDE each of those regions (chan_state() at their top) -- loaded once
+    // up front under `if (needed)`, the five values had to be zeroed on the common path (five s_mov per wave of every tile)
+    // for the regions no common tile enters.
+    typedef const FMD_AS_CONSTANT FmdChanState* cptr_t;
+    FmdChanState st0{};
+    if (!X.rich && (jfirst <= 0 || T.k0 == 0 || T.last)) st0 = *((cptr_t)(uintptr_t)L.st_in + c);
+    auto chan_state = [&]() -> FmdChanState {
+        if (X.rich) return *((cptr_t)(uintptr_t)L.rg.st_in + c);
+        return st0;
+    };
 
     // Lane-constant weights of the fast window.  The window of decimated sample j starts at call dword
     // m0 = DH*j - p0/2; rotate_90's sign pattern has period 2 dwords, a lane's two windows are 64 samples
@@ -573,9 +584,11 @@ __device__ __forceinline__ void tile_body(const FmdLaunch& L, const TileCtx& X, 
         // swap, conjugate, dot products or conversions of the product -- and half the DPP traffic.  A lane's windows are
         // 2 DH dwords apart (a 2-way LDS bank conflict for odd DH: cheaper than what it saves); the rotation parity of
         // the first window is the same for every lane of a wave, the second window's differs by DH.
-        const int wbase = wofs - (int)hp + DH * jfirst;      // LDS dword index of window i is wbase + DH * i
+        const int wbase = X.rich ? X.wbase : wofs - (int)hp + DH * jfirst;      // LDS dword index of window i is wbase + DH * i
         const int jw = jfirst + (int)wave * RS;
-        const bool o1 = ((((DH & 1) ? ((uint32_t)jw ^ hp) : hp)) & 1u) != 0u, o2 = o1 != ((DH & 1) != 0);
+        // (RS is odd: the parity of jfirst + wave * RS is the row's parity bit flipped by the wave's)
+        const bool o1 = X.rich ? (((X.par ^ ((DH & 1) ? wave : 0u)) & 1u) != 0u) : (((((DH & 1) ? ((uint32_t)jw ^ hp) : hp)) & 1u) != 0u);
+        const bool o2 = o1 != ((DH & 1) != 0);
         const uint32_t r1A = o1 ? FMD_W_RE_ODD : FMD_W_RE_EVEN, r1B = o1 ? FMD_W_RE_EVEN : FMD_W_RE_ODD;
         const uint32_t m1A = o1 ? FMD_W_IM_ODD : FMD_W_IM_EVEN, m1B = o1 ? FMD_W_IM_EVEN : FMD_W_IM_ODD;
         const uint32_t r2A = o2 ? FMD_W_RE_ODD : FMD_W_RE_EVEN, r2B = o2 ? FMD_W_RE_EVEN : FMD_W_RE_ODD;
@@ -630,13 +643,14 @@ __device__ __forceinline__ void tile_body(const FmdLaunch& L, const TileCtx& X, 
             if (FULL || i2 < cnt) d16[i2] = (int16_t)disc_f32_c<DH == 1, true>(ar2, ai2, ar1, ai1);
         };
         int base = (int)wave * RS;
-        for (; base + 128 <= cnt && !FMD_ABLATE(6); base += NW * RS) pair_round(base, std::true_type{});
+        const int full_to = cnt - 128;                       // (the bound as ONE scalar: `base + 128 <= cnt` cost an add per round)
+        for (; base <= full_to && !FMD_ABLATE(6); base += NW * RS) pair_round(base, std::true_type{});
         for (; base < last && !FMD_ABLATE(6); base += NW * RS) pair_round(base, std::false_type{});
     } else if (fastwin) {
         // Hot loop: no branches, no special cases.  Lanes whose window lies outside the tile (the two
         // call-start samples of tile 0, surplus lanes of the last round) read whatever LDS holds there --
         // out-of-range DS reads return 0 -- and their results are either not stored or patched below.
-        const int wbase = wofs - (int)hp + DH * jfirst;      // LDS dword index of window i is wbase + DH * i
+        const int wbase = X.rich ? X.wbase : wofs - (int)hp + DH * jfirst;      // LDS dword index of window i is wbase + DH * i
         for (int base = (int)wave * RS; base < last && !FMD_ABLATE(6); base += NW * RS) {
             const int i1 = base + (int)lane, i2 = i1 + 64;
             int re1 = DH, im1 = im0, re2 = DH, im2 = im0;
@@ -670,9 +684,9 @@ __device__ __forceinline__ void tile_body(const FmdLaunch& L, const TileCtx& X, 
             if (i2 < cnt) d16[i2] = (int16_t)(FMD_ABLATE(0) ? (int)(pk2 ^ prev2) : disc_f32<kBias, false, true>(pk2, prev2));
         }
     } else if (DH == -1) {
-        d1_pair_rounds(raw_w, d16, wofs, jfirst - (int)p0, cnt, lane, wave);
+        d1_pair_rounds(raw_w, d16, wofs, X.rich ? X.s00 : jfirst - (int)p0, cnt, lane, wave);
     } else if (DH < -1 && DH >= -15) {
-        if constexpr (DH < -1 && DH >= -15) odd_pair_rounds<-DH, (-DH <= 3)>(raw_w, d16, wofs, -DH * jfirst - (int)p0, cnt, lane, wave);
+        if constexpr (DH < -1 && DH >= -15) odd_pair_rounds<-DH, (-DH <= 3)>(raw_w, d16, wofs, X.rich ? X.s00 : -DH * jfirst - (int)p0, cnt, lane, wave);
     } else {
         // Any downsample, any phase: a window of D samples starting at call sample s covers the dwords
         // s/2 .. (s + D - 1)/2; the half dwords at its ends are masked out of the byte weights.  s mod 4 (the
@@ -682,7 +696,7 @@ __device__ __forceinline__ void tile_body(const FmdLaunch& L, const TileCtx& X, 
         // window): telling the compiler so prunes every other window length, the wrap-around walk and the general loop
         // from those kernels (the launch's hot loop is the same; the kernel around it shrinks to a third)
         const int D = DH > 0 ? 2 * DH : DH < 0 ? -DH : (int)r.D;             // DH < 0: an odd downsample -DH with a kernel of its own
-        const int s00 = D * jfirst - (int)p0;                // start sample of window i is s00 + D*i
+        const int s00 = X.rich ? X.s00 : D * jfirst - (int)p0;   // start sample of window i is s00 + D*i
         const int sl = s00 + D * ((int)wave * RS + (int)lane);
         const uint32_t sm = (uint32_t)sl & 3u;               // two's complement: right for the clipped windows too
         const bool podd = ((sl >> 1) & 1) != 0;              // call-dword parity of the first dword
@@ -787,6 +801,7 @@ __device__ __forceinline__ void tile_body(const FmdLaunch& L, const TileCtx& X, 
     // wave as the loop's own stores to these entries, so program order makes the patch win.
     bool any_guard = false;                                  // a guarded f64 sample in this tile (FmdF64Exc, fmd_kernels.h)
     if (jfirst <= 0 && tid == 0) {
+        const FmdChanState st = chan_state();
         int r0, i0, r1, i1w, cr, ci;
         lds_window_sum(raw_w, wofs, 0, fmd_win_end(r.D, p0, 0), r0, i0);
         r0 += st.lp_now_re; i0 += st.lp_now_im;
@@ -809,6 +824,7 @@ __device__ __forceinline__ void tile_body(const FmdLaunch& L, const TileCtx& X, 
         // (after the barrier: another wave may have stored it) and a second barrier orders the resampler behind it.
         if (T.last) {                                        // block-uniform
             if (tid == 0) {
+                const FmdChanState st = chan_state();
                 const int j = (int)P.M - 1;                  // >= 1: the host guarantees M >= 2
                 int ar, ai, br, bi, cr, ci;
                 lds_window_sum(raw_w, wofs, fmd_win_begin(r.D, p0, j), fmd_win_end(r.D, p0, j), ar, ai);
@@ -826,6 +842,7 @@ __device__ __forceinline__ void tile_body(const FmdLaunch& L, const TileCtx& X, 
     // boundaries fall into one, and one lane redoes them -- after the barrier (another wave's loop wrote the entry)
     // and with a second one before the resampler reads it.
     if (L.block_ns && tid == 0) {
+        const FmdChanState st = chan_state();
         const uint32_t D = r.D, nb = L.block_ns;
         const uint32_t lo = (uint32_t)(T.jA > 1 ? T.jA : 1) * D;             // first sample count that can complete sample jA
         uint32_t b = lo > p0 ? (lo - p0 + nb - 1u) / nb : 1u;                 // smallest b with (p0 + b*nb) / D >= max(jA, 1)
@@ -855,8 +872,11 @@ __device__ __forceinline__ void tile_body(const FmdLaunch& L, const TileCtx& X, 
     // fa + 1 when the remainder of that one division is below fb (then the previous group ended one sample
     // earlier) -- so one small division gives both ends.  Only the first group of a call can be shorter
     // (it continues the previous call's partial sum, :410-417): one lane redoes it below.
-    const uint32_t nk = FMD_ABLATE(7) ? 0u : T.k1 - T.k0;
-    int16_t* const outc = L.out + (uint64_t)c * L.out_stride;
+    const uint32_t nk = FMD_ABLATE(7) ? 0u : X.rich ? X.nk : T.k1 - T.k0;
+    // (table form: a 32-bit product -- the host admits it only while the whole output array is below 4 GiB)
+    // (L.out itself, not the copy of its address in L.rg: a pointer that is a kernel argument is known to be global memory, one
+    //  rebuilt from an integer would make every store a flat_store)
+    int16_t* const outc = X.rich ? L.out + c * L.rg.out_stride : L.out + (uint64_t)c * L.out_stride;
     // The pass is one loop per group length, chosen by ONE block-uniform switch in front of it: with the switch inside the
     // loop (its exit is per lane) hipcc's structurizer turned the dispatch into forty scalar flag moves and tests per pass --
     // and the scalar unit is what these kernels run out of (profiles/r04_experiments.md 28).
@@ -909,6 +929,7 @@ __device__ __forceinline__ void tile_body(const FmdLaunch& L, const TileCtx& X, 
         default: resample(std::integral_constant<int, 0>{}); break;
     }
     if (T.k0 == 0 && tid == 0 && nk > 0) {                   // same lane as the loop's store to outc[0]: this one wins
+        const FmdChanState st = chan_state();
         const int e = (int)(T.eq + fmd_udiv_small(T.er, r.sr, L.inv_sr));
         int sum = st.now_lpr;
         for (int jj = 0; jj <= e; ++jj) sum += d16[jj - jfirst];
@@ -916,10 +937,11 @@ __device__ __forceinline__ void tile_body(const FmdLaunch& L, const TileCtx& X, 
     }
 
     // Guarded f64 samples (rare: within 2^-20 of an integer): their records need the finished group sums.
-    if ((jfirst < 0 || L.block_ns) && tid == 0 && any_guard) tile_exc_flush(L, X, st, raw_w, d16);
+    if ((jfirst < 0 || L.block_ns) && tid == 0 && any_guard) tile_exc_flush(L, X, chan_state(), raw_w, d16);
 
     // ---- Demod state after the call (last tile only; :232-239) -------------------------------------
     if (T.last && tid == 0 && !FMD_ABLATE(5)) {
+        const FmdChanState st = chan_state();
         FmdChanState ns_;
         const int s = P.K == 0 ? 0 : (int)fmd_audio_end(r, P.i0r, P.K - 1) + 1;
         int sum = P.K == 0 ? st.now_lpr : 0;
@@ -965,8 +987,14 @@ __device__ __forceinline__ FastAddr fast_addr(const FmdLaunch& L)
     FastAddr A;
     A.c = blockIdx.x * g.per + blockIdx.z;                   // grid (8, tiles, per): blockIdx.x is the XCD
     A.t = blockIdx.y;
-    if (FAST == 2) {                                         // the tile's row of the table
-        A.lo2 = L.rows[A.t].lo2; A.hi2 = L.rows[A.t].hi2;
+    if constexpr (FAST == 2) {                               // the tile's row of the table: the staged range ready-made
+        const FmdTileRow& R = L.rows[A.t];
+        A.lo2 = R.lo2a; A.hi2 = 0u;
+        A.gbase = L.rg.iq + (uint64_t)A.c * L.rg.chan_stride;
+        A.a0 = A.gbase + R.lo2a;
+        A.nchunks = R.nchunks;
+        A.whole = true;
+        return A;
     } else {
         const int32_t base = (int32_t)(A.t * g.step2);
         const int32_t lo = base + g.lo_off2, hi = base + g.hi_off2;
@@ -992,15 +1020,24 @@ __device__ __forceinline__ TileCtx fast_ctx(const FmdLaunch& L, const FastAddr& 
     TileCtx X;
     X.c = A.c; X.cls = 0u; X.valid = true; X.whole = A.whole;
     X.a0 = A.a0; X.nchunks = A.nchunks; X.gbase = A.gbase;
-    X.wofs = -(int)((A.lo2 & ~15u) >> 2);
     FmdTile& T = X.T;
     const uint32_t t = A.t;
+    if constexpr (FAST == 2) {                               // everything from the row: no index arithmetic
+        const FmdTileRow& R = L.rows[t];
+        X.rich = true;
+        X.wofs = R.wofs; X.jfirst = R.jfirst; X.cnt = (int)R.cnt;
+        X.wbase = R.wbase; X.s00 = R.s00; X.par = R.par; X.nk = R.nk;
+        X.need_state = (R.flags & FMD_ROW_STATE) != 0u;
+        T.last = (R.flags & FMD_ROW_LAST) != 0u;
+        T.k0 = R.k0; T.k1 = R.k0 + R.nk; T.eq = R.eq; T.er = R.er; T.jA = R.jA; T.jB = R.jB;
+        T.nLo = 0; T.nHi = 0;                                // (only the general prologue's staging reads them)
+        return X;
+    }
+    X.wofs = -(int)((A.lo2 & ~15u) >> 2);
     T.last = t + 1u == g.nt;
     T.k0 = t * L.r.kt;
     T.k1 = T.k0 + L.r.kt < P.K ? T.k0 + L.r.kt : P.K;
-    if (FAST == 2) {
-        T.eq = L.rows[t].eq; T.er = L.rows[t].er; T.jA = L.rows[t].jA; T.jB = L.rows[t].jB;
-    } else {
+    {
         T.eq = t * g.Qt + P.eq0;
         T.er = P.er0;
         const int32_t ja = (int32_t)(t * g.Qt) + g.jA_off;

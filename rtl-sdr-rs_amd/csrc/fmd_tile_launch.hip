@@ -41,19 +41,38 @@ static uint32_t fmd_fast_geometry(FmdLaunch& L, uint32_t per)
     // 32-bit arithmetic on its row and never runs past the buffer (the scalar unit is the kernels' co-bottleneck:
     // profiles/r04_experiments.md 28).  Anything else takes the general prologue.
     if (((uint64_t)(uintptr_t)L.iq | L.chan_stride | ns2) & 15u) return 0u;
-    FmdFastGeo& g = L.fg;
-    g.iq = (uint64_t)(uintptr_t)L.iq; g.iq_end = g.iq + L.total_bytes; g.chan_stride = L.chan_stride;
-    g.n_channels = L.n_channels; g.per = per; g.nt = P.nt; g.ns2 = (uint32_t)ns2; g.Qt = tl.Qt;
-    // the table whenever it fits (measured ~1 % faster than the closed form even where both apply: two scalar loads and
-    // no multiply-adds); FMD_FAST=1 keeps the closed form for A/B
-    if (P.nt <= FMD_FAST_ROWS && (tl.Rt != 0u || L.fast != 1u) ) {
+    // the table whenever it fits (round 4: ~1 % faster than the closed form even where both apply; round 5: the row carries the
+    // whole tile context); FMD_FAST=1 keeps the closed form for A/B.  The table form addresses the output array with 32-bit
+    // products.
+    if (P.nt <= FMD_FAST_ROWS && (tl.Rt != 0u || L.fast != 1u) && (uint64_t)L.n_channels * L.out_stride * 2ull < (1ull << 32)) {
+        const uint32_t hp = P.p0 >> 1, dhalf = r.D >> 1;
         for (uint32_t t = 0; t < P.nt; ++t) {
             const FmdTile T = fmd_tile_fast(r, P, tl, L.ns, t);
             if ((uint64_t)(T.jB - T.jA + 2) > L.lp_cap || (!L.stream && 2ull * (uint64_t)(T.nHi - T.nLo) + 30u > L.raw_cap)) return 0u;
-            L.rows[t] = FmdTileRow{2u * (uint32_t)T.nLo, 2u * (uint32_t)T.nHi, T.jA, T.jB, T.eq, T.er};
+            FmdTileRow R{};
+            const uint32_t lo2 = 2u * (uint32_t)T.nLo, hi2 = 2u * (uint32_t)T.nHi;
+            R.lo2a = lo2 & ~15u;
+            R.nchunks = (hi2 - R.lo2a + 15u) >> 4;
+            R.wofs = -(int32_t)(R.lo2a >> 2);
+            R.jfirst = T.jA - 1;
+            R.cnt = (uint32_t)(T.jB - R.jfirst + 1);
+            R.eq = T.eq; R.er = T.er; R.k0 = T.k0; R.nk = T.k1 - T.k0; R.jA = T.jA; R.jB = T.jB;
+            R.flags = (T.last ? FMD_ROW_LAST : 0u) | ((R.jfirst <= 0 || T.k0 == 0u || T.last) ? FMD_ROW_STATE : 0u);
+            R.wbase = R.wofs - (int32_t)hp + (int32_t)dhalf * R.jfirst;
+            R.s00 = (int32_t)r.D * R.jfirst - (int32_t)P.p0;
+            R.par = (((dhalf & 1u) ? (uint32_t)R.jfirst : 0u) ^ hp) & 1u;
+            L.rows[t] = R;
         }
+        FmdRowGeo& q = L.rg;
+        q = FmdRowGeo{};
+        q.iq = (uint64_t)(uintptr_t)L.iq; q.out = (uint64_t)(uintptr_t)L.out; q.chan_stride = L.chan_stride;
+        q.n_channels = L.n_channels; q.per = per; q.out_stride = (uint32_t)L.out_stride; q.raw_cap = L.raw_cap;
+        q.p0 = P.p0; q.nt = P.nt; q.st_in = (uint64_t)(uintptr_t)L.st_in;
         return 2u;
     }
+    FmdFastGeo& g = L.fg;
+    g.iq = (uint64_t)(uintptr_t)L.iq; g.iq_end = g.iq + L.total_bytes; g.chan_stride = L.chan_stride;
+    g.n_channels = L.n_channels; g.per = per; g.nt = P.nt; g.ns2 = (uint32_t)ns2; g.Qt = tl.Qt;
     if (tl.Rt != 0u) return 0u;
     const int64_t jA_off = (int64_t)P.eq0 - tl.fq + (P.er0 >= tl.frr ? 1 : 0);
     const int64_t jB_off = (int64_t)P.eq0 + tl.Bq + (P.er0 + tl.Br >= r.sr ? 1 : 0);

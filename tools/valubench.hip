@@ -61,7 +61,6 @@ KERNEL(k_rcp_f32,   I8("v_rcp_f32", "%8"))
 KERNEL(k_mul_f32,   I8S("v_mul_f32", ", ", "%8"))
 KERNEL(k_fma_f32,   I8S("v_fma_f32", ", %8, ", "%9"))
 KERNEL(k_add_f32,   I8S("v_add_f32", ", ", "%8"))
-KERNEL(k_pk_fma_f32, I8S("v_fma_f32", ", %8, ", "%9"))
 KERNEL(k_pk_add_u16, I8S("v_pk_add_u16", ", ", "%8"))
 KERNEL(k_pk_mul_lo_u16, I8S("v_pk_mul_lo_u16", ", ", "%8"))
 KERNEL(k_sad_u32,   I8S("v_sad_u32", ", %8, ", "%9"))
@@ -98,34 +97,38 @@ KERNEL(k_cvt_pk_i16, I8S("v_cvt_pk_i16_i32", ", ", "%8"))
 KERNEL(k_add_lshl,  I8S("v_add_lshl_u32", ", %8, ", "2"))
 KERNEL(k_lshl_or,   I8S("v_lshl_or_b32", ", 16, ", "%9"))
 
-// packed f32 (two floats per 64-bit register pair)
-#define KERNEL64(NAME, OP)                                                                              \
+// packed f32 (two floats per 64-bit register pair).  Round 4's versions of these three kernels typed the accumulators `double`
+// and reported 0.28x an add -- not a plausible issue rate (profiles/r04_valubench.txt); round 5: float2 operands as in
+// tools/pkbench.hip, finite values that stay finite (b = 1 +- 2^-23, c tiny), and tools/valubench_check.sh asserts from the
+// emitted ISA that each loop body holds exactly eight of the named instruction.
+typedef float vb_f2 __attribute__((ext_vector_type(2)));
+#define KERNEL64(NAME, BODY)                                                                            \
     __global__ void __launch_bounds__(256) NAME(unsigned* out, int iters, unsigned seed)                \
     {                                                                                                   \
-        double a0 = threadIdx.x + seed, a1 = a0 * 3, a2 = a0 * 5, a3 = a0 * 7, a4 = a0 + 11, a5 = a0 + 99, a6 = a0 + 5, a7 = a0 * 9; \
-        double b = a0 * 17 + 1, c = a0 * 29 + 3;                                                        \
+        vb_f2 a0 = {(float)(threadIdx.x + seed), 1.f}, a1 = a0 * 3.f, a2 = a0 * 5.f, a3 = a0 * 7.f, a4 = a0 + 11.f, a5 = a0 + 99.f, a6 = a0 + 5.f, a7 = a0 * 9.f; \
+        vb_f2 b = {1.0000001f, 0.9999999f}, c = {1e-9f, 2e-9f};                                         \
         for (int it = 0; it < iters; ++it) {                                                            \
-            asm volatile(OP " %0, %0, %8, %9\n" OP " %1, %1, %8, %9\n" OP " %2, %2, %8, %9\n" OP " %3, %3, %8, %9\n" \
-                         OP " %4, %4, %8, %9\n" OP " %5, %5, %8, %9\n" OP " %6, %6, %8, %9\n" OP " %7, %7, %8, %9\n" \
-                         : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b), "v"(c)); \
+            asm volatile(BODY : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b), "v"(c)); \
         }                                                                                               \
-        out[blockIdx.x * 256 + threadIdx.x] = (unsigned)(a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7);        \
+        const vb_f2 s = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7;                                          \
+        out[blockIdx.x * 256 + threadIdx.x] = (unsigned)(s.x + s.y);                                    \
     }
-#define KERNEL64B(NAME, OP)                                                                             \
-    __global__ void __launch_bounds__(256) NAME(unsigned* out, int iters, unsigned seed)                \
-    {                                                                                                   \
-        double a0 = threadIdx.x + seed, a1 = a0 * 3, a2 = a0 * 5, a3 = a0 * 7, a4 = a0 + 11, a5 = a0 + 99, a6 = a0 + 5, a7 = a0 * 9; \
-        double b = a0 * 17 + 1;                                                                         \
-        for (int it = 0; it < iters; ++it) {                                                            \
-            asm volatile(OP " %0, %0, %8\n" OP " %1, %1, %8\n" OP " %2, %2, %8\n" OP " %3, %3, %8\n" \
-                         OP " %4, %4, %8\n" OP " %5, %5, %8\n" OP " %6, %6, %8\n" OP " %7, %7, %8\n" \
-                         : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b)); \
-        }                                                                                               \
-        out[blockIdx.x * 256 + threadIdx.x] = (unsigned)(a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7);        \
-    }
-KERNEL64(k_pk_fma_f32x2, "v_pk_fma_f32")
-KERNEL64B(k_pk_add_f32x2, "v_pk_add_f32")
-KERNEL64B(k_pk_mul_f32x2, "v_pk_mul_f32")
+#define P8_3(OP) OP " %0, %0, %8, %9\n" OP " %1, %1, %8, %9\n" OP " %2, %2, %8, %9\n" OP " %3, %3, %8, %9\n" OP " %4, %4, %8, %9\n" OP " %5, %5, %8, %9\n" OP " %6, %6, %8, %9\n" OP " %7, %7, %8, %9\n"
+#define P8_2(OP) OP " %0, %0, %8\n" OP " %1, %1, %8\n" OP " %2, %2, %8\n" OP " %3, %3, %8\n" OP " %4, %4, %8\n" OP " %5, %5, %8\n" OP " %6, %6, %8\n" OP " %7, %7, %8\n"
+KERNEL64(k_pk_fma_f32x2, P8_3("v_pk_fma_f32"))
+KERNEL64(k_pk_add_f32x2, P8_2("v_pk_add_f32"))
+KERNEL64(k_pk_mul_f32x2, P8_2("v_pk_mul_f32"))
+// the same three with the modifiers a paired discriminator would use: a negated operand half (neg_lo / neg_hi), the clamp bit,
+// and a swapped source half (op_sel) -- none of them may change the issue cost
+KERNEL64(k_pk_add_f32_neg, "v_pk_add_f32 %0, %0, %8 neg_lo:[0,1] neg_hi:[0,1]\nv_pk_add_f32 %1, %1, %8 neg_lo:[0,1] neg_hi:[0,1]\nv_pk_add_f32 %2, %2, %8 neg_lo:[0,1] neg_hi:[0,1]\nv_pk_add_f32 %3, %3, %8 neg_lo:[0,1] neg_hi:[0,1]\n"
+                           "v_pk_add_f32 %4, %4, %8 neg_lo:[0,1] neg_hi:[0,1]\nv_pk_add_f32 %5, %5, %8 neg_lo:[0,1] neg_hi:[0,1]\nv_pk_add_f32 %6, %6, %8 neg_lo:[0,1] neg_hi:[0,1]\nv_pk_add_f32 %7, %7, %8 neg_lo:[0,1] neg_hi:[0,1]\n")
+KERNEL64(k_pk_fma_f32_clamp, "v_pk_fma_f32 %0, %0, %8, %9 clamp\nv_pk_fma_f32 %1, %1, %8, %9 clamp\nv_pk_fma_f32 %2, %2, %8, %9 clamp\nv_pk_fma_f32 %3, %3, %8, %9 clamp\n"
+                             "v_pk_fma_f32 %4, %4, %8, %9 clamp\nv_pk_fma_f32 %5, %5, %8, %9 clamp\nv_pk_fma_f32 %6, %6, %8, %9 clamp\nv_pk_fma_f32 %7, %7, %8, %9 clamp\n")
+KERNEL64(k_pk_mul_f32_opsel, "v_pk_mul_f32 %0, %0, %8 op_sel:[0,1] op_sel_hi:[1,0]\nv_pk_mul_f32 %1, %1, %8 op_sel:[0,1] op_sel_hi:[1,0]\nv_pk_mul_f32 %2, %2, %8 op_sel:[0,1] op_sel_hi:[1,0]\nv_pk_mul_f32 %3, %3, %8 op_sel:[0,1] op_sel_hi:[1,0]\n"
+                             "v_pk_mul_f32 %4, %4, %8 op_sel:[0,1] op_sel_hi:[1,0]\nv_pk_mul_f32 %5, %5, %8 op_sel:[0,1] op_sel_hi:[1,0]\nv_pk_mul_f32 %6, %6, %8 op_sel:[0,1] op_sel_hi:[1,0]\nv_pk_mul_f32 %7, %7, %8 op_sel:[0,1] op_sel_hi:[1,0]\n")
+// a DEPENDENT chain (one accumulator, eight deep) against the same of v_add_f32: latency, not issue
+KERNEL64(k_pk_add_f32_chain, "v_pk_add_f32 %0, %0, %8\nv_pk_add_f32 %0, %0, %8\nv_pk_add_f32 %0, %0, %8\nv_pk_add_f32 %0, %0, %8\nv_pk_add_f32 %0, %0, %8\nv_pk_add_f32 %0, %0, %8\nv_pk_add_f32 %0, %0, %8\nv_pk_add_f32 %0, %0, %8\n")
+KERNEL(k_add_f32_chain, "v_add_f32 %0, %0, %8\nv_add_f32 %0, %0, %8\nv_add_f32 %0, %0, %8\nv_add_f32 %0, %0, %8\nv_add_f32 %0, %0, %8\nv_add_f32 %0, %0, %8\nv_add_f32 %0, %0, %8\nv_add_f32 %0, %0, %8\n")
 
 template <typename K>
 static void run(const char* name, K kern, int blocks_per_cu, int iters, double base_ns)
@@ -177,6 +180,7 @@ int main()
     R(k_cvt_pk_i16); R(k_add_lshl); R(k_lshl_or);
     R(k_add_f32_abs); R(k_add_f32_clamp); R(k_fma_f32_neg); R(k_mul_f32_e64); R(k_cmp8_f32);
     R(k_pk_fma_f32x2); R(k_pk_add_f32x2); R(k_pk_mul_f32x2);
+    R(k_pk_add_f32_neg); R(k_pk_fma_f32_clamp); R(k_pk_mul_f32_opsel); R(k_pk_add_f32_chain); R(k_add_f32_chain);
     R(k_mul_u24); R(k_mad_i24); R(k_xad_u32); R(k_ldexp_f32); R(k_max_u32); R(k_min_u32); R(k_mul_hi_u32);
     return 0;
 }
