@@ -196,7 +196,10 @@ __device__ __forceinline__ void fir_dma16(const unsigned char* g, unsigned char*
 __device__ __forceinline__ uint32_t fir_swz_slot(uint32_t slot) { return slot ^ (((slot >> 4) & 1u) << 1); }
 
 template <int NKU, bool SWZ>
-__global__ void __launch_bounds__(kFirThreads, 8) fmd_fir_mfma_kernel(const FirLaunch L)
+// (8 blocks per CU = 64 VGPRs per lane hold up to six operand fragments beside the accumulators; the two longest filter shapes
+//  -- NKU 7, 8: beyond ~190 taps at decimate 8 -- spilled 4 ... 32 registers to scratch memory under that bound, which
+//  tests/test_isa_invariants.py now forbids for every kernel: they take 6 and 4 blocks per CU)
+__global__ void __launch_bounds__(kFirThreads, NKU <= 6 ? 8 : (NKU == 7 ? 6 : 4)) fmd_fir_mfma_kernel(const FirLaunch L)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     const uint32_t tid = threadIdx.x;

@@ -159,7 +159,7 @@ static __device__ __noinline__ void exc_emit_direct(FmdExcBuf* exc, uint32_t c, 
 }
 
 template <int NKU, int RS>
-__global__ void __launch_bounds__(kThreads, 8) fmd_firdemod_kernel(const FirDemodLaunch L)
+__global__ void __launch_bounds__(kThreads, NKU <= 7 ? 8 : 6) fmd_firdemod_kernel(const FirDemodLaunch L)   // (NKU 8 spilled at 8 blocks per CU)
 {
     constexpr bool REUSE = RS > 0;                           // RS = decim / 8: k-steps between a column's output groups
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
@@ -424,8 +424,16 @@ __global__ void __launch_bounds__(kThreads, 8) fmd_firdemod_kernel(const FirDemo
 //     kernel above) and adds the two partial sums to the groups' accumulators in LDS.
 // Gone: the packed-sample array (4 bytes per output: the tile grows from 17 to 22 audio samples at 8 tiles per CU), its
 // stores and 4-way-conflicting reads, one barrier, the per-lane run bookkeeping of the second pass.
+// (blocks per CU by column length; the long-filter shapes NKU >= 7 and the table-less form -- calls of more than kFdRows tiles --
+//  one step lower: at the bounds of the common shapes they spilled 4 ... 8 registers to scratch memory)
+constexpr int fd_reg_blocks(int nku, int ng, bool rows)
+{
+    if (nku >= 7 && ng == 6) return 5;
+    if (nku >= 7 || !rows) return ng <= 6 ? 6 : (ng <= 8 ? 4 : 3);
+    return ng <= 6 ? 8 : (ng <= 8 ? 5 : 3);
+}
 template <int NKU, int NG, bool ROWS>
-__global__ void __launch_bounds__(kThreads, NG <= 6 ? 8 : (NG <= 8 ? 5 : 3)) fmd_firdemod_reg_kernel(const FirDemodLaunch L)
+__global__ void __launch_bounds__(kThreads, fd_reg_blocks(NKU, NG, ROWS)) fmd_firdemod_reg_kernel(const FirDemodLaunch L)
 {
     constexpr int PC = 4 * NG - 2;                           // outputs per column
     constexpr int WSTEP = 16 * PC - 1;                       // tile outputs from one wave's first column to the next wave's

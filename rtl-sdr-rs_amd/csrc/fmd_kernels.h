@@ -90,6 +90,7 @@ struct FmdTileRow {
 static_assert(sizeof(FmdTileRow) == 64, "one s_load_dwordx16");
 #define FMD_ROW_LAST  1u      /* the channel-call's last tile: writes the next state */
 #define FMD_ROW_STATE 2u      /* the tile reads the channel's state (call start, first audio sample, last tile) */
+#define FMD_ROW_BLOCKS 4u     /* the launch carries several reference calls (fmd_demod_set_block_len): every row of such a launch */
 #define FMD_FAST_ROWS 32
 
 // First 64 bytes of the kernel arguments in the table form (FmdLaunch::fast == 2): what a fresh block needs beside its row.

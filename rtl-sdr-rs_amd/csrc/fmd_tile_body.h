@@ -61,6 +61,18 @@ constexpr int RS = 127;
 #define FMD_AS_LDS
 #endif
 
+// Opens a region that only `special` tiles enter (TileCtx::special_bits, wave-uniform).  The flag word goes through an empty
+// asm at every site: the test is then s_and + s_cbranch_scc on the spot -- hipcc otherwise keeps ONE 64-bit mask of the
+// condition alive across the whole body and folds `if (special) if (cond && tid == 0)` back into a vector condition, which puts
+// the mask bookkeeping (and the scalar loads of `cond`) on every tile's path again.
+__device__ __forceinline__ bool fmd_special(uint32_t bits, bool rich)
+{
+    if (!rich) return true;                                  // the other prologues test every condition themselves
+    asm volatile("" : "+s"(bits));
+    return bits != 0u;
+}
+#define FMD_SPECIAL_ONLY(X) if (fmd_special((X).special_bits, (X).rich))
+
 // Cache policy of the staging loads (aux of global_load_lds): 2 = nt (read once, do not keep).  Settled-clock A/B at the
 // bench configuration: nt -0.8 % against the default policy (0), equal elsewhere; on some boxes the default is 15 % slower
 // (profiles/HISTORY.md).
@@ -138,6 +150,11 @@ struct TileCtx {
     int wbase = 0, s00 = 0;     // FmdTileRow::wbase, ::s00
     uint32_t par = 0, nk = 0;   // FmdTileRow::par, ::nk
     bool need_state = false;    // FMD_ROW_STATE
+    // Does the tile have ANY of the one-lane jobs around the rounds and the resampler -- call-start patch, block_len boundaries,
+    // first audio sample, guard records, state epilogue?  A common tile has none, and in the table form it learns so from ONE
+    // flag test per group of them (each `cond && tid == 0` region costs ~5 scalar instructions of mask bookkeeping whether or
+    // not it is entered; round 4 counted ~75 per wave for them).  The other prologues test every condition as before.
+    uint32_t special_bits = 1u;
 };
 
 __device__ __forceinline__ TileCtx tile_setup(const FmdLaunch& L, uint32_t c, uint32_t t)
@@ -639,8 +656,15 @@ __device__ __forceinline__ void tile_body(const FmdLaunch& L, const TileCtx& X, 
             const float br1 = u2f(wave_shr1_dead(dead1, f2u(ar2))), bi1 = u2f(wave_shr1_dead(dead2, f2u(ai2)));   // second window of lane l - 1
             // (:362); DH == 1 is downsample 2: no i32 wrap to emulate.  The discriminators sit INSIDE the predicated stores
             // (see stream_pair_rounds)
+#ifdef FMD_PK_DISC
+            int o1, o2;
+            disc_f32_c_x2<DH == 1>(ar1, ai1, br1, bi1, ar2, ai2, o1, o2);
+            if (lane > 0 && (FULL || i1 < cnt)) d16[i1] = (int16_t)o1;
+            if (FULL || i2 < cnt) d16[i2] = (int16_t)o2;
+#else
             if (lane > 0 && (FULL || i1 < cnt)) d16[i1] = (int16_t)disc_f32_c<DH == 1, true>(ar1, ai1, br1, bi1);
             if (FULL || i2 < cnt) d16[i2] = (int16_t)disc_f32_c<DH == 1, true>(ar2, ai2, ar1, ai1);
+#endif
         };
         int base = (int)wave * RS;
         const int full_to = cnt - 128;                       // (the bound as ONE scalar: `base + 128 <= cnt` cost an add per round)
@@ -756,8 +780,11 @@ __device__ __forceinline__ void tile_body(const FmdLaunch& L, const TileCtx& X, 
                     wa = pa[o + 1] ^ 0x80808080u; wb = pb[o + 1] ^ 0x80808080u;
                     re1 = sdot4(wa, wreB, re1); im1 = sdot4(wa, wimB, im1);
                     re2 = sdot4(wb, wreB, re2); im2 = sdot4(wb, wimB, im2);
+                    // wrap: a mask where the window length is a compile-time power of two (downsample 16, 32, 64), sign-mask
+                    // arithmetic otherwise -- as `o == ndw ? 0 : o` it was a compare and a VCC-masked select per two dwords
                     o += 2u;
-                    o = o == (uint32_t)ndw ? 0u : o;
+                    if constexpr (DH >= 8 && (DH & (DH - 1)) == 0) o &= (uint32_t)(DH - 1);     // (here ndw == DH: see `rotate`)
+                    else o &= (uint32_t)((int)(o - (uint32_t)ndw) >> 31);                   // o < ndw: keep; o == ndw: 0
                 }
                 const uint32_t pk1 = pack_lp_perm(re1, im1), pk2 = pack_lp_perm(re2, im2);
                 const uint32_t prev1 = wave_shr1(pk1);
@@ -800,7 +827,7 @@ __device__ __forceinline__ void tile_body(const FmdLaunch& L, const TileCtx& X, 
     // window plus lp_now, d[0] takes the f64 path (:359); d[0] and d[1] are rewritten with them.  Same
     // wave as the loop's own stores to these entries, so program order makes the patch win.
     bool any_guard = false;                                  // a guarded f64 sample in this tile (FmdF64Exc, fmd_kernels.h)
-    if (jfirst <= 0 && tid == 0) {
+    FMD_SPECIAL_ONLY(X) if (jfirst <= 0 && tid == 0) {
         const FmdChanState st = chan_state();
         int r0, i0, r1, i1w, cr, ci;
         lds_window_sum(raw_w, wofs, 0, fmd_win_end(r.D, p0, 0), r0, i0);
@@ -822,7 +849,7 @@ __device__ __forceinline__ void tile_body(const FmdLaunch& L, const TileCtx& X, 
         // window the span runs past the channel-call -- stream_pair_rounds clamps its load into the call, which shifts the
         // lane's bytes.  At most that one sample per channel-call can be affected; one lane redoes it from global memory
         // (after the barrier: another wave may have stored it) and a second barrier orders the resampler behind it.
-        if (T.last) {                                        // block-uniform
+        FMD_SPECIAL_ONLY(X) if (T.last) {                    // block-uniform
             if (tid == 0) {
                 const FmdChanState st = chan_state();
                 const int j = (int)P.M - 1;                  // >= 1: the host guarantees M >= 2
@@ -841,7 +868,7 @@ __device__ __forceinline__ void tile_body(const FmdLaunch& L, const TileCtx& X, 
     // f64 path against its predecessor (:359).  A tile owns discriminator samples jA .. jB; at most a few
     // boundaries fall into one, and one lane redoes them -- after the barrier (another wave's loop wrote the entry)
     // and with a second one before the resampler reads it.
-    if (L.block_ns && tid == 0) {
+    FMD_SPECIAL_ONLY(X) if (L.block_ns && tid == 0) {
         const FmdChanState st = chan_state();
         const uint32_t D = r.D, nb = L.block_ns;
         const uint32_t lo = (uint32_t)(T.jA > 1 ? T.jA : 1) * D;             // first sample count that can complete sample jA
@@ -862,7 +889,7 @@ __device__ __forceinline__ void tile_body(const FmdLaunch& L, const TileCtx& X, 
             any_guard |= g;
         }
     }
-    if (L.block_ns) __syncthreads();
+    FMD_SPECIAL_ONLY(X) if (L.block_ns) __syncthreads();
 
     // a block that is nearly done holds 20 KB of LDS for nothing: let its last phase win issue arbitration
     // (A/B, two interleaved rounds: config 3 0.1620 -> 0.1607 ms, the reference's rates equal)
@@ -916,19 +943,16 @@ __device__ __forceinline__ void tile_body(const FmdLaunch& L, const TileCtx& X, 
             }
         }
     };
-    if (r.fr == 1u) resample(std::integral_constant<int, -1>{});
-    else switch (L.fa) {                                     // block-uniform
-        case 1: resample(std::integral_constant<int, 1>{}); break;
-        case 2: resample(std::integral_constant<int, 2>{}); break;
-        case 3: resample(std::integral_constant<int, 3>{}); break;
-        case 4: resample(std::integral_constant<int, 4>{}); break;
-        case 5: resample(std::integral_constant<int, 5>{}); break;
-        case 6: resample(std::integral_constant<int, 6>{}); break;
-        case 7: resample(std::integral_constant<int, 7>{}); break;
-        case 8: resample(std::integral_constant<int, 8>{}); break;
-        default: resample(std::integral_constant<int, 0>{}); break;
-    }
-    if (T.k0 == 0 && tid == 0 && nk > 0) {                   // same lane as the loop's store to outc[0]: this one wins
+    // (an explicit decision tree, every leaf its own call: as a `switch` with a shared default hipcc's structurizer threaded
+    //  three 64-bit "which case ran" flags through all of it -- set, tested and cleared on every tile's path)
+#define FMD_RS(N) resample(std::integral_constant<int, N>{})
+    const uint32_t fa = L.fa;                                // block-uniform; >= 1 (rate_out >= rate_resample)
+    if (r.fr == 1u) FMD_RS(-1);
+    else if (fa <= 4u) { if (fa <= 2u) { if (fa == 1u) FMD_RS(1); else FMD_RS(2); } else { if (fa == 3u) FMD_RS(3); else FMD_RS(4); } }
+    else if (fa <= 8u) { if (fa <= 6u) { if (fa == 5u) FMD_RS(5); else FMD_RS(6); } else { if (fa == 7u) FMD_RS(7); else FMD_RS(8); } }
+    else FMD_RS(0);
+#undef FMD_RS
+    FMD_SPECIAL_ONLY(X) if (T.k0 == 0 && tid == 0 && nk > 0) {   // same lane as the loop's store to outc[0]: this one wins
         const FmdChanState st = chan_state();
         const int e = (int)(T.eq + fmd_udiv_small(T.er, r.sr, L.inv_sr));
         int sum = st.now_lpr;
@@ -937,10 +961,10 @@ __device__ __forceinline__ void tile_body(const FmdLaunch& L, const TileCtx& X, 
     }
 
     // Guarded f64 samples (rare: within 2^-20 of an integer): their records need the finished group sums.
-    if ((jfirst < 0 || L.block_ns) && tid == 0 && any_guard) tile_exc_flush(L, X, chan_state(), raw_w, d16);
+    FMD_SPECIAL_ONLY(X) if ((jfirst < 0 || L.block_ns) && tid == 0 && any_guard) tile_exc_flush(L, X, chan_state(), raw_w, d16);
 
     // ---- Demod state after the call (last tile only; :232-239) -------------------------------------
-    if (T.last && tid == 0 && !FMD_ABLATE(5)) {
+    FMD_SPECIAL_ONLY(X) if (T.last && tid == 0 && !FMD_ABLATE(5)) {
         const FmdChanState st = chan_state();
         FmdChanState ns_;
         const int s = P.K == 0 ? 0 : (int)fmd_audio_end(r, P.i0r, P.K - 1) + 1;
@@ -980,6 +1004,10 @@ struct FastAddr {
     bool whole;
 };
 
+// Row t of the table.  (Indexing is all hipcc may see: taking the address of a member of the by-value kernel-argument struct --
+// to form a 32-bit row offset by hand -- makes it copy the whole 3 KB argument block to scratch memory first.)
+__device__ __forceinline__ const FmdTileRow* fast_row(const FmdLaunch& L, uint32_t t) { return &L.rows[t]; }
+
 template <int FAST>
 __device__ __forceinline__ FastAddr fast_addr(const FmdLaunch& L)
 {
@@ -988,9 +1016,9 @@ __device__ __forceinline__ FastAddr fast_addr(const FmdLaunch& L)
     A.c = blockIdx.x * g.per + blockIdx.z;                   // grid (8, tiles, per): blockIdx.x is the XCD
     A.t = blockIdx.y;
     if constexpr (FAST == 2) {                               // the tile's row of the table: the staged range ready-made
-        const FmdTileRow& R = L.rows[A.t];
+        const FmdTileRow& R = *fast_row(L, A.t);
         A.lo2 = R.lo2a; A.hi2 = 0u;
-        A.gbase = L.rg.iq + (uint64_t)A.c * L.rg.chan_stride;
+        A.gbase = L.rg.iq + (uint64_t)A.c * (uint32_t)L.rg.chan_stride;      // (a call is below 2^31 bytes per channel)
         A.a0 = A.gbase + R.lo2a;
         A.nchunks = R.nchunks;
         A.whole = true;
@@ -1023,11 +1051,12 @@ __device__ __forceinline__ TileCtx fast_ctx(const FmdLaunch& L, const FastAddr& 
     FmdTile& T = X.T;
     const uint32_t t = A.t;
     if constexpr (FAST == 2) {                               // everything from the row: no index arithmetic
-        const FmdTileRow& R = L.rows[t];
+        const FmdTileRow& R = *fast_row(L, t);
         X.rich = true;
         X.wofs = R.wofs; X.jfirst = R.jfirst; X.cnt = (int)R.cnt;
         X.wbase = R.wbase; X.s00 = R.s00; X.par = R.par; X.nk = R.nk;
         X.need_state = (R.flags & FMD_ROW_STATE) != 0u;
+        X.special_bits = R.flags & (FMD_ROW_STATE | FMD_ROW_BLOCKS);
         T.last = (R.flags & FMD_ROW_LAST) != 0u;
         T.k0 = R.k0; T.k1 = R.k0 + R.nk; T.eq = R.eq; T.er = R.er; T.jA = R.jA; T.jB = R.jB;
         T.nLo = 0; T.nHi = 0;                                // (only the general prologue's staging reads them)

@@ -57,7 +57,7 @@ static uint32_t fmd_fast_geometry(FmdLaunch& L, uint32_t per)
             R.jfirst = T.jA - 1;
             R.cnt = (uint32_t)(T.jB - R.jfirst + 1);
             R.eq = T.eq; R.er = T.er; R.k0 = T.k0; R.nk = T.k1 - T.k0; R.jA = T.jA; R.jB = T.jB;
-            R.flags = (T.last ? FMD_ROW_LAST : 0u) | ((R.jfirst <= 0 || T.k0 == 0u || T.last) ? FMD_ROW_STATE : 0u);
+            R.flags = (T.last ? FMD_ROW_LAST : 0u) | ((R.jfirst <= 0 || T.k0 == 0u || T.last) ? FMD_ROW_STATE : 0u) | (L.block_ns ? FMD_ROW_BLOCKS : 0u);
             R.wbase = R.wofs - (int32_t)hp + (int32_t)dhalf * R.jfirst;
             R.s00 = (int32_t)r.D * R.jfirst - (int32_t)P.p0;
             R.par = (((dhalf & 1u) ? (uint32_t)R.jfirst : 0u) ^ hp) & 1u;

@@ -1,0 +1,89 @@
+#!/usr/bin/env python3
+"""Interleaved A/B of library BUILDS inside ONE process on ONE box: every build is dlopen()ed side by side (its own handle, its own
+code objects), all run on the same input buffers and the same clocks, one after the other, round after round -- processes of
+their own per build (scripts/ab_libs.sh) turned out to differ by up to 2 % between themselves whatever they load
+(profiles/r05_experiments.md section 2).  Usage:
+    tools/ab_libs.py [--cfg ref|24|D,fast,slow]... [--rounds 5] [--steps 100] name=path/to/lib.so name2=...   ('name=' : the shipped library)
+Prints one JSON line per (config, build) with the per-round times, the median and the difference to the first build."""
+import argparse, ctypes as C, json, os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+import rtl_sdr_rs_amd as fmd
+from rtl_sdr_rs_amd import _ffi
+
+NAMED = {"ref": (6, 170000, 32000), "24": (10, 240000, 32000)}
+
+
+def load(path):
+    l = C.CDLL(path)
+    for name, (res, args) in _ffi.PROTOTYPES.items():
+        try:
+            fn = getattr(l, name)
+        except AttributeError:
+            continue
+        fn.restype, fn.argtypes = res, args
+    return l
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--cfg", action="append", default=[])
+    ap.add_argument("--rounds", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--settle", type=int, default=100)
+    ap.add_argument("--channels", type=int, default=4096)
+    ap.add_argument("builds", nargs="+")
+    a = ap.parse_args()
+    cfgs = [NAMED[c] if c in NAMED else tuple(int(x) for x in c.split(",")) for c in (a.cfg or ["24", "ref"])]
+    builds = []
+    for b in a.builds:
+        name, _, path = b.partition("=")
+        builds.append((name, load(os.path.join(ROOT, path) if path else _ffi.SO_PATH)))
+    nch, N = a.channels, fmd.DEFAULT_BUF_LENGTH
+    stream = torch.cuda.current_stream().cuda_stream
+    bufs = []
+    for b in range(3):
+        t = torch.empty((nch, N), dtype=torch.uint8, device="cuda")
+        fmd.synth.fill_device(t.data_ptr(), nch, N, sample_offset=b * (N // 2), stream=stream)
+        bufs.append(t)
+    torch.cuda.synchronize()
+    for D, fast, slow in cfgs:
+        cfg = fmd.DemodConfig(fast, fast, slow, D, max(1, (1 << 15) // (128 * D)))
+        cap = int(builds[0][1].fmd_out_cap(C.byref(cfg), N))
+        out = torch.zeros((nch, cap), dtype=torch.int16, device="cuda")
+        hs = []
+        for name, l in builds:
+            h = C.c_void_p()
+            dev = fmd.DeviceConfig(nch, -1, 0)
+            rc = l.fmd_demod_new(C.byref(cfg), C.byref(dev), C.byref(h))
+            assert rc == 0, (name, rc)
+            hs.append(h)
+        res = {name: [] for name, _ in builds}
+        kern = {}
+        for rnd in range(a.rounds):
+            for (name, l), h in zip(builds, hs):
+                for i in range(a.settle):
+                    l.fmd_demod_demodulate_device(h, bufs[i % 3].data_ptr(), N, out.data_ptr(), cap, None, stream)
+                torch.cuda.synchronize()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for i in range(a.steps):
+                    l.fmd_demod_demodulate_device(h, bufs[i % 3].data_ptr(), N, out.data_ptr(), cap, None, stream)
+                e1.record(); torch.cuda.synchronize()
+                assert l.fmd_demod_check(h) == 0
+                res[name].append(e0.elapsed_time(e1) / a.steps)
+                buf = C.create_string_buffer(128)
+                l.fmd_demod_last_kernel(h, buf, len(buf)); kern[name] = buf.value.decode()
+        base = None
+        for (name, l), h in zip(builds, hs):
+            ts = sorted(res[name]); med = ts[len(ts) // 2]
+            base = base or med
+            print(json.dumps({"cfg": [D, fast, slow], "build": name, "kernel": kern[name], "ms": [round(t, 4) for t in res[name]], "median_ms": round(med, 4),
+                              "vs_first_pct": round(100 * (med / base - 1), 2)}), flush=True)
+            l.fmd_demod_free(h)
+        del out
+
+
+if __name__ == "__main__":
+    main()
