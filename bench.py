@@ -46,7 +46,8 @@ HBM_PEAK_GBS = 8000.0            # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E
 KERNEL_EXPECTED = "fmd_tk::fmd_demod_tile_kernel<5, 2>"
 MIN_TIMED_S = 1.0                # repeat the K-step region until this much has been timed
 MAX_REGIONS = 4000
-PMC_SUMMARY = os.path.join("profiles", "r04_pmc_summary.json")
+PMC_SUMMARY = os.path.join("profiles", "r05_pmc_summary.json")
+BOUNDS = os.path.join("profiles", "r05_bounds.json")   # per-row pipe utilisation from the committed PMC passes (scripts/summarize_bounds.py)
 
 
 # what the headline kernel is built from (the FIR kernels, the sink and the CLI do not enter it)
@@ -64,6 +65,33 @@ def kernel_source_hash():
     return h.hexdigest()[:16]
 
 
+def load_bounds():
+    """profiles/r05_bounds.json (scripts/summarize_bounds.py): how busy the vector / scalar / matrix pipes were per row, from the committed
+    PMC passes -- quoted only when they were taken on THESE kernel sources (same rule as the traffic figure)."""
+    try:
+        with open(os.path.join(ROOT, BOUNDS)) as f:
+            b = json.load(f)
+    except (OSError, ValueError):
+        return None
+    b["current"] = b.get("kernel_source_sha16") == kernel_source_hash()
+    return b
+
+
+def bound_fields(b, key, hbm_frac, section="demod"):
+    """`bound` + the pipe fractions of one row.  A row is VALU-bound when its vector pipes were executing >= 70 % of the launch (under the
+    counters) and that share exceeds the launch's HBM fraction; HBM-bound otherwise."""
+    if not b:
+        return {}
+    row = (b.get(section) or {}).get(key) if section == "demod" else b.get(section)
+    if not row:
+        return {}
+    out = {k: row[k] for k in ("valu_issue_frac", "salu_issue_frac", "mfma_busy_frac", "lds_bank_conflict_share") if row.get(k) is not None}
+    v = row.get("valu_issue_frac") or 0.0
+    out["bound"] = "valu" if v >= 0.70 and v > hbm_frac else "hbm"
+    out["bound_source"] = "%s%s" % (BOUNDS, "" if b.get("current") else " (taken on EARLIER kernel sources: indicative only)")
+    return out
+
+
 def load_oracle():
     """The CPU oracle (oracle/fm_oracle.c): checker and CPU baseline only -- never on the measured path."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -71,7 +99,7 @@ def load_oracle():
     return oracle_lib.load()
 
 
-def cpu_baseline(fmd, torch, cfg, iq_dev, target_s=12.0):
+def cpu_baseline(fmd, torch, cfg, iq_dev, target_s=4.0):
     """The oracle (oracle/fm_oracle.c, a C restatement of the reference passes: kind 'port') timed on this
     box's host cores over a bounded sample of the same workload; BASELINE.md's CPU-1 line (the reference's own
     configuration, one channel, one thread, >= 8 blocks) beside it."""
@@ -92,7 +120,7 @@ def cpu_baseline(fmd, torch, cfg, iq_dev, target_s=12.0):
     if run() <= 0:                                            # warm-up pass (page faults, thread start)
         return None
     total, passes = 0.0, 0
-    while total < target_s and passes < 4000:                 # ~12 s of CPU work, bounded
+    while total < target_s and passes < 4000:                 # ~4 s of CPU work by default (the all-threads figure converges in < 2 s), bounded
         t = run()
         if t <= 0:
             return None
@@ -175,7 +203,7 @@ def time_calls(torch, call, settle=150, steps=100, regions=5):
     return regs[len(regs) // 2], regs[0], regs[-1], last
 
 
-def extra_config4(fmd, torch, dev, stream, fused):
+def extra_config4(fmd, torch, dev, stream, fused, bounds=None):
     """BASELINE configs[3] beside the headline (outside its timed region): 127-tap FIR, decimate 8, 256 channels x
     2 MiB per call.  fused=False: the stand-alone operator fmd_fir_* (complex i32 out, 3 B per IQ sample);
     fused=True: FIR -> discriminator -> resampler in one kernel (fmd_firdemod_*, s16 audio out)."""
@@ -211,11 +239,12 @@ def extra_config4(fmd, torch, dev, stream, fused):
            "ms_min_max": [round(lo, 4), round(hi, 4)],
            "iq_msamples_per_s": round(nch * (n // 2) / ms / 1e3, 1), "outputs_per_channel": int(nout),
            "algorithmic_bytes_per_launch": alg, "GBps": round(alg / ms / 1e6, 1), "frac": round(alg / ms / 1e6 / HBM_PEAK_GBS, 4)}
+    res.update(bound_fields(bounds, None, res["frac"], section="config4_fir_demod_fused" if fused else "config4_fir"))
     del bank, out, bufs
     return res
 
 
-def extra_cfg_ref(fmd, torch, dev, stream, bufs):
+def extra_cfg_ref(fmd, torch, dev, stream, bufs, bounds=None):
     """The reference's OWN configuration -- what optimal_settings(94.9 MHz, 170 kHz) produces for the shipped example
     (simple_fm.rs:25-27,48: downsample 6, 170 kHz -> 32 kHz) -- on the headline's batch shape and input buffers."""
     d, fast, slow = CFG_REF
@@ -232,6 +261,7 @@ def extra_cfg_ref(fmd, torch, dev, stream, bufs):
            "kernel": bank.last_kernel(), "ms_per_call": round(ms, 4), "ms_min_max": [round(lo, 4), round(hi, 4)],
            "iq_msamples_per_s": round(nch * (BLOCK // 2) / ms / 1e3, 1), "algorithmic_bytes_per_launch": alg,
            "GBps": round(alg / ms / 1e6, 1), "frac": round(alg / ms / 1e6 / HBM_PEAK_GBS, 4), "tiling": bank.tiling()}
+    res.update(bound_fields(bounds, "%d,%d,%d" % (d, fast, slow), res["frac"]))
     bank.close()
     return res
 
@@ -241,7 +271,7 @@ DOMAIN = [(1, 48000, 48000), (2, 500000, 32000), (4, 256000, 48000), (5, 250000,
           (12, 192000, 32000), (16, 150000, 32000), (64, 37500, 8000)]
 
 
-def extra_domain(fmd, torch, dev, stream, bufs):
+def extra_domain(fmd, torch, dev, stream, bufs, bounds=None):
     """Every other kernel family of the demod path on the headline's batch shape and input buffers (outside its timed
     region, <= 0.2 s each): odd factors, the register-streaming kernel (2, 4), the wrap-around walk (16, 64), one
     discriminator per IQ sample (1).  Each line names the kernel the library reports it launched."""
@@ -257,14 +287,59 @@ def extra_domain(fmd, torch, dev, stream, bufs):
             ms, lo, hi, _ = time_calls(torch, call, settle=60, steps=40, regions=3)
             bank.check()
             alg = nch * BLOCK + 2 * int(bank.last_out_len().sum())
-            rows.append({"downsample": d, "rate_out": fast, "rate_resample": slow, "kernel": bank.last_kernel(),
-                         "ms_per_call": round(ms, 4), "ms_min_max": [round(lo, 4), round(hi, 4)], "GBps": round(alg / ms / 1e6, 1),
-                         "frac": round(alg / ms / 1e6 / HBM_PEAK_GBS, 4), "audio_per_tile": bank.tiling()["audio_per_tile"]})
+            row = {"downsample": d, "rate_out": fast, "rate_resample": slow, "kernel": bank.last_kernel(),
+                   "ms_per_call": round(ms, 4), "ms_min_max": [round(lo, 4), round(hi, 4)], "GBps": round(alg / ms / 1e6, 1),
+                   "frac": round(alg / ms / 1e6 / HBM_PEAK_GBS, 4), "audio_per_tile": bank.tiling()["audio_per_tile"]}
+            row.update(bound_fields(bounds, "%d,%d,%d" % (d, fast, slow), row["frac"]))
+            rows.append(row)
             bank.close()
             del out
         except Exception as e:
             rows.append({"downsample": d, "rate_out": fast, "rate_resample": slow, "error": repr(e)})
     return {"workload": "%d channels x %d B/call per configuration, 3 regions of 40 calls after 60 untimed ones" % (nch, BLOCK), "rows": rows}
+
+
+def extra_skeleton(fmd, torch, dev, stream, bufs):
+    """The kernels' own ceiling on THIS box: the staging skeleton of the tile kernel -- prologue, LDS-DMAs, barrier, one store; no
+    rounds, no resampler (ablation bit 3 of the -DFMD_EXPERIMENT build, loaded side by side here; the shipped library has no such
+    switch) -- on the headline's batch and on the reference's own rates.  `frac_of_skeleton` of a row = how much of the time its
+    memory side alone would need the whole kernel takes; the skeleton itself runs at the full shader clock, the kernels at the
+    power-capped one (extra.power_clock)."""
+    from rtl_sdr_rs_amd import _ffi
+    exp = os.path.join(ROOT, "rtl-sdr-rs_amd", "libfmd_hip_exp.so")
+    if not os.path.exists(exp):
+        return {"error": "libfmd_hip_exp.so not built"}
+    lib = C.CDLL(exp)
+    for name, (res_t, args) in _ffi.PROTOTYPES.items():
+        if hasattr(lib, name):
+            getattr(lib, name).restype, getattr(lib, name).argtypes = res_t, args
+    nch = bufs[0].shape[0]
+    out = {"what": "fmd_demod_tile_kernel with FMD_DBG=8 (experiment build): staging only; %d channels x %d B per launch" % (nch, BLOCK)}
+    saved = os.environ.get("FMD_DBG")
+    try:
+        for key, (d, fast, slow) in (("headline", (D, FAST, SLOW)), ("cfg_ref", CFG_REF)):
+            cfg = fmd.DemodConfig(fast, fast, slow, d, max(1, (1 << 15) // (128 * d)))
+            cap = int(lib.fmd_out_cap(C.byref(cfg), BLOCK))
+            o = torch.zeros((nch, cap), dtype=torch.int16, device=dev)
+            os.environ["FMD_DBG"] = "8"                          # read when the handle is created (experiment build only)
+            h = C.c_void_p()
+            dc = fmd.DeviceConfig(nch, dev.index, 0)
+            if lib.fmd_demod_new(C.byref(cfg), C.byref(dc), C.byref(h)) != 0:
+                out[key] = {"error": "fmd_demod_new failed"}
+                continue
+            call = lambda i: lib.fmd_demod_demodulate_device(h, bufs[i % len(bufs)].data_ptr(), BLOCK, o.data_ptr(), cap, None, stream)
+            ms, lo, hi, _ = time_calls(torch, call, settle=60, steps=60, regions=3)
+            lib.fmd_demod_check(h)
+            lib.fmd_demod_free(h)
+            out[key] = {"ms_per_call": round(ms, 4), "ms_min_max": [round(lo, 4), round(hi, 4)], "input_GBps": round(nch * BLOCK / ms / 1e6, 1),
+                        "frac_of_spec_reads_only": round(nch * BLOCK / ms / 1e6 / HBM_PEAK_GBS, 4)}
+            del o
+    finally:
+        if saved is None:
+            os.environ.pop("FMD_DBG", None)
+        else:
+            os.environ["FMD_DBG"] = saved
+    return out
 
 
 def extra_config2(fmd, torch, dev, stream):
@@ -529,7 +604,7 @@ def main():
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline and the parity bit (both use the oracle)")
     ap.add_argument("--no-extra", action="store_true", help="skip the side lines (extra.*), the per-GPU clock / power sample included")
     ap.add_argument("--power-only", action="store_true", help="of the side lines keep only extra.power_clock (every rank samples its own GPU)")
-    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="oracle time spent on the CPU baseline (rank 0)")
+    ap.add_argument("--cpu-seconds", type=float, default=4.0, help="oracle time spent on the all-threads CPU baseline (rank 0); + 1 s + 2 s for the two single-thread figures")
     ap.add_argument("--min-timed-s", type=float, default=MIN_TIMED_S, help="repeat the K-step region until this much has been timed")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="torch.distributed backend for the barrier / max-over-ranks timing (nccl = RCCL); with gloo "
@@ -756,6 +831,10 @@ def main():
                          "kernel_ms_events_per_launch_median": round(kern_ms_pair, 4),
                          "kernel_ms_events_per_launch_min_max": [round(per_launch[0], 4), round(per_launch[-1], 4)]},
         }
+        hb = bound_fields(load_bounds(), "%d,%d,%d" % (D, FAST, SLOW), res["roofline"]["frac"])
+        for k in ("valu_issue_frac", "salu_issue_frac", "lds_bank_conflict_share", "bound_source"):
+            if k in hb:
+                res["roofline"][k] = hb[k]
         if launched != KERNEL_EXPECTED:
             sys.stderr.write("bench.py: the library launched %r, expected %r\n" % (launched, KERNEL_EXPECTED))
         if par is not None:
@@ -781,20 +860,34 @@ def main():
                     "what": "hipMemcpyDtoD (torch copy_) of one %d-byte input batch on this box, read + write bytes / HIP-event time; "
                             "the kernel's `achieved` is %.2f x this" % (bufs[0].numel(), achieved / copy_gbs)}
                 del dst
+                sk = extra_skeleton(fmd, torch, dev, stream, bufs)
+                res["roofline"]["box_reference"]["skeleton"] = sk
+                if isinstance(sk.get("headline"), dict) and sk["headline"].get("ms_per_call"):
+                    res["roofline"]["box_reference"]["skeleton_ms_headline"] = sk["headline"]["ms_per_call"]
+                    res["roofline"]["frac_of_skeleton"] = round(sk["headline"]["ms_per_call"] / kern_ms_region, 4)
+                if isinstance(sk.get("cfg_ref"), dict) and sk["cfg_ref"].get("ms_per_call"):
+                    res["roofline"]["box_reference"]["skeleton_ms_cfg_ref"] = sk["cfg_ref"]["ms_per_call"]
             except Exception as e:
                 res["roofline"]["box_reference"] = {"error": repr(e)}
-            side = [("cfg_ref", lambda: extra_cfg_ref(fmd, torch, dev, stream, bufs)),
+            bounds = load_bounds()
+            side = [("cfg_ref", lambda: extra_cfg_ref(fmd, torch, dev, stream, bufs, bounds)),
                     ("check_per_step", lambda: extra_check_per_step(fmd, torch, bank, bufs, out, cap, stream)),
                     ("config2_1channel", lambda: extra_config2(fmd, torch, dev, stream)),
-                    ("config4_fir", lambda: extra_config4(fmd, torch, dev, stream, False)),
-                    ("config4_fir_demod_fused", lambda: extra_config4(fmd, torch, dev, stream, True)),
+                    ("config4_fir", lambda: extra_config4(fmd, torch, dev, stream, False, bounds)),
+                    ("config4_fir_demod_fused", lambda: extra_config4(fmd, torch, dev, stream, True, bounds)),
                     ("sink_pcie", lambda: extra_sink_pcie(fmd, dev_index)),
-                    ("domain", lambda: extra_domain(fmd, torch, dev, stream, bufs))]
+                    ("domain", lambda: extra_domain(fmd, torch, dev, stream, bufs, bounds))]
             for name, fn in side:
                 try:
                     res["extra"][name] = fn()
                 except Exception as e:          # side lines never break the headline
                     res["extra"][name] = {"error": repr(e)}
+            try:                                 # the reference's own rates against THEIR staging skeleton on this box
+                sk_ref = res["roofline"]["box_reference"].get("skeleton_ms_cfg_ref")
+                if sk_ref and res["extra"]["cfg_ref"].get("ms_per_call"):
+                    res["extra"]["cfg_ref"]["frac_of_skeleton"] = round(sk_ref / res["extra"]["cfg_ref"]["ms_per_call"], 4)
+            except (KeyError, TypeError, AttributeError):
+                pass
         if not args.no_cpu:                      # rank 0 only, after the last timed region; the other ranks wait at the final barrier
             try:
                 res["cpu_baseline"] = cpu_baseline(fmd, torch, cfg, bufs[0], target_s=args.cpu_seconds)

@@ -289,10 +289,10 @@ __device__ __forceinline__ int disc_f32_c(float ar, float ai, float br, float bi
 // same order per sample (no contraction: -ffp-contract=off): bit-identical results.  32 + a few moves instead of 46 vector
 // instructions per pair.  LO16 results (see disc_f32_xy).
 typedef float fmd_f2 __attribute__((ext_vector_type(2)));
-template <bool NOWRAP = false>
-__device__ __forceinline__ void disc_f32_c_x2(float ar1, float ai1, float br1, float bi1, float ar2, float ai2, int& o1, int& o2)
+template <bool NOWRAP = false, bool LO16 = true>
+__device__ __forceinline__ void disc_f32_c_x2(float ar1, float ai1, float br1, float bi1, float ar2, float ai2, float br2, float bi2, int& o1, int& o2)
 {
-    const fmd_f2 AR = {ar1, ar2}, AI = {ai1, ai2}, BR = {br1, ar1}, BI = {bi1, ai1};       // sample 2's predecessor is sample 1
+    const fmd_f2 AR = {ar1, ar2}, AI = {ai1, ai2}, BR = {br1, br2}, BI = {bi1, bi2};
     const fmd_f2 zero = {0.0f, 0.0f};
     const fmd_f2 X = __builtin_elementwise_fma(AI, BI, __builtin_elementwise_fma(AR, BR, zero));
     const fmd_f2 Y = __builtin_elementwise_fma(AI, BR, __builtin_elementwise_fma(-AR, BI, zero));
@@ -315,8 +315,12 @@ __device__ __forceinline__ void disc_f32_c_x2(float ar1, float ai1, float br1, f
     const fmd_f2 k8192 = {8192.0f, 8192.0f}, magic = {12582912.0f, 12582912.0f};
     const fmd_f2 RES0 = (k8192 - B4) - QS;
     const fmd_f2 RES = {u2f(f2u(RES0.x) ^ (f2u(Y.x) & 0x80000000u)), u2f(f2u(RES0.y) ^ (f2u(Y.y) & 0x80000000u))};
-    const fmd_f2 OUT = RES + magic;
-    o1 = (int)f2u(OUT.x); o2 = (int)f2u(OUT.y);
+    if constexpr (LO16) {
+        const fmd_f2 OUT = RES + magic;
+        o1 = (int)f2u(OUT.x); o2 = (int)f2u(OUT.y);
+    } else {
+        o1 = fmd_cvt_i32_nan0(RES.x); o2 = fmd_cvt_i32_nan0(RES.y);
+    }
 }
 #endif
 

@@ -510,7 +510,7 @@ __global__ void __launch_bounds__(kThreads, fd_reg_blocks(NKU, NG, ROWS)) fmd_fi
     if (jfirst < 0 || k0 == 0 || last) st = L.st_in[c];
     // under the load latency: audio group k of the tile (k == nk: the trailing partial group) -- zero its accumulator and
     // tabulate its first and last discriminator sample (see fmd_firdemod_kernel)
-    for (uint32_t k = tid; k <= H.kt; k += kThreads) {
+    for (uint32_t k = tid; k <= H.kt && !FD_ABLATE(22); k += kThreads) {   // (ablation 22: no group table)
         gsum[k] = 0;
         const uint32_t x = er + k * L.fb;
         uint32_t u, xrem;
@@ -534,6 +534,10 @@ __global__ void __launch_bounds__(kThreads, fd_reg_blocks(NKU, NG, ROWS)) fmd_fi
     __builtin_amdgcn_s_setprio(0);
     __builtin_amdgcn_s_waitcnt(0x0F70);                      // vmcnt(0): the LDS-DMAs (and the A fragments) have landed
     __syncthreads();
+    if (FD_ABLATE(23)) {                                     // ablation: staging skeleton only (prologue, DMAs, barrier, one store)
+        if (tid == 0) L.out[(uint64_t)c * L.out_stride + t * H.kt] = (int16_t)(lds[t & 63u] + (uint32_t)A[0].x);
+        return;
+    }
 
     // ---- FIR on the matrix cores: NKU + NG - 1 operand fragments feed NG accumulators (fragment reuse, see above) ----------
     const uint32_t tcol = wave * (uint32_t)WSTEP + j * (uint32_t)PC;     // tile output index of the column's first output
@@ -544,11 +548,15 @@ __global__ void __launch_bounds__(kThreads, fd_reg_blocks(NKU, NG, ROWS)) fmd_fi
         const uint8_t* col = reinterpret_cast<const uint8_t*>(lds) + 16u * tcol + 16u * q;   // decimate 8: 16 bytes per output
 #pragma unroll
         for (int sft = 0; sft < NKU + NG - 1; ++sft) {
+            if (FD_ABLATE(16)) continue;                                                    // ablation: no operand reads, no matrix instructions
             fd_i4 B = *reinterpret_cast<const fd_i4*>(col + 64 * sft);
             B = B ^ (int)0x80808080;                                                       // u8 -> s8
 #pragma unroll
             for (int jj = 0; jj < NG; ++jj)
-                if (sft - jj >= 0 && sft - jj < NKU) acc[jj] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A[sft - jj], B, acc[jj], 0, 0, 0);
+                if (sft - jj >= 0 && sft - jj < NKU) {
+                    if (!FD_ABLATE(17)) acc[jj] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A[sft - jj], B, acc[jj], 0, 0, 0);
+                    else acc[jj].x ^= B.x + A[sft - jj].y;                                 // ablation: operand reads kept, every matrix instruction replaced by two vector ones
+                }
         }
     }
     // lane (j, q) holds (re_lo, re_hi, im_lo, im_hi) of tile output tcol + 4 gi + q in acc[gi]: combine the tap digits, add
@@ -560,6 +568,7 @@ __global__ void __launch_bounds__(kThreads, fd_reg_blocks(NKU, NG, ROWS)) fmd_fi
     float fr[NG], fi[NG];
 #pragma unroll
     for (int gi = 0; gi < NG; ++gi) {
+        if (FD_ABLATE(18)) { fr[gi] = u2f((uint32_t)acc[gi].x & 0x3F800FFFu); fi[gi] = u2f((uint32_t)acc[gi].z & 0x3F800FFFu); continue; }   // ablation: no digit combine / shift / conversion
         const int re = (int)((uint32_t)acc[gi].x + ((uint32_t)acc[gi].y << 7) + (uint32_t)cre) >> L.shift;     // floor(y / 2^shift)
         const int im = (int)((uint32_t)acc[gi].z + ((uint32_t)acc[gi].w << 7) + (uint32_t)cim) >> L.shift;
         fr[gi] = (float)re; fi[gi] = (float)im;
@@ -579,11 +588,12 @@ __global__ void __launch_bounds__(kThreads, fd_reg_blocks(NKU, NG, ROWS)) fmd_fi
     float pr[NG], pi[NG];
 #pragma unroll
     for (int gi = 0; gi < NG; ++gi) {
+        if (FD_ABLATE(19)) { pr[gi] = fi[gi]; pi[gi] = fr[gi]; continue; }                  // ablation: no predecessor moves
         pr[gi] = u2f((uint32_t)__builtin_amdgcn_ds_bpermute(down, (int)f2u(fr[gi])));
         pi[gi] = u2f((uint32_t)__builtin_amdgcn_ds_bpermute(down, (int)f2u(fi[gi])));
     }
-    const float xr = u2f((uint32_t)__builtin_amdgcn_ds_bpermute(left, (int)f2u(fr[NG - 1])));
-    const float xi = u2f((uint32_t)__builtin_amdgcn_ds_bpermute(left, (int)f2u(fi[NG - 1])));
+    const float xr = FD_ABLATE(19) ? fi[0] : u2f((uint32_t)__builtin_amdgcn_ds_bpermute(left, (int)f2u(fr[NG - 1])));
+    const float xi = FD_ABLATE(19) ? fr[0] : u2f((uint32_t)__builtin_amdgcn_ds_bpermute(left, (int)f2u(fi[NG - 1])));
     const bool q0 = q == 0u;
     // (every lane takes part in every move: ds_bpermute returns 0 for a source lane that is masked off, so the row-0 lanes
     //  cannot fetch their previous-register values under an EXEC mask of their own -- they select instead)
@@ -606,11 +616,28 @@ __global__ void __launch_bounds__(kThreads, fd_reg_blocks(NKU, NG, ROWS)) fmd_fi
     int sum_all = 0, sum_lo = 0;
     int d_first = 0, cr0 = 0, ci0 = 0;
     bool any_guard = false;
+#ifdef FMD_PK_DISC
+    int dpk[NG];                                             // EXPERIMENT: the lane's discriminators in pairs, packed f32 (fmd_device.h)
+#pragma unroll
+    for (int gi = 0; gi + 1 < NG; gi += 2) {
+        const float b1r = q0 ? (gi == 0 ? xr : pr[gi - 1]) : pr[gi], b1i = q0 ? (gi == 0 ? xi : pi[gi - 1]) : pi[gi];
+        const float b2r = q0 ? pr[gi] : pr[gi + 1], b2i = q0 ? pi[gi] : pi[gi + 1];
+        disc_f32_c_x2<false, false>(fr[gi], fi[gi], b1r, b1i, fr[gi + 1], fi[gi + 1], b2r, b2i, dpk[gi], dpk[gi + 1]);
+    }
+    if constexpr (NG % 2 == 1) {
+        const float br = q0 ? pr[NG - 2] : pr[NG - 1], bi = q0 ? pi[NG - 2] : pi[NG - 1];
+        dpk[NG - 1] = disc_f32_c(fr[NG - 1], fi[NG - 1], br, bi);
+    }
+#endif
 #pragma unroll
     for (int gi = 0; gi < NG; ++gi) {
         const float br = q0 ? (gi == 0 ? xr : pr[gi - 1]) : pr[gi];
         const float bi = q0 ? (gi == 0 ? xi : pi[gi - 1]) : pi[gi];
-        int d = disc_f32_c(fr[gi], fi[gi], br, bi);          // (:362); the value fits i16, `as i16` changes nothing
+#ifdef FMD_PK_DISC
+        int d = dpk[gi]; (void)br; (void)bi;
+#else
+        int d = FD_ABLATE(20) ? (int)(f2u(fr[gi]) ^ f2u(bi)) + (int)f2u(br) : disc_f32_c(fr[gi], fi[gi], br, bi);   // (:362); the value fits i16, `as i16` changes nothing (ablation 20: no discriminator)
+#endif
         if (gi == 0 && jfirst < 0 && tid == 0) {             // the first sample of the call takes the f64 path (:359) against demod_pre
             fmd_mul_conj((int)fr[0], (int)fi[0], st.demod_pre_re, st.demod_pre_im, cr0, ci0);
             bool g;
@@ -627,8 +654,11 @@ __global__ void __launch_bounds__(kThreads, fd_reg_blocks(NKU, NG, ROWS)) fmd_fi
         sum_lo += gi < g_split ? dv : 0;
     }
     // (a lane whose outputs are all beyond the tile or not owned adds zeros: harmless)
-    if (kq <= H.kt) atomicAdd(&gsum[kqc], sum_lo);
-    if (kq + 1u <= H.kt && sum_all != sum_lo) atomicAdd(&gsum[kq + 1u], sum_all - sum_lo);
+    if (FD_ABLATE(21)) { if (sum_all == 0x7fffffff) gsum[0] = sum_lo; }                   // ablation: no group sums in LDS
+    else {
+        if (kq <= H.kt) atomicAdd(&gsum[kqc], sum_lo);
+        if (kq + 1u <= H.kt && sum_all != sum_lo) atomicAdd(&gsum[kq + 1u], sum_all - sum_lo);
+    }
     __syncthreads();
 
     // ---- low_pass_real (:418-422): one divide per audio sample ---------------------------------------------------

@@ -658,7 +658,7 @@ __device__ __forceinline__ void tile_body(const FmdLaunch& L, const TileCtx& X, 
             // (see stream_pair_rounds)
 #ifdef FMD_PK_DISC
             int o1, o2;
-            disc_f32_c_x2<DH == 1>(ar1, ai1, br1, bi1, ar2, ai2, o1, o2);
+            disc_f32_c_x2<DH == 1>(ar1, ai1, br1, bi1, ar2, ai2, ar1, ai1, o1, o2);     // the second window's predecessor is the first
             if (lane > 0 && (FULL || i1 < cnt)) d16[i1] = (int16_t)o1;
             if (FULL || i2 < cnt) d16[i2] = (int16_t)o2;
 #else

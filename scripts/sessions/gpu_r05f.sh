@@ -8,3 +8,5 @@ for ka in 0 1; do
   HIP_FORCE_DEV_KERNARG=$ka python tools/ab_libs.py --rounds 4 --cfg 24 --cfg ref --cfg 64,37500,8000 r04=rtl-sdr-rs_amd/libfmd_hip_r04.so s2= 2>/dev/null | sed "s/^/KA=$ka /" | tee -a $OUT/ab_kernarg.txt | cut -c1-230
 done
 python tools/ab_libs.py --rounds 4 --cfg 24 --cfg ref --cfg 64,37500,8000 r04=rtl-sdr-rs_amd/libfmd_hip_r04.so s2= 2>/dev/null | sed "s/^/KA=default /" | tee -a $OUT/ab_kernarg.txt | cut -c1-230
+# (3) per-region counters of the fused FIR kernel
+bash scripts/gpu_pmc_fd_regions.sh $OUT/fd_regions.jsonl > $OUT/fd_regions.log 2>&1; cut -c1-420 $OUT/fd_regions.jsonl

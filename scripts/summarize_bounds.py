@@ -1,0 +1,63 @@
+#!/usr/bin/env python3
+"""profiles/<round>_bounds.json: for every measured row (demodulation configurations, the stand-alone FIR, the fused FIR kernel) how
+busy the vector / scalar / matrix pipes and the LDS were, from the committed PMC passes -- the figures bench.py attaches to its
+`extra` rows (`bound`, `valu_issue_frac`, ...).  Usage: summarize_bounds.py <tag> <round>     (reads gpurun_out/<tag>_pmc_configs.jsonl,
+gpurun_out/<tag>_pmc_fir/summary.json, gpurun_out/<tag>_pmc_fd/summary.json; method in profiles/README.md)
+
+Units (MI355X, gfx950): SQ_ACTIVE_INST_* and SQ_WAVE_CYCLES count in quad-cycles (4 shader clocks) summed over waves; SQ_BUSY_CYCLES counts
+shader clocks while the launch runs, summed over the chip's 32 shader engines.  With 1024 SIMDs (256 CUs x 4):
+    launch_cycles   = SQ_BUSY_CYCLES / 32
+    valu_issue_frac = SQ_ACTIVE_INST_VALU x 4 / 1024 / launch_cycles        (share of a SIMD's time its vector pipe was executing)
+    salu_issue_frac = SQ_ACTIVE_INST_SCA  x 4 / 1024 / launch_cycles
+    mfma_busy_frac  = SQ_VALU_MFMA_BUSY_CYCLES / 1024 / launch_cycles        (shader clocks the matrix pipes were busy, summed over SIMDs)
+A row is called VALU-bound when valu_issue_frac >= 0.70 AND it is the largest of the fractions beside the HBM fraction of the same launch."""
+import json, os, sys
+tag, rnd = sys.argv[1], sys.argv[2]
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+g = os.path.join(root, "gpurun_out")
+N_SE, N_SIMD = 32.0, 1024.0
+rows, sha = {}, None
+for l in open(os.path.join(g, tag + "_pmc_configs.jsonl")):
+    d = json.loads(l)
+    if "per_wave" not in d or not d.get("cfg"):
+        continue
+    key = ",".join(str(x) for x in d["cfg"])
+    r = rows.setdefault(key, {"config": d["config"], "kernel": d.get("kernel_reported"), "waves_per_launch": d["waves_per_launch"], "per_wave": {}})
+    r["per_wave"].update(d["per_wave"])
+    sha = d.get("kernel_source_sha16", sha)
+out = {"kernel_source_sha16": sha, "method": __doc__.split("Units", 1)[1].strip(), "demod": {}}
+for key, r in rows.items():
+    p, w = r["per_wave"], r["waves_per_launch"]
+    if "SQ_BUSY_CYCLES" not in p or "SQ_ACTIVE_INST_VALU" not in p:
+        continue
+    cyc = p["SQ_BUSY_CYCLES"] * w / N_SE
+    o = {"config": r["config"], "kernel": r["kernel"], "launch_cycles_under_pmc": round(cyc),
+         "valu_issue_frac": round(p["SQ_ACTIVE_INST_VALU"] * w * 4 / N_SIMD / cyc, 3),
+         "salu_issue_frac": round(p.get("SQ_ACTIVE_INST_SCA", 0) * w * 4 / N_SIMD / cyc, 3),
+         "lds_issue_frac": round(p.get("SQ_ACTIVE_INST_LDS", 0) * w * 4 / N_SIMD / cyc, 3),
+         "valu_per_wave": p.get("SQ_INSTS_VALU"), "salu_per_wave": p.get("SQ_INSTS_SALU"),
+         "lds_bank_conflict_share": round(p["SQ_LDS_BANK_CONFLICT"] / p["SQ_LDS_IDX_ACTIVE"], 3) if p.get("SQ_LDS_IDX_ACTIVE") else None}
+    out["demod"][key] = o
+for name, sub in (("config4_fir", tag + "_pmc_fir"), ("config4_fir_demod_fused", tag + "_pmc_fd")):
+    f = os.path.join(g, sub, "summary.json")
+    if not os.path.exists(f):
+        continue
+    c = {k: v["mean_per_launch"] for k, v in json.load(open(f)).items() if isinstance(v, dict) and "mean_per_launch" in v}
+    if "SQ_BUSY_CYCLES" not in c:
+        continue
+    cyc = c["SQ_BUSY_CYCLES"] / N_SE
+    o = {"launch_cycles_under_pmc": round(cyc), "waves_per_launch": round(c.get("SQ_WAVES", 0))}
+    if "SQ_ACTIVE_INST_VALU" in c:
+        o["valu_issue_frac"] = round(c["SQ_ACTIVE_INST_VALU"] * 4 / N_SIMD / cyc, 3)
+    if "SQ_ACTIVE_INST_SCA" in c:
+        o["salu_issue_frac"] = round(c["SQ_ACTIVE_INST_SCA"] * 4 / N_SIMD / cyc, 3)
+    if "SQ_VALU_MFMA_BUSY_CYCLES" in c:
+        o["mfma_busy_frac"] = round(c["SQ_VALU_MFMA_BUSY_CYCLES"] / N_SIMD / cyc, 3)
+    if c.get("SQ_LDS_IDX_ACTIVE"):
+        o["lds_bank_conflict_share"] = round(c.get("SQ_LDS_BANK_CONFLICT", 0) / c["SQ_LDS_IDX_ACTIVE"], 3)
+    w = c.get("SQ_WAVES")
+    if w:
+        o["per_wave"] = {k: round(c[k] / w, 1) for k in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_INSTS_MFMA") if k in c}
+    out[name] = o
+json.dump(out, open(os.path.join(root, "profiles", rnd + "_bounds.json"), "w"), indent=1)
+print(json.dumps(out, indent=1)[:3000])

@@ -26,6 +26,54 @@ def load(path):
     return l
 
 
+def firdemod(a):
+    import numpy as np
+    builds = []
+    for b in a.builds:
+        name, _, path = b.partition("=")
+        builds.append((name, load(os.path.join(ROOT, path) if path else _ffi.SO_PATH)))
+    nch, n, T, M, fast, slow = 256, 2 << 20, 127, 8, 2500000, 48000
+    taps = np.random.default_rng(1).integers(-2047, 2048, T).astype(np.int16)
+    shift = fmd.auto_shift(taps)
+    stream = torch.cuda.current_stream().cuda_stream
+    bufs = []
+    for b in range(3):
+        t = torch.empty((nch, n), dtype=torch.uint8, device="cuda")
+        fmd.synth.fill_device(t.data_ptr(), nch, n, sample_offset=b * (n // 2), stream=stream)
+        bufs.append(t)
+    cap = int(builds[0][1].fmd_firdemod_out_cap(M, fast, slow, n))
+    out = torch.zeros((nch, cap), dtype=torch.int16, device="cuda")
+    hs = []
+    for name, l in builds:
+        h = C.c_void_p()
+        dev = fmd.DeviceConfig(nch, -1, 0)
+        rc = l.fmd_firdemod_new(taps.ctypes.data_as(C.POINTER(C.c_int16)), T, M, shift, fast, slow, C.byref(dev), C.byref(h))
+        assert rc == 0, (name, rc)
+        hs.append(h)
+    res = {name: [] for name, _ in builds}
+    k = C.c_size_t(0)
+    for rnd in range(a.rounds):
+        for (name, l), h in zip(builds, hs):
+            for i in range(a.settle):
+                l.fmd_firdemod_demodulate_device(h, bufs[i % 3].data_ptr(), n, out.data_ptr(), cap, C.byref(k), stream)
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for i in range(a.steps):
+                l.fmd_firdemod_demodulate_device(h, bufs[i % 3].data_ptr(), n, out.data_ptr(), cap, C.byref(k), stream)
+            e1.record(); torch.cuda.synchronize()
+            assert l.fmd_firdemod_check(h) == 0
+            res[name].append(e0.elapsed_time(e1) / a.steps)
+    alg = nch * n + 2 * nch * k.value
+    base = None
+    for (name, l), h in zip(builds, hs):
+        ts = sorted(res[name]); med = ts[len(ts) // 2]
+        base = base or med
+        print(json.dumps({"cfg": "config4 fused FIR", "build": name, "ms": [round(t, 4) for t in res[name]], "median_ms": round(med, 4),
+                          "frac": round(alg / med / 1e6 / 8000, 4), "vs_first_pct": round(100 * (med / base - 1), 2)}), flush=True)
+        l.fmd_firdemod_free(h)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--cfg", action="append", default=[])
@@ -33,8 +81,11 @@ def main():
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--settle", type=int, default=100)
     ap.add_argument("--channels", type=int, default=4096)
+    ap.add_argument("--firdemod", action="store_true", help="BASELINE configs[3] through the fused FIR kernel (127 taps, decimate 8, 256 channels x 2 MiB) instead of the demodulation kernels")
     ap.add_argument("builds", nargs="+")
     a = ap.parse_args()
+    if a.firdemod:
+        return firdemod(a)
     cfgs = [NAMED[c] if c in NAMED else tuple(int(x) for x in c.split(",")) for c in (a.cfg or ["24", "ref"])]
     builds = []
     for b in a.builds:

@@ -37,7 +37,7 @@ for name, D, fast, slow in CONFIGS:
     e1.record(); torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / steps
     alg = nch * N + 2 * int(bank.last_out_len().sum())
-    print(json.dumps({"config": name, "ms_per_call": round(ms, 4), "iq_msamples_per_s": round(nch * N / 2 / ms / 1e3, 0),
+    print(json.dumps({"config": name, "cfg": [D, fast, slow], "kernel": bank.last_kernel(), "ms_per_call": round(ms, 4), "iq_msamples_per_s": round(nch * N / 2 / ms / 1e3, 0),
                       "algorithmic_GBps": round(alg / ms / 1e6, 1), "hbm_frac_of_8TBps": round(alg / ms / 1e6 / 8000, 4),
                       "tiling": bank.tiling()}), flush=True)
     bank.close(); del out
