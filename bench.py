@@ -78,16 +78,16 @@ def load_bounds():
 
 
 def bound_fields(b, key, hbm_frac, section="demod"):
-    """`bound` + the pipe fractions of one row.  A row is VALU-bound when its vector pipes were executing >= 70 % of the launch (under the
-    counters) and that share exceeds the launch's HBM fraction; HBM-bound otherwise."""
+    """`bound` + the pipe fractions of one row: the largest of the launch's HBM fraction and the vector / scalar / matrix pipes' issue
+    fractions under the counters (method and units: scripts/summarize_bounds.py, profiles/README.md)."""
     if not b:
         return {}
     row = (b.get(section) or {}).get(key) if section == "demod" else b.get(section)
     if not row:
         return {}
     out = {k: row[k] for k in ("valu_issue_frac", "salu_issue_frac", "mfma_busy_frac", "lds_bank_conflict_share") if row.get(k) is not None}
-    v = row.get("valu_issue_frac") or 0.0
-    out["bound"] = "valu" if v >= 0.70 and v > hbm_frac else "hbm"
+    cand = {"hbm": hbm_frac, "valu": row.get("valu_issue_frac") or 0.0, "salu": row.get("salu_issue_frac") or 0.0, "mfma": row.get("mfma_busy_frac") or 0.0}
+    out["bound"] = max(cand, key=cand.get)
     out["bound_source"] = "%s%s" % (BOUNDS, "" if b.get("current") else " (taken on EARLIER kernel sources: indicative only)")
     return out
 

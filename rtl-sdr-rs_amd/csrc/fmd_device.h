@@ -280,50 +280,6 @@ __device__ __forceinline__ int disc_f32_c(float ar, float ai, float br, float bi
     return disc_f32_xy<NOWRAP, LO16>(xf, yf, k4096);
 }
 
-#ifdef FMD_PK_DISC
-// EXPERIMENT (round 5; scripts/build_variant.sh pk -DFMD_PK_DISC): the two discriminators a lane computes in
-// the adjacent-window rounds as ONE instruction stream with packed-f32 arithmetic (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32 on
-// register pairs) wherever no abs modifier is needed -- packed operands take neg and clamp, not abs -- i.e. the complex
-// products, the i32-wrap emulation, the quotient's multiply / clamped fma / subtract and the three final adds; |x| + |y|,
-// |x| - |y|, 4096 |sp|, the reciprocals, the roundings and the sign transfers stay per sample.  Same IEEE operations in the
-// same order per sample (no contraction: -ffp-contract=off): bit-identical results.  32 + a few moves instead of 46 vector
-// instructions per pair.  LO16 results (see disc_f32_xy).
-typedef float fmd_f2 __attribute__((ext_vector_type(2)));
-template <bool NOWRAP = false, bool LO16 = true>
-__device__ __forceinline__ void disc_f32_c_x2(float ar1, float ai1, float br1, float bi1, float ar2, float ai2, float br2, float bi2, int& o1, int& o2)
-{
-    const fmd_f2 AR = {ar1, ar2}, AI = {ai1, ai2}, BR = {br1, br2}, BI = {bi1, bi2};
-    const fmd_f2 zero = {0.0f, 0.0f};
-    const fmd_f2 X = __builtin_elementwise_fma(AI, BI, __builtin_elementwise_fma(AR, BR, zero));
-    const fmd_f2 Y = __builtin_elementwise_fma(AI, BR, __builtin_elementwise_fma(-AR, BI, zero));
-    const float den1 = __builtin_fabsf(X.x) + __builtin_fabsf(Y.x), den2 = __builtin_fabsf(X.y) + __builtin_fabsf(Y.y);
-    const float t1 = __builtin_fabsf(X.x) - __builtin_fabsf(Y.x), t2 = __builtin_fabsf(X.y) - __builtin_fabsf(Y.y);
-    const uint32_t sx1 = f2u(X.x) & 0x80000000u, sx2 = f2u(X.y) & 0x80000000u;
-    const fmd_f2 S = {u2f(f2u(t1) ^ sx1), u2f(f2u(t2) ^ sx2)};
-    const fmd_f2 half = {0.5f, 0.5f}, big = {13194139533312.0f, 13194139533312.0f};
-    const fmd_f2 SP = NOWRAP ? S : S - (((S + half) + big) - big);
-    const float m1 = __builtin_fabsf(SP.x) * 4096.0f, m2 = __builtin_fabsf(SP.y) * 4096.0f;
-    const fmd_f2 M = {m1, m2}, DEN = {den1, den2};
-    const fmd_f2 R = {__builtin_amdgcn_rcpf(den1), __builtin_amdgcn_rcpf(den2)};
-    const fmd_f2 KQ = M * R;
-    const fmd_f2 K = {__builtin_rintf(KQ.x), __builtin_rintf(KQ.y)};
-    const fmd_f2 E0 = __builtin_elementwise_fma(K, DEN, -M);
-    const fmd_f2 E = {clamp01(E0.x), clamp01(E0.y)};
-    const fmd_f2 Q = K - E;
-    const fmd_f2 QS = {u2f(f2u(Q.x) ^ (f2u(SP.x) & 0x80000000u)), u2f(f2u(Q.y) ^ (f2u(SP.y) & 0x80000000u))};
-    const fmd_f2 B4 = {u2f(f2u(4096.0f) ^ sx1), u2f(f2u(4096.0f) ^ sx2)};
-    const fmd_f2 k8192 = {8192.0f, 8192.0f}, magic = {12582912.0f, 12582912.0f};
-    const fmd_f2 RES0 = (k8192 - B4) - QS;
-    const fmd_f2 RES = {u2f(f2u(RES0.x) ^ (f2u(Y.x) & 0x80000000u)), u2f(f2u(RES0.y) ^ (f2u(Y.y) & 0x80000000u))};
-    if constexpr (LO16) {
-        const fmd_f2 OUT = RES + magic;
-        o1 = (int)f2u(OUT.x); o2 = (int)f2u(OUT.y);
-    } else {
-        o1 = fmd_cvt_i32_nan0(RES.x); o2 = fmd_cvt_i32_nan0(RES.y);
-    }
-}
-#endif
-
 // Decimated samples travel packed: re in the low, im in the high 16 bits (|lp| <= 128 * D <= 16384).
 __device__ __forceinline__ uint32_t pack_lp(int re, int im) { return ((uint32_t)re & 0xFFFFu) | ((uint32_t)im << 16); }
 __device__ __forceinline__ int lp_re(uint32_t p) { return (int)(int16_t)(p & 0xFFFFu); }

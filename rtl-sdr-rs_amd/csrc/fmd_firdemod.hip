@@ -541,6 +541,8 @@ __global__ void __launch_bounds__(kThreads, fd_reg_blocks(NKU, NG, ROWS)) fmd_fi
 
     // ---- FIR on the matrix cores: NKU + NG - 1 operand fragments feed NG accumulators (fragment reuse, see above) ----------
     const uint32_t tcol = wave * (uint32_t)WSTEP + j * (uint32_t)PC;     // tile output index of the column's first output
+    if (FD_ABLATE(24)) __builtin_amdgcn_s_setprio(3);                    // knob: the matrix phase's dependent LDS -> xor -> MFMA chains at raised priority
+    if (FD_ABLATE(25)) __builtin_amdgcn_s_setprio(1);
     fd_i4 acc[NG];
 #pragma unroll
     for (int gi = 0; gi < NG; ++gi) acc[gi] = fd_i4{0, 0, 0, 0};     // (all zero: the first matrix instruction takes the inline constant, no v_mov)
@@ -565,6 +567,8 @@ __global__ void __launch_bounds__(kThreads, fd_reg_blocks(NKU, NG, ROWS)) fmd_fi
     // window parity is 0 for every output of every call: no sign flip of the matrix-core results (the general kernel
     // negates them for odd parities) and one pair of additive constants (scalars).
     const int cre = L.mre[0], cim = L.mim[0];
+    if (FD_ABLATE(24) || FD_ABLATE(25)) __builtin_amdgcn_s_setprio(0);
+    if (FD_ABLATE(26)) __builtin_amdgcn_s_setprio(2);                    // knob: the discriminator phase at raised priority instead
     float fr[NG], fi[NG];
 #pragma unroll
     for (int gi = 0; gi < NG; ++gi) {
@@ -616,28 +620,11 @@ __global__ void __launch_bounds__(kThreads, fd_reg_blocks(NKU, NG, ROWS)) fmd_fi
     int sum_all = 0, sum_lo = 0;
     int d_first = 0, cr0 = 0, ci0 = 0;
     bool any_guard = false;
-#ifdef FMD_PK_DISC
-    int dpk[NG];                                             // EXPERIMENT: the lane's discriminators in pairs, packed f32 (fmd_device.h)
-#pragma unroll
-    for (int gi = 0; gi + 1 < NG; gi += 2) {
-        const float b1r = q0 ? (gi == 0 ? xr : pr[gi - 1]) : pr[gi], b1i = q0 ? (gi == 0 ? xi : pi[gi - 1]) : pi[gi];
-        const float b2r = q0 ? pr[gi] : pr[gi + 1], b2i = q0 ? pi[gi] : pi[gi + 1];
-        disc_f32_c_x2<false, false>(fr[gi], fi[gi], b1r, b1i, fr[gi + 1], fi[gi + 1], b2r, b2i, dpk[gi], dpk[gi + 1]);
-    }
-    if constexpr (NG % 2 == 1) {
-        const float br = q0 ? pr[NG - 2] : pr[NG - 1], bi = q0 ? pi[NG - 2] : pi[NG - 1];
-        dpk[NG - 1] = disc_f32_c(fr[NG - 1], fi[NG - 1], br, bi);
-    }
-#endif
 #pragma unroll
     for (int gi = 0; gi < NG; ++gi) {
         const float br = q0 ? (gi == 0 ? xr : pr[gi - 1]) : pr[gi];
         const float bi = q0 ? (gi == 0 ? xi : pi[gi - 1]) : pi[gi];
-#ifdef FMD_PK_DISC
-        int d = dpk[gi]; (void)br; (void)bi;
-#else
         int d = FD_ABLATE(20) ? (int)(f2u(fr[gi]) ^ f2u(bi)) + (int)f2u(br) : disc_f32_c(fr[gi], fi[gi], br, bi);   // (:362); the value fits i16, `as i16` changes nothing (ablation 20: no discriminator)
-#endif
         if (gi == 0 && jfirst < 0 && tid == 0) {             // the first sample of the call takes the f64 path (:359) against demod_pre
             fmd_mul_conj((int)fr[0], (int)fi[0], st.demod_pre_re, st.demod_pre_im, cr0, ci0);
             bool g;

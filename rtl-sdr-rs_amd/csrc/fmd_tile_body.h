@@ -656,15 +656,8 @@ __device__ __forceinline__ void tile_body(const FmdLaunch& L, const TileCtx& X, 
             const float br1 = u2f(wave_shr1_dead(dead1, f2u(ar2))), bi1 = u2f(wave_shr1_dead(dead2, f2u(ai2)));   // second window of lane l - 1
             // (:362); DH == 1 is downsample 2: no i32 wrap to emulate.  The discriminators sit INSIDE the predicated stores
             // (see stream_pair_rounds)
-#ifdef FMD_PK_DISC
-            int o1, o2;
-            disc_f32_c_x2<DH == 1>(ar1, ai1, br1, bi1, ar2, ai2, ar1, ai1, o1, o2);     // the second window's predecessor is the first
-            if (lane > 0 && (FULL || i1 < cnt)) d16[i1] = (int16_t)o1;
-            if (FULL || i2 < cnt) d16[i2] = (int16_t)o2;
-#else
             if (lane > 0 && (FULL || i1 < cnt)) d16[i1] = (int16_t)disc_f32_c<DH == 1, true>(ar1, ai1, br1, bi1);
             if (FULL || i2 < cnt) d16[i2] = (int16_t)disc_f32_c<DH == 1, true>(ar2, ai2, ar1, ai1);
-#endif
         };
         int base = (int)wave * RS;
         const int full_to = cnt - 128;                       // (the bound as ONE scalar: `base + 128 <= cnt` cost an add per round)
@@ -1013,17 +1006,29 @@ __device__ __forceinline__ FastAddr fast_addr(const FmdLaunch& L)
 {
     const FmdFastGeo& g = L.fg;
     FastAddr A;
-    A.c = blockIdx.x * g.per + blockIdx.z;                   // grid (8, tiles, per): blockIdx.x is the XCD
     A.t = blockIdx.y;
     if constexpr (FAST == 2) {                               // the tile's row of the table: the staged range ready-made
+        // ONE scalar-memory round trip for everything a block needs up to its resampler: the geometry block (first 64 bytes of the
+        // kernel arguments) and the tile's WHOLE row (one 64-byte line).  The empty asm statement makes every field "used" here,
+        // so all the loads go out together and are waited for once; left to itself hipcc fetches each field where it is first
+        // used -- the block's channel behind one wait, the staged range behind a second, `s00` / `wbase` and the boxcar phase behind
+        // the staging barrier: one more round trip at the head of every wave's compute phase (session r05g: the rows that run
+        // closest to their staging skeleton lost 1 - 2 % to it).
         const FmdTileRow& R = *fast_row(L, A.t);
+        const FmdRowGeo& G = L.rg;
+        asm volatile("" :: "s"(G.iq), "s"(G.chan_stride), "s"(G.n_channels), "s"(G.per), "s"(G.raw_cap), "s"(G.p0), "s"(G.out_stride),
+                     "s"(R.lo2a), "s"(R.nchunks), "s"(R.wofs), "s"(R.jfirst), "s"(R.cnt), "s"(R.eq), "s"(R.er), "s"(R.k0), "s"(R.nk), "s"(R.jB),
+                     "s"(R.flags), "s"(R.wbase), "s"(R.s00), "s"(R.par));
+        __builtin_amdgcn_sched_barrier(0);
+        A.c = blockIdx.x * G.per + blockIdx.z;               // grid (8, tiles, per): blockIdx.x is the XCD
         A.lo2 = R.lo2a; A.hi2 = 0u;
-        A.gbase = L.rg.iq + (uint64_t)A.c * (uint32_t)L.rg.chan_stride;      // (a call is below 2^31 bytes per channel)
+        A.gbase = G.iq + (uint64_t)A.c * (uint32_t)G.chan_stride;            // (a call is below 2^31 bytes per channel)
         A.a0 = A.gbase + R.lo2a;
         A.nchunks = R.nchunks;
         A.whole = true;
         return A;
     } else {
+        A.c = blockIdx.x * g.per + blockIdx.z;
         const int32_t base = (int32_t)(A.t * g.step2);
         const int32_t lo = base + g.lo_off2, hi = base + g.hi_off2;
         A.lo2 = (uint32_t)(lo > 0 ? lo : 0);
@@ -1108,7 +1113,14 @@ __global__ void __launch_bounds__(kThreads) fmd_demod_tile_kernel(const FmdLaunc
         // checked the LDS sizing of every tile of this launch (fmd_fast_geometry), so there is nothing to assert.
         const FastAddr A = fast_addr<FAST>(L);
         if (A.c >= L.fg.n_channels) return;
+        if (FMD_ABLATE(9)) __builtin_amdgcn_s_sleep(2);      // pacing probes (experiment build): 128 / 512 clocks in front of the DMAs
+        if (FMD_ABLATE(10)) __builtin_amdgcn_s_sleep(8);
         if (!FMD_ABLATE(4)) issue_dma(A.a0, A.nchunks, smem, tid);
+        if constexpr (FAST == 2) {
+            // ... and what the resampler starts with, fetched under the DMAs' latency (waited for at the staging barrier, which waits
+            // for scalar loads anyway) instead of behind a wait of its own between the rounds and the resampler pass
+            asm volatile("" :: "s"(L.out), "s"(L.fa), "s"(L.fb), "s"(L.sr_shift), "s"(L.r.sr), "s"(L.r.fr), "s"(L.magic_R.m), "s"(L.magic_R.sh), "s"(L.inv_sr));
+        }
         const TileCtx X = fast_ctx<FAST>(L, A);              // scalar work under the load latency
         if (FMD_ABLATE(3)) {                                 // ablation: staging skeleton only
             __syncthreads();
@@ -1118,6 +1130,8 @@ __global__ void __launch_bounds__(kThreads) fmd_demod_tile_kernel(const FmdLaunc
         __builtin_amdgcn_s_waitcnt(0x0F70);
         __syncthreads();
         __builtin_amdgcn_s_setprio(0);
+        if (FMD_ABLATE(11)) __builtin_amdgcn_s_sleep(4);     // ... 256 / 1024 clocks behind the staging barrier
+        if (FMD_ABLATE(12)) __builtin_amdgcn_s_sleep(16);
         tile_body<DH>(L, X, smem);
         return;
     }

@@ -4,18 +4,28 @@ busy the vector / scalar / matrix pipes and the LDS were, from the committed PMC
 `extra` rows (`bound`, `valu_issue_frac`, ...).  Usage: summarize_bounds.py <tag> <round>     (reads gpurun_out/<tag>_pmc_configs.jsonl,
 gpurun_out/<tag>_pmc_fir/summary.json, gpurun_out/<tag>_pmc_fd/summary.json; method in profiles/README.md)
 
-Units (MI355X, gfx950): SQ_ACTIVE_INST_* and SQ_WAVE_CYCLES count in quad-cycles (4 shader clocks) summed over waves; SQ_BUSY_CYCLES counts
-shader clocks while the launch runs, summed over the chip's 32 shader engines.  With 1024 SIMDs (256 CUs x 4):
+Units (MI355X, gfx950): SQ_BUSY_CYCLES counts shader clocks while the launch runs, summed over the chip's 32 shader engines; SQ_INSTS_* are
+wave-instructions.  SQ_ACTIVE_INST_VALU / _SCA turned out to be issue-SLOT counts (1.02 / 1.08 quad-cycles per instruction whatever the
+instruction: session r05g), not pipe time -- a SIMD-32 starts a 2-clock instruction every 2 clocks, so slots x 4 clocks exceeds the launch
+(1.39 at downsample 1).  Pipe time is therefore instruction count x issue cost.  With 1024 SIMDs (256 CUs x 4):
     launch_cycles   = SQ_BUSY_CYCLES / 32
-    valu_issue_frac = SQ_ACTIVE_INST_VALU x 4 / 1024 / launch_cycles        (share of a SIMD's time its vector pipe was executing)
-    salu_issue_frac = SQ_ACTIVE_INST_SCA  x 4 / 1024 / launch_cycles
-    mfma_busy_frac  = SQ_VALU_MFMA_BUSY_CYCLES / 1024 / launch_cycles        (shader clocks the matrix pipes were busy, summed over SIMDs)
-A row is called VALU-bound when valu_issue_frac >= 0.70 AND it is the largest of the fractions beside the HBM fraction of the same launch."""
+    valu_issue_frac = SQ_INSTS_VALU x w / 1024 / launch_cycles    w = average issue clocks per vector instruction of the kernel's rounds, from the
+                      SHIPPED code object (tools/valu_weights.py: 2 clocks add / logic / f32 add-mul, 8 v_rcp_f32, 4 everything else; ~3.0 here)
+    salu_issue_frac = SQ_INSTS_SALU x 4.7 / 1024 / launch_cycles  (an s_add_u32 costs a SIMD 2.23 ns = 4.7 clocks at 8 waves: profiles/r04_salubench.txt)
+    mfma_busy_frac  = SQ_VALU_MFMA_BUSY_CYCLES / 1024 / launch_cycles   (shader clocks the matrix pipes were busy, summed over SIMDs)
+`bound` in bench.py = the largest of (HBM fraction of the launch, valu_issue_frac, salu_issue_frac, mfma_busy_frac)."""
 import json, os, sys
 tag, rnd = sys.argv[1], sys.argv[2]
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 g = os.path.join(root, "gpurun_out")
-N_SE, N_SIMD = 32.0, 1024.0
+N_SE, N_SIMD, SALU_CLOCKS = 32.0, 1024.0, 4.7
+sys.path.insert(0, os.path.join(root, "tools"))
+import valu_weights
+W = valu_weights.weights_by_kernel()
+
+
+def kernel_weight(name):
+    return W.get((name or "").strip(), 3.0)
 rows, sha = {}, None
 for l in open(os.path.join(g, tag + "_pmc_configs.jsonl")):
     d = json.loads(l)
@@ -28,13 +38,14 @@ for l in open(os.path.join(g, tag + "_pmc_configs.jsonl")):
 out = {"kernel_source_sha16": sha, "method": __doc__.split("Units", 1)[1].strip(), "demod": {}}
 for key, r in rows.items():
     p, w = r["per_wave"], r["waves_per_launch"]
-    if "SQ_BUSY_CYCLES" not in p or "SQ_ACTIVE_INST_VALU" not in p:
+    if "SQ_BUSY_CYCLES" not in p or "SQ_ACTIVE_INST_VALU" not in p or "SQ_INSTS_VALU" not in p:
         continue
     cyc = p["SQ_BUSY_CYCLES"] * w / N_SE
-    o = {"config": r["config"], "kernel": r["kernel"], "launch_cycles_under_pmc": round(cyc),
-         "valu_issue_frac": round(p["SQ_ACTIVE_INST_VALU"] * w * 4 / N_SIMD / cyc, 3),
-         "salu_issue_frac": round(p.get("SQ_ACTIVE_INST_SCA", 0) * w * 4 / N_SIMD / cyc, 3),
-         "lds_issue_frac": round(p.get("SQ_ACTIVE_INST_LDS", 0) * w * 4 / N_SIMD / cyc, 3),
+    kw = kernel_weight(r["kernel"])
+    o = {"config": r["config"], "kernel": r["kernel"], "launch_cycles_under_pmc": round(cyc), "valu_clocks_per_instruction": round(kw, 3),
+         "valu_issue_frac": round(p["SQ_INSTS_VALU"] * w * kw / N_SIMD / cyc, 3),
+         "salu_issue_frac": round(p.get("SQ_INSTS_SALU", 0) * w * SALU_CLOCKS / N_SIMD / cyc, 3),
+         "valu_issue_slots_x4_frac": round(p["SQ_ACTIVE_INST_VALU"] * w * 4 / N_SIMD / cyc, 3),
          "valu_per_wave": p.get("SQ_INSTS_VALU"), "salu_per_wave": p.get("SQ_INSTS_SALU"),
          "lds_bank_conflict_share": round(p["SQ_LDS_BANK_CONFLICT"] / p["SQ_LDS_IDX_ACTIVE"], 3) if p.get("SQ_LDS_IDX_ACTIVE") else None}
     out["demod"][key] = o
@@ -47,10 +58,13 @@ for name, sub in (("config4_fir", tag + "_pmc_fir"), ("config4_fir_demod_fused",
         continue
     cyc = c["SQ_BUSY_CYCLES"] / N_SE
     o = {"launch_cycles_under_pmc": round(cyc), "waves_per_launch": round(c.get("SQ_WAVES", 0))}
-    if "SQ_ACTIVE_INST_VALU" in c:
-        o["valu_issue_frac"] = round(c["SQ_ACTIVE_INST_VALU"] * 4 / N_SIMD / cyc, 3)
-    if "SQ_ACTIVE_INST_SCA" in c:
-        o["salu_issue_frac"] = round(c["SQ_ACTIVE_INST_SCA"] * 4 / N_SIMD / cyc, 3)
+    kname = {"config4_fir": "(anonymous namespace)::fmd_fir_mfma_kernel<5, false>", "config4_fir_demod_fused": "(anonymous namespace)::fmd_firdemod_reg_kernel<5, 8, true>"}[name]
+    kw = kernel_weight(kname)
+    o["kernel"], o["valu_clocks_per_instruction"] = kname, round(kw, 3)
+    if "SQ_INSTS_VALU" in c:
+        o["valu_issue_frac"] = round(c["SQ_INSTS_VALU"] * kw / N_SIMD / cyc, 3)
+    if "SQ_INSTS_SALU" in c:
+        o["salu_issue_frac"] = round(c["SQ_INSTS_SALU"] * SALU_CLOCKS / N_SIMD / cyc, 3)
     if "SQ_VALU_MFMA_BUSY_CYCLES" in c:
         o["mfma_busy_frac"] = round(c["SQ_VALU_MFMA_BUSY_CYCLES"] / N_SIMD / cyc, 3)
     if c.get("SQ_LDS_IDX_ACTIVE"):

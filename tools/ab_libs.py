@@ -4,6 +4,7 @@ code objects), all run on the same input buffers and the same clocks, one after 
 their own per build (scripts/ab_libs.sh) turned out to differ by up to 2 % between themselves whatever they load
 (profiles/r05_experiments.md section 2).  Usage:
     tools/ab_libs.py [--cfg ref|24|D,fast,slow]... [--rounds 5] [--steps 100] name=path/to/lib.so name2=...   ('name=' : the shipped library)
+    name=path@VAR=val,VAR2=val : environment variables set while THAT build's handle is created (knobs of the -DFMD_EXPERIMENT build)
 Prints one JSON line per (config, build) with the per-round times, the median and the difference to the first build."""
 import argparse, ctypes as C, json, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -15,8 +16,31 @@ from rtl_sdr_rs_amd import _ffi
 NAMED = {"ref": (6, 170000, 32000), "24": (10, 240000, 32000)}
 
 
+def parse_build(b):
+    name, _, rest = b.partition("=")
+    path, _, envs = rest.partition("@")
+    env = dict(e.split("=", 1) for e in envs.split(",") if e)
+    return name, load(os.path.join(ROOT, path) if path else _ffi.SO_PATH), env
+
+
+class knobs:
+    """environment of one build while its handle is created"""
+    def __init__(self, env):
+        self.env, self.saved = env, {}
+    def __enter__(self):
+        for k, v in self.env.items():
+            self.saved[k] = os.environ.get(k); os.environ[k] = v
+    def __exit__(self, *a):
+        for k, v in self.saved.items():
+            if v is None: os.environ.pop(k, None)
+            else: os.environ[k] = v
+
+
+_loaded = {}
 def load(path):
-    l = C.CDLL(path)
+    if path in _loaded:
+        return _loaded[path]
+    l = _loaded[path] = C.CDLL(path)
     for name, (res, args) in _ffi.PROTOTYPES.items():
         try:
             fn = getattr(l, name)
@@ -28,10 +52,9 @@ def load(path):
 
 def firdemod(a):
     import numpy as np
-    builds = []
-    for b in a.builds:
-        name, _, path = b.partition("=")
-        builds.append((name, load(os.path.join(ROOT, path) if path else _ffi.SO_PATH)))
+    parsed = [parse_build(b) for b in a.builds]
+    builds = [(n_, l_) for n_, l_, _ in parsed]
+    envs = [e_ for _, _, e_ in parsed]
     nch, n, T, M, fast, slow = 256, 2 << 20, 127, 8, 2500000, 48000
     taps = np.random.default_rng(1).integers(-2047, 2048, T).astype(np.int16)
     shift = fmd.auto_shift(taps)
@@ -44,10 +67,11 @@ def firdemod(a):
     cap = int(builds[0][1].fmd_firdemod_out_cap(M, fast, slow, n))
     out = torch.zeros((nch, cap), dtype=torch.int16, device="cuda")
     hs = []
-    for name, l in builds:
+    for (name, l), env in zip(builds, envs):
         h = C.c_void_p()
         dev = fmd.DeviceConfig(nch, -1, 0)
-        rc = l.fmd_firdemod_new(taps.ctypes.data_as(C.POINTER(C.c_int16)), T, M, shift, fast, slow, C.byref(dev), C.byref(h))
+        with knobs(env):
+            rc = l.fmd_firdemod_new(taps.ctypes.data_as(C.POINTER(C.c_int16)), T, M, shift, fast, slow, C.byref(dev), C.byref(h))
         assert rc == 0, (name, rc)
         hs.append(h)
     res = {name: [] for name, _ in builds}
@@ -87,10 +111,9 @@ def main():
     if a.firdemod:
         return firdemod(a)
     cfgs = [NAMED[c] if c in NAMED else tuple(int(x) for x in c.split(",")) for c in (a.cfg or ["24", "ref"])]
-    builds = []
-    for b in a.builds:
-        name, _, path = b.partition("=")
-        builds.append((name, load(os.path.join(ROOT, path) if path else _ffi.SO_PATH)))
+    parsed = [parse_build(b) for b in a.builds]
+    builds = [(n_, l_) for n_, l_, _ in parsed]
+    envs = [e_ for _, _, e_ in parsed]
     nch, N = a.channels, fmd.DEFAULT_BUF_LENGTH
     stream = torch.cuda.current_stream().cuda_stream
     bufs = []
@@ -104,10 +127,11 @@ def main():
         cap = int(builds[0][1].fmd_out_cap(C.byref(cfg), N))
         out = torch.zeros((nch, cap), dtype=torch.int16, device="cuda")
         hs = []
-        for name, l in builds:
+        for (name, l), env in zip(builds, envs):
             h = C.c_void_p()
             dev = fmd.DeviceConfig(nch, -1, 0)
-            rc = l.fmd_demod_new(C.byref(cfg), C.byref(dev), C.byref(h))
+            with knobs(env):
+                rc = l.fmd_demod_new(C.byref(cfg), C.byref(dev), C.byref(h))
             assert rc == 0, (name, rc)
             hs.append(h)
         res = {name: [] for name, _ in builds}
