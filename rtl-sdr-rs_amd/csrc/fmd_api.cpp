@@ -111,29 +111,49 @@ int choose_tiling(fmd_demod* d, uint32_t kt_req)
         // audio sample per thread, so e.g. 272 audio samples per tile (a second pass for 16 of them) measured
         // 10 % slower than 256 at the reference's own rates.  Weights are instruction counts of the kernel.
         const uint32_t waves = FMD_BLOCK_THREADS / 64u;
-        const double budget = 20480.0;
         const uint32_t dh = (r.D + 1u) / 2u;                                 // dwords per window
         const double c_round = 64.0 + 12.0 * dh, c_audio = 70.0 + 6.0 * (double)(r.fr / r.sr), c_fixed = 90.0;   // per wave: prologue, staging, barriers, epilogue
-        double best = 0.0;
-        kt = 1;
-        for (uint32_t k = 1; k <= 8192u; ++k) {              // (1024 until the end of round 2: at rate ratios near 1 that left most of the LDS unused)
-            r.kt = k;
-            if ((uint64_t)r.sr * (k + 2) >= (1u << 24)) break;
-            const uint32_t lp = fmd_tile_lp_cap(r), raw = fmd_tile_raw_cap(r);
-            const double lds = (double)raw + 2.0 * (lp + r.fr / r.sr + 2) + 32.0;
-            if (lds > budget && k > 1) break;
-            const uint64_t cnt = ((uint64_t)k * r.fr + r.sr - 1) / r.sr + 1;            // decimated samples formed
-            const uint64_t rounds = (cnt + 126) / 127, per_wave = (rounds + waves - 1) / waves;
-            // The chip is VALU-issue-saturated at almost every rate, so what counts is the wave-instructions a
-            // tile costs in all -- its rounds, the resampler once per wave that has an audio sample to form, the per-wave
-            // prologue / epilogue -- plus a share of the round slots that stay idle when the rounds do not divide by the
-            // waves (the tile's LDS is held until its busiest wave is done).  Checked against tiling sweeps at downsample 4,
-            // 5, 6, 10, 13, 14, 32, 64 (e.g. 64: 27 audio samples = one full round, not 31 = a second, nearly empty one: -7 %).
-            const uint64_t wave_passes = (k + 63) / 64;
-            const double idle = (double)(per_wave * waves - rounds);
-            const double work = ((double)rounds + 0.35 * idle) * c_round + (double)wave_passes * c_audio + (double)waves * c_fixed;
-            const double per_byte = work / (2.0 * r.D * (double)cnt);
-            if (k == 1 || per_byte < best) { best = per_byte; kt = k; }
+        // Two LDS budgets (round 5, profiles/r05_experiments.md section 9).  Rows whose vector work per tile would keep a CU's four
+        // SIMDs busy for less than ~85 % of the time its share of the HBM bandwidth needs for the tile's bytes (downsample 10, 12,
+        // 16 ...: ~3 clocks per wave-instruction on 4 SIMDs against ~13 bytes per clock and CU) run 1.5 - 2.8 % faster on ~17 KB tiles
+        // than on the 20 KB that 8 blocks per CU admit -- since the scalar diet made a tile's fixed costs cheap; the vector-bound
+        // rows (downsample <= 8, the odd factors up to 9) still want the largest tile.  So: plan with the large budget, price the
+        // result, and plan again with the small one if the row is on the memory side.
+        // plan(lo, hi): the tiling with the least issue work per input byte among those whose LDS need lies in (lo, hi]; 0 = none
+        auto plan = [&](double lo, double hi, double* per_byte_out) -> uint32_t {
+            double best = 0.0;
+            uint32_t pick = 0;
+            for (uint32_t k = 1; k <= 8192u; ++k) {          // (1024 until the end of round 2: at rate ratios near 1 that left most of the LDS unused)
+                r.kt = k;
+                if ((uint64_t)r.sr * (k + 2) >= (1u << 24)) break;
+                const uint32_t lp = fmd_tile_lp_cap(r), raw = fmd_tile_raw_cap(r);
+                const double lds = (double)raw + 2.0 * (lp + r.fr / r.sr + 2) + 32.0;
+                if (lds > hi && k > 1) break;
+                if (lds <= lo) continue;
+                const uint64_t cnt = ((uint64_t)k * r.fr + r.sr - 1) / r.sr + 1;        // decimated samples formed
+                const uint64_t rounds = (cnt + 126) / 127, per_wave = (rounds + waves - 1) / waves;
+                // What counts is the wave-instructions a tile costs in all -- its rounds, the resampler once per wave that has an
+                // audio sample to form, the per-wave prologue / epilogue -- plus a share of the round slots that stay idle when the
+                // rounds do not divide by the waves (the tile's LDS is held until its busiest wave is done).  Checked against tiling
+                // sweeps at downsample 4, 5, 6, 10, 13, 14, 32, 64 (e.g. 64: 27 audio samples = one full round, not 31 = a second,
+                // nearly empty one: -7 %).
+                const uint64_t wave_passes = (k + 63) / 64;
+                const double idle = (double)(per_wave * waves - rounds);
+                const double work = ((double)rounds + 0.35 * idle) * c_round + (double)wave_passes * c_audio + (double)waves * c_fixed;
+                const double per_byte = work / (2.0 * r.D * (double)cnt);
+                if (pick == 0 || per_byte < best) { best = per_byte; pick = k; }
+            }
+            if (per_byte_out) *per_byte_out = best;
+            return pick;
+        };
+        double per_byte = 0.0;
+        kt = plan(0.0, 20480.0, &per_byte);
+        if (kt == 0) kt = 1;
+        // per_byte = wave-instructions per input byte of that tiling: x 3 clocks / 4 SIMDs = vector clocks per byte and CU; the memory
+        // side: 1 / 13 clocks per byte and CU (8 TB/s over 256 CUs at 2.4 GHz)
+        if (per_byte * 0.75 * 13.0 < 0.85) {
+            const uint32_t k2 = plan(15500.0, 17300.0, nullptr);
+            if (k2) kt = k2;
         }
     }
     r.kt = kt;

@@ -266,6 +266,7 @@ __global__ void __launch_bounds__(kFirThreads, NKU <= 6 ? 8 : (NKU == 7 ? 6 : 4)
     __builtin_amdgcn_s_waitcnt(0x0F70);                             // vmcnt(0): the LDS-DMAs (and the A fragments) have landed
     __syncthreads();
 
+    if (FIR_ABLATE(8)) __builtin_amdgcn_s_sleep(16);                // pacing probes (experiment build): 1024 clocks behind the staging barrier ...
     const uint8_t* lb = reinterpret_cast<const uint8_t*>(lds);
     fir_i4 acc[kFirGroupsPerWave];
 #pragma unroll
@@ -299,6 +300,8 @@ __global__ void __launch_bounds__(kFirThreads, NKU <= 6 ? 8 : (NKU == 7 ? 6 : 4)
                                                          : ((gw)(uintptr_t)L.iq)[(uint64_t)c * L.stride_w + (w - L.Hw)];
         }
     }
+    if (FIR_ABLATE(9)) __builtin_amdgcn_s_sleep(16);                // ... or in front of the output stores
+    if (FIR_ABLATE(10)) __builtin_amdgcn_s_sleep(8);
     // lane (j, q) holds rows 4q..4q+3 of column j: (re_lo, re_hi, im_lo, im_hi) of output 4j + q
     const uint32_t par = (L.par_first ^ (L.half_M * q)) & 1u;
     const int cre = L.mre[par], cim = L.mim[par];

@@ -541,6 +541,7 @@ __global__ void __launch_bounds__(kThreads, fd_reg_blocks(NKU, NG, ROWS)) fmd_fi
 
     // ---- FIR on the matrix cores: NKU + NG - 1 operand fragments feed NG accumulators (fragment reuse, see above) ----------
     const uint32_t tcol = wave * (uint32_t)WSTEP + j * (uint32_t)PC;     // tile output index of the column's first output
+    if (FD_ABLATE(27)) __builtin_amdgcn_s_sleep(16);                     // pacing probes: 1024 clocks behind the staging barrier ...
     if (FD_ABLATE(24)) __builtin_amdgcn_s_setprio(3);                    // knob: the matrix phase's dependent LDS -> xor -> MFMA chains at raised priority
     if (FD_ABLATE(25)) __builtin_amdgcn_s_setprio(1);
     fd_i4 acc[NG];
@@ -649,6 +650,7 @@ __global__ void __launch_bounds__(kThreads, fd_reg_blocks(NKU, NG, ROWS)) fmd_fi
     __syncthreads();
 
     // ---- low_pass_real (:418-422): one divide per audio sample ---------------------------------------------------
+    if (FD_ABLATE(28)) __builtin_amdgcn_s_sleep(16);         // ... or in front of the divide pass
     const uint32_t nk = k1 - k0;
     int16_t* const outc = L.out + (uint64_t)c * L.out_stride;
     for (uint32_t k = tid; k < nk; k += kThreads) {

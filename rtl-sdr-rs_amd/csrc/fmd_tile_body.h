@@ -886,6 +886,9 @@ __device__ __forceinline__ void tile_body(const FmdLaunch& L, const TileCtx& X, 
 
     // a block that is nearly done holds 20 KB of LDS for nothing: let its last phase win issue arbitration
     // (A/B, two interleaved rounds: config 3 0.1620 -> 0.1607 ms, the reference's rates equal)
+    if (FMD_ABLATE(15)) __builtin_amdgcn_s_sleep(16);        // pacing probes: 1024 / 512 / 256 clocks between the rounds and the resampler pass
+    if (FMD_ABLATE(16)) __builtin_amdgcn_s_sleep(8);
+    if (FMD_ABLATE(17)) __builtin_amdgcn_s_sleep(4);
     __builtin_amdgcn_s_setprio(3);
     // ---- low_pass_real: one audio sample per lane -------------------------------------------------
     // Audio sample k0 + q ends at decimated sample e = eq + q*fa + (er + q*fb) / sr; it sums fa samples, or
@@ -1132,6 +1135,8 @@ __global__ void __launch_bounds__(kThreads) fmd_demod_tile_kernel(const FmdLaunc
         __builtin_amdgcn_s_setprio(0);
         if (FMD_ABLATE(11)) __builtin_amdgcn_s_sleep(4);     // ... 256 / 1024 clocks behind the staging barrier
         if (FMD_ABLATE(12)) __builtin_amdgcn_s_sleep(16);
+        if (FMD_ABLATE(13)) __builtin_amdgcn_s_sleep(32);
+        if (FMD_ABLATE(14)) __builtin_amdgcn_s_sleep(64);
         tile_body<DH>(L, X, smem);
         return;
     }

@@ -149,7 +149,12 @@ def main():
                 assert l.fmd_demod_check(h) == 0
                 res[name].append(e0.elapsed_time(e1) / a.steps)
                 buf = C.create_string_buffer(128)
-                l.fmd_demod_last_kernel(h, buf, len(buf)); kern[name] = buf.value.decode()
+                l.fmd_demod_last_kernel(h, buf, len(buf))
+                t1, t2, t3 = C.c_uint32(), C.c_uint32(), C.c_uint32()
+                l.fmd_demod_tiling(h, C.byref(t1), C.byref(t2), C.byref(t3))
+                lens = (C.c_size_t * nch)()
+                l.fmd_demod_last_out_len(h, lens)
+                kern[name] = "%s kt=%d lds=%d tiles=%d" % (buf.value.decode(), t1.value, t2.value, -(-int(lens[0]) // max(1, t1.value)))
         base = None
         for (name, l), h in zip(builds, hs):
             ts = sorted(res[name]); med = ts[len(ts) // 2]
