@@ -25,7 +25,7 @@ def summarize_firdemod(g, tag, rnd, out):
 
 
 tag = sys.argv[1]
-rnd = sys.argv[2] if len(sys.argv) > 2 else "r04"
+rnd = sys.argv[2] if len(sys.argv) > 2 else "r05"
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src, pmc, out = os.path.join(root, "gpurun_out", tag), os.path.join(root, "gpurun_out", tag + "_pmc"), os.path.join(root, "profiles")
 if "--firdemod-only" in sys.argv:      # a session that re-measured only the fused FIR kernel (its source is not one of the headline's)
@@ -120,6 +120,26 @@ if os.path.exists(os.path.join(g, tag + "_fir_mfma.json")):
     print("FIR mfma %.4f ms (%.1f %% of HBM spec), valu %.4f ms | trace timed %.1f us | traffic x%.4f | bank conflicts %.0f" % (
         m["ms_per_call"], 100 * m["hbm_frac_of_8TBps"], v["ms_per_call"], fir["rocprofv3_kernel_trace"]["avg_us_timed_region_last_100"],
         pf["hbm_traffic"]["ratio"], pf["lds_bank_conflict_cycles"]))
+# ---- config 4, stand-alone FIR, round 4 onwards: <tag>_fir.json (tools/bench_fir.py) + <tag>_pmc_fir/summary.json -------------------
+fj, fs = os.path.join(g, tag + "_fir.json"), os.path.join(g, tag + "_pmc_fir", "summary.json")
+if os.path.exists(fj) and os.path.exists(fs) and not os.path.exists(os.path.join(g, tag + "_fir_mfma.json")):
+    m = json.loads(open(fj).read().strip().splitlines()[-1])
+    c = json.load(open(fs))
+    w = c["SQ_WAVES"]["mean_per_launch"]
+    alg = m["algorithmic_GBps"] * m["ms_per_call"] * 1e6
+    fetch, wr = c["FETCH_SIZE"]["mean_per_launch"] * 2048, c["WRITE_SIZE"]["mean_per_launch"] * 1024
+    pf = {"command": "rocprofv3 --kernel-trace --pmc <set> -- python3 tools/bench_fir.py (scripts/gpu_pmc_fir.sh; one pass per counter set)",
+          "kernel": c.get("kernel_name"), "kernel_ns_under_pmc": c.get("kernel_ns_under_pmc"), "bench_line_same_session": m,
+          "counters": {k: v for k, v in c.items() if isinstance(v, dict) and "mean_per_launch" in v},
+          "per_wave": {k: round(c[k]["mean_per_launch"] / w, 2) for k in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_INSTS_VMEM_RD", "SQ_INSTS_VMEM_WR", "SQ_INSTS_MFMA",
+                                                                        "SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY") if k in c},
+          "mfma_busy_cycles_per_mfma": round(c["SQ_VALU_MFMA_BUSY_CYCLES"]["mean_per_launch"] / c["SQ_INSTS_MFMA"]["mean_per_launch"], 2),
+          "lds_bank_conflict_cycles": c["SQ_LDS_BANK_CONFLICT"]["mean_per_launch"], "lds_idx_active_cycles": c["SQ_LDS_IDX_ACTIVE"]["mean_per_launch"],
+          "hbm_traffic": {"fetch_bytes_per_launch(FETCH_SIZE x 1 KiB x 2)": fetch, "write_bytes_per_launch(WRITE_SIZE x 1 KiB)": wr,
+                          "bytes_per_launch": fetch + wr, "algorithmic_bytes_per_launch": round(alg), "ratio": round((fetch + wr) / alg, 4)}}
+    json.dump(pf, open(os.path.join(out, rnd + "_config4_fir_pmc.json"), "w"), indent=1)
+    print("FIR %.4f ms (%.1f %% of HBM spec) | traffic x%.4f | bank conflicts %.0f of %.0f LDS cycles" % (
+        m["ms_per_call"], 100 * m["hbm_frac_of_8TBps"], pf["hbm_traffic"]["ratio"], pf["lds_bank_conflict_cycles"], pf["lds_idx_active_cycles"]))
 cfgs = os.path.join(g, tag + "_configs.jsonl")
 if os.path.exists(cfgs):
     with open(os.path.join(out, rnd + "_configs.jsonl"), "w") as f:
@@ -131,4 +151,7 @@ if os.path.exists(pc):
 pr = os.path.join(g, tag + "_pmc_regions.jsonl")          # per-region instruction counts (scripts/gpu_pmc_regions.sh)
 if os.path.exists(pr):
     shutil.copy(pr, os.path.join(out, rnd + "_pmc_regions.jsonl"))
+pfr = os.path.join(g, tag + "_pmc_fd_regions.jsonl")       # per-region counters of the fused FIR kernel (scripts/gpu_pmc_fd_regions.sh)
+if os.path.exists(pfr):
+    shutil.copy(pfr, os.path.join(out, rnd + "_pmc_fd_regions.jsonl"))
 summarize_firdemod(g, tag, rnd, out)
