@@ -240,6 +240,17 @@ def extra_config4(fmd, torch, dev, stream, fused, bounds=None):
            "iq_msamples_per_s": round(nch * (n // 2) / ms / 1e3, 1), "outputs_per_channel": int(nout),
            "algorithmic_bytes_per_launch": alg, "GBps": round(alg / ms / 1e6, 1), "frac": round(alg / ms / 1e6 / HBM_PEAK_GBS, 4)}
     res.update(bound_fields(bounds, None, res["frac"], section="config4_fir_demod_fused" if fused else "config4_fir"))
+    if not fused:
+        # A third of this operator's bytes are WRITTEN (int32 re, im), and one 268 MB output buffer written again by every call
+        # partly stays in the 256 MB memory-side cache.  The same calls rotating over four output buffers (1.07 GB: every written
+        # byte goes to HBM) are the steady state of a consumer that keeps the outputs; `frac` above stays the round-to-round figure.
+        outs = [out] + [torch.zeros_like(out) for _ in range(3)]
+        ms4, lo4, hi4, _ = time_calls(torch, lambda i: bank.filter_device(bufs[i % 3].data_ptr(), n, outs[i % 4].data_ptr(), cap, stream),
+                                      settle=60, steps=60, regions=3)
+        res["rotating_4_output_buffers"] = {"ms_per_call": round(ms4, 4), "frac": round(alg / ms4 / 1e6 / HBM_PEAK_GBS, 4)}
+        res["note"] = ("33 % of the bytes are outputs; reads alone stream at ~6.7 TB/s, written bytes at ~4.9 TB/s, the matrix phase is "
+                       "hidden (-1.9 % without it): profiles/r05_experiments.md section 12")
+        del outs
     del bank, out, bufs
     return res
 

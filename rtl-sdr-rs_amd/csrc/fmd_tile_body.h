@@ -836,7 +836,7 @@ __device__ __forceinline__ void tile_body(const FmdLaunch& L, const TileCtx& X, 
         fmd_mul_conj(r1, i1w, r0, i0, cr, ci);
         d16[1 - jfirst] = (int16_t)fmd_fast_atan2(ci, cr);
     }
-    __syncthreads();
+    if (!FMD_ABLATE(20)) __syncthreads();                    // (probe, experiment build: what the barrier in front of the resampler pass costs)
     if constexpr (STREAM && (DH == 1 || DH == 2)) {
         // The call's LAST decimated sample: a lane's span is two windows, and when the call ends after a lane's FIRST
         // window the span runs past the channel-call -- stream_pair_rounds clamps its load into the call, which shifts the
@@ -911,6 +911,7 @@ __device__ __forceinline__ void tile_body(const FmdLaunch& L, const TileCtx& X, 
 #pragma clang loop unroll(disable) vectorize(disable)
         for (uint32_t q = tid; q < nk; q += kThreads) {
             if (FMD_ABLATE(2)) { outc[T.k0 + q] = d16[q + 1]; continue; }       // ablation: no resampler
+            if (FMD_ABLATE(21)) { outc[T.k0 + q] = (int16_t)q; continue; }      // ... and no LDS read either: the bare store
             if constexpr (FA < 0) {
                 const int s = (int)(T.eq + T.er + q);
                 outc[T.k0 + q] = d16[(s > 0 ? s : 0) - jfirst];
@@ -935,7 +936,12 @@ __device__ __forceinline__ void tile_body(const FmdLaunch& L, const TileCtx& X, 
                     const int v = dp[L.fa];
                     sum += extra ? v : 0;
                 }
-                outc[T.k0 + q] = (int16_t)fmd_sdiv_magic(sum, L.magic_R);
+                const int16_t av = (int16_t)fmd_sdiv_magic(sum, L.magic_R);
+                if (FMD_ABLATE(18)) __builtin_nontemporal_store(av, &outc[T.k0 + q]);      // store-policy probe (experiment build): nt
+                else if (FMD_ABLATE(19)) asm volatile("" :: "v"((int)av));                // ... everything but the store itself
+                else if (FMD_ABLATE(22)) L.out[(c & 63u) * 256u + (q & 255u)] = av;       // ... stores that never leave the L2 (32 KB of addresses)
+                else outc[T.k0 + q] = av;
+                if (FMD_ABLATE(23)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // ... does the end of the wave wait for the store anyway?
             }
         }
     };
