@@ -278,7 +278,7 @@ def extra_cfg_ref(fmd, torch, dev, stream, bufs, bounds=None):
 
 
 # (downsample, rate_out, rate_resample): the rest of the supported domain, tools/bench_configs.py's table
-DOMAIN = [(1, 48000, 48000), (2, 500000, 32000), (4, 256000, 48000), (5, 250000, 44100), (7, 166666, 32000), (8, 250000, 44100),
+DOMAIN = [(1, 48000, 48000), (2, 500000, 32000), (3, 400000, 48000), (4, 256000, 48000), (5, 250000, 44100), (7, 166666, 32000), (8, 250000, 44100),
           (12, 192000, 32000), (16, 150000, 32000), (64, 37500, 8000)]
 
 

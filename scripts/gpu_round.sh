@@ -7,7 +7,7 @@ TAG=${1:-r05}
 bash scripts/gpu_check.sh $TAG; RC=$?
 bash scripts/gpu_pmc.sh ${TAG}_pmc > gpurun_out/${TAG}_pmc.log 2>&1
 python3 tools/bench_configs.py > gpurun_out/${TAG}_configs.jsonl 2> gpurun_out/${TAG}_configs.err
-bash scripts/gpu_pmc_configs.sh ${TAG} "cfg-ref" "cfg-2.4" "D=1 48k" "D=2 500k" "D=4" "D=5" "D=7" "D=8" "D=12" "D=16" "D=64" > gpurun_out/${TAG}_pmc_configs.log 2>&1
+bash scripts/gpu_pmc_configs.sh ${TAG} "cfg-ref" "cfg-2.4" "D=1 48k" "D=2 500k" "D=3 (odd)" "D=4" "D=5" "D=7" "D=8" "D=12" "D=16" "D=64" > gpurun_out/${TAG}_pmc_configs.log 2>&1
 python3 tools/bench_fir.py > gpurun_out/${TAG}_fir.json 2>/dev/null
 bash scripts/gpu_pmc_fir.sh ${TAG}_pmc_fir > gpurun_out/${TAG}_pmc_fir.log 2>&1
 python3 tools/bench_firdemod.py > gpurun_out/${TAG}_firdemod.json 2>/dev/null

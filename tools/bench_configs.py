@@ -9,7 +9,7 @@ import rtl_sdr_rs_amd as fmd
 CONFIGS = [("cfg-ref (optimal_settings(94.9 MHz, 170 kHz), simple_fm.rs:25-27)", 6, 170000, 32000),
            ("cfg-2.4 (BASELINE configs[2])", 10, 240000, 32000),
            ("D=4 256k->48k", 4, 256000, 48000), ("D=8 250k->44.1k", 8, 250000, 44100), ("D=2 500k->32k", 2, 500000, 32000),
-           ("D=7 (odd) 166666->32k", 7, 166666, 32000), ("D=5 (odd) 250k->44.1k", 5, 250000, 44100),
+           ("D=3 (odd) 400k->48k", 3, 400000, 48000), ("D=7 (odd) 166666->32k", 7, 166666, 32000), ("D=5 (odd) 250k->44.1k", 5, 250000, 44100),
            ("D=1 48k->48k", 1, 48000, 48000), ("D=16 150k->32k", 16, 150000, 32000), ("D=64 37.5k->8k", 64, 37500, 8000),
            ("D=32 512k->32k", 32, 512000, 32000), ("D=12 192k->32k", 12, 192000, 32000), ("D=13 (odd) 208k->32k", 13, 208000, 32000), ("D=14 224k->32k", 14, 224000, 32000)]
 if len(sys.argv) > 1:
