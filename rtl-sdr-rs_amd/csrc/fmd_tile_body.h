@@ -1116,6 +1116,13 @@ __global__ void __launch_bounds__(kThreads) fmd_demod_tile_kernel(const FmdLaunc
     // A freshly dispatched block's only job is to get its loads out: let it win issue arbitration against the
     // computing waves of the other resident blocks until the DMAs are queued (measured -1.8 % launch time).
     __builtin_amdgcn_s_setprio(3);
+#ifdef FMD_EXPERIMENT
+    // Timeline probe (ablation bit 29; tools/timeline.py): every wave records its entry, the end of its staging barrier and its end
+    // (shader-clock counter) with the hardware slot it ran in, behind the per-channel counts of the caller's `out_len` array.
+    const bool tl_on = FMD_ABLATE(29);
+    uint64_t tl_t0 = 0, tl_t1 = 0;
+    if (tl_on) tl_t0 = __builtin_readcyclecounter();
+#endif
     if constexpr (FAST) {
         // One phase class, tiles that repeat exactly (kt * fr % sr == 0), XCD-aware grid (8, tiles, ceil(C / 8)):
         // the byte range of the tile is a multiply-add of the first 64 bytes of the kernel arguments.  The host has
@@ -1143,7 +1150,21 @@ __global__ void __launch_bounds__(kThreads) fmd_demod_tile_kernel(const FmdLaunc
         if (FMD_ABLATE(12)) __builtin_amdgcn_s_sleep(16);
         if (FMD_ABLATE(13)) __builtin_amdgcn_s_sleep(32);
         if (FMD_ABLATE(14)) __builtin_amdgcn_s_sleep(64);
+#ifdef FMD_EXPERIMENT
+        if (tl_on) tl_t1 = __builtin_readcyclecounter();
+#endif
         tile_body<DH>(L, X, smem);
+#ifdef FMD_EXPERIMENT
+        if (tl_on && (tid & 63u) == 0u && L.out_len) {
+            const uint64_t t2 = __builtin_readcyclecounter();
+            const uint32_t lin = (blockIdx.z * gridDim.y + blockIdx.y) * 8u + blockIdx.x;
+            uint32_t* rec = L.out_len + ((L.n_channels + 1023u) & ~1023u) + 8u * (4u * lin + (tid >> 6));
+            rec[0] = (uint32_t)tl_t0; rec[1] = (uint32_t)(tl_t0 >> 32); rec[2] = (uint32_t)(tl_t1 - tl_t0); rec[3] = (uint32_t)(t2 - tl_t0);
+            rec[4] = __builtin_amdgcn_s_getreg((31 << 11) | 4);      // HW_ID
+            rec[5] = __builtin_amdgcn_s_getreg((31 << 11) | 20);     // XCC_ID
+            rec[6] = X.c; rec[7] = blockIdx.y | (blockIdx.y << 16);  // (tile, block of the channel-call)
+        }
+#endif
         return;
     }
     uint32_t c = blockIdx.z * 65535u + blockIdx.y, tix = blockIdx.x;

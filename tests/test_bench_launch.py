@@ -201,7 +201,7 @@ def test_default_line_carries_parity_and_the_side_lines():
     assert 0.3 < ex["cfg_ref"]["frac"] < 1.0 and ex["check_per_step"]["ms_per_step"] >= r["ms_per_step"] * 0.9
     assert ex["sink_pcie"]["all_status_ok"] and ex["sink_pcie"]["delivered"] >= 40
     rows = {row["downsample"]: row for row in ex["domain"]["rows"]}
-    assert set(rows) == {1, 2, 4, 5, 7, 8, 12, 16, 64} and all("error" not in row and 0.05 < row["frac"] < 1.0 for row in rows.values())
+    assert set(rows) == {1, 2, 3, 4, 5, 7, 8, 12, 16, 64} and all("error" not in row and 0.05 < row["frac"] < 1.0 for row in rows.values())
     assert rows[4]["kernel"].startswith("fmd_tk::fmd_demod_stream_kernel<2,") and rows[7]["kernel"].startswith("fmd_tk::fmd_demod_tile_kernel<-7,")
     assert ex["cfg_ref"]["kernel"].startswith("fmd_tk::fmd_demod_tile_kernel<3,")
     pc = ex["power_clock"]                                      # clock and power under load: sensors may be absent on a box,
