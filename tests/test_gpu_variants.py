@@ -51,3 +51,22 @@ def test_shipped_library_ignores_the_knobs(fmd, monkeypatch):
     for k, v in {"FMD_XCD": "0", "FMD_KT": "7", "FMD_FORCE_GENERIC": "1", "FMD_F64_GUARD_LOG2": "-1"}.items():
         monkeypatch.setenv(k, v)
     assert fmd.DemodBank(mkcfg(fmd, *CFG_24), 16).tiling() == ref
+
+
+def test_two_budget_tiling_plans_what_was_measured(fmd):
+    """`choose_tiling` (csrc/fmd_api.cpp) plans twice: the most audio samples per tile that fit 20 KB of LDS (8 tiles per CU), and --
+    for the rows whose vector work leaves the CU's SIMDs idle most of the time -- again among the tilings of 15.5 ... 17.3 KB
+    (profiles/r05_experiments.md 9: -2 ... -4 % on those rows, the vector-heavier rows want the largest tile).  The figures in DESIGN.md
+    and the committed profiles were measured with exactly these tilings; a planner change has to show up here."""
+    import os
+    if os.environ.get("FMD_LIB"):
+        pytest.skip("a tuning build is loaded")
+    from test_gpu_parity import mkcfg
+    want = {(10, 240000, 32000): 101, (12, 192000, 32000): 105, (20, 200000, 48000): 91, (16, 150000, 32000): 106,   # re-planned (memory side)
+            (6, 170000, 32000): 256, (5, 250000, 44100): 256, (7, 166666, 32000): 242, (8, 250000, 44100): 179,    # the largest that fits
+            (64, 37500, 8000): 26, (14, 224000, 32000): 72}
+    for cfg, kt in want.items():
+        t = fmd.DemodBank(mkcfg(fmd, *cfg), 4096).tiling()
+        assert t["audio_per_tile"] == kt and t["lds_bytes"] <= 20480 and t["block_threads"] == 256, (cfg, t)
+        if cfg[0] >= 10 and cfg != (14, 224000, 32000) and cfg != (64, 37500, 8000):
+            assert 15500 < t["lds_bytes"] <= 17700, (cfg, t)
