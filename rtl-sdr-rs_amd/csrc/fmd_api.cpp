@@ -538,7 +538,11 @@ int fmd_demod_new(const fmd_demod_config* config, const fmd_device_config* dev, 
                 if (fmd_tile_lp_cap(rs) > cap_cnt || (uint64_t)rs.sr * (k + 2) >= (1u << 24)) break;
                 const uint64_t cnt = ((uint64_t)k * r.fr + r.sr - 1) / r.sr + 1;
                 const uint64_t rounds = (cnt + 126) / 127, per_wave = (rounds + 3) / 4, passes = (k + 255) / 256;
-                const double work = (double)per_wave * 4.0 * 100.0 + (double)passes * 4.0 * (70.0 + 6.0 * (double)(r.fr / r.sr)) + 4.0 * 150.0;
+                // (the fixed cost of a tile: downsample 2 -- twice the rounds per byte, half the bytes per round -- measured best at the
+                //  largest tile its rounds admit, 384 instead of 256 audio samples at 500 k -> 32 k: -2.5 %; downsample 4 at the model's
+                //  choice: profiles/r05_experiments.md 15)
+                const double fixed = r.D == 2u ? 250.0 : 150.0;
+                const double work = (double)per_wave * 4.0 * 100.0 + (double)passes * 4.0 * (70.0 + 6.0 * (double)(r.fr / r.sr)) + 4.0 * fixed;
                 const double per_audio = work / (double)k;
                 if (kts == 0u || per_audio < best) { best = per_audio; kts = k; }
             }
