@@ -980,8 +980,9 @@ int fmd_firdemod_new(const int16_t* taps, uint32_t n_taps, uint32_t decim, uint3
         if (ng > 8u) ng = 8u;                                 // (9 ... 12 are instantiated in the experiment build only)
 #endif
         if (ng >= 4u && ng <= 12u && ng != 9u && ng != 11u && fa >= 4ull * ng && (uint64_t)r.sr * (64u * (4u * ng - 2u)) < (1u << 24)) f->reg_ng = ng;
-        // tiles per CU that go with the column length: 8 (20 KB) up to 18 outputs per column, then 7, 6, 5
-        static const uint32_t budget[13] = {0, 0, 0, 0, 20480, 20480, 23400, 27300, 32700, 32700, 40900, 40900, 54600};
+        // tiles per CU that go with the column length: 8 (20 KB) up to 18 outputs per column, then 7, 6, 5, 4, 3 -- in whole LDS
+        // allocation granules (1280 bytes on gfx950: 128 per CU), so that a tile a few bytes over does not cost a CU one of its blocks
+        static const uint32_t budget[13] = {0, 0, 0, 0, 20480, 20480, 23040, 26880, 32000, 32000, 40960, 40960, 53760};
         if (f->reg_ng && !lds_knob) f->lds_budget = budget[f->reg_ng];
     }
     for (uint32_t kt = 1; kt <= 1024; ++kt) {

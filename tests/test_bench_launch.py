@@ -27,7 +27,11 @@ def test_gpus_flag_spawns_ranks_and_fails_loudly_without_gpu(fmd):
                        capture_output=True, env=clean_env(), timeout=600)
     err = p.stderr.decode()
     assert p.returncode != 0
-    assert "rank exit codes" in err and err.count("no gfx950 device") >= 2, err[-2000:]   # both ranks ran and refused
+    # both ranks ran and refused (on a box under load the launcher's 15 s grace can end the slower rank before it has said so:
+    # then its exit code -- a kill -- still counts as a failure, and one refusal message is enough)
+    assert "rank exit codes" in err and err.count("no gfx950 device") >= 1, err[-2000:]
+    codes = err[err.index("rank exit codes"):].split("[", 1)[1].split("]", 1)[0].split(",")
+    assert len(codes) == 2 and all(int(c) != 0 for c in codes), err[-2000:]
     assert p.stdout.decode().strip() == ""
 
 

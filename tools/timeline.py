@@ -77,6 +77,7 @@ def main():
     ap.add_argument("--cfg", action="append", default=[])
     ap.add_argument("--lib", default="rtl-sdr-rs_amd/libfmd_hip_exp.so")
     ap.add_argument("--dbg", type=int, default=0)
+    ap.add_argument("--kt", type=int, default=0, help="FMD_KT of the experiment build: audio samples per tile")
     ap.add_argument("--channels", type=int, default=4096)
     ap.add_argument("--dump", default=None, help="write the raw records of the last configuration to this .npy file")
     a = ap.parse_args()
@@ -98,6 +99,7 @@ def main():
         out = torch.zeros((nch, cap), dtype=torch.int16, device="cuda")
         for dbg in (a.dbg, a.dbg | (1 << 29)):
             os.environ["FMD_DBG"] = str(dbg)
+            if a.kt: os.environ["FMD_KT"] = str(a.kt)
             h = C.c_void_p()
             dev = fmd.DeviceConfig(nch, -1, 0)
             assert l.fmd_demod_new(C.byref(cfg), C.byref(dev), C.byref(h)) == 0
@@ -120,6 +122,9 @@ def main():
                 buf = C.create_string_buffer(128)
                 l.fmd_demod_last_kernel(h, buf, len(buf))
                 res["kernel"] = buf.value.decode()
+                t1, t2, t3 = C.c_uint32(), C.c_uint32(), C.c_uint32()
+                l.fmd_demod_tiling(h, C.byref(t1), C.byref(t2), C.byref(t3))
+                res["audio_per_tile"], res["lds_bytes"] = t1.value, t2.value
                 print(json.dumps(res), flush=True)
                 if a.dump:
                     np.save(a.dump, rec[rec[:, 3] != 0])
