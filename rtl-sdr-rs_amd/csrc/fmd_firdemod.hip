@@ -980,9 +980,13 @@ int fmd_firdemod_new(const int16_t* taps, uint32_t n_taps, uint32_t decim, uint3
         if (ng > 8u) ng = 8u;                                 // (9 ... 12 are instantiated in the experiment build only)
 #endif
         if (ng >= 4u && ng <= 12u && ng != 9u && ng != 11u && fa >= 4ull * ng && (uint64_t)r.sr * (64u * (4u * ng - 2u)) < (1u << 24)) f->reg_ng = ng;
-        // tiles per CU that go with the column length: 8 (20 KB) up to 18 outputs per column, then 7, 6, 5, 4, 3 -- in whole LDS
-        // allocation granules (1280 bytes on gfx950: 128 per CU), so that a tile a few bytes over does not cost a CU one of its blocks
-        static const uint32_t budget[13] = {0, 0, 0, 0, 20480, 20480, 23040, 26880, 32000, 32000, 40960, 40960, 53760};
+        // tiles per CU that go with the column length: 8 (20 KB) up to 18 outputs per column, then 6, 5, 5, 4, 3 -- in whole LDS
+        // allocation granules (1280 bytes on gfx950, 128 per CU: profiles/r05_lds_granule.jsonl), so that a tile a few bytes over
+        // does not cost a CU one of its blocks.  The full columns of NG = 6 / 7 need 23.3 / 27.6 KB: one granule more than 7 / 6
+        // blocks per CU leave, so they get the budget of 6 / 5 (rounds 4 - 5 gave them 23 400 / 27 300 bytes: the blocks per CU of
+        // the larger budget with the tile of the smaller one; session r05as: whole-granule budgets BELOW the columns' need are
+        // far worse -- the planner then cuts the tile until it fits)
+        static const uint32_t budget[13] = {0, 0, 0, 0, 20480, 20480, 26880, 32000, 32000, 32000, 40960, 40960, 53760};
         if (f->reg_ng && !lds_knob) f->lds_budget = budget[f->reg_ng];
     }
     for (uint32_t kt = 1; kt <= 1024; ++kt) {
