@@ -233,7 +233,7 @@ __global__ void __launch_bounds__(kFirThreads, NKU <= 6 ? 8 : (NKU == 7 ? 6 : 4)
     const gq amat = (gq)(uintptr_t)H.amat + lane;
     fir_i4 A[NKU];
 #pragma unroll
-    for (int k = 0; k < NKU; ++k) A[k] = amat[k * 64];
+    for (int k = 0; k < NKU; ++k) A[k] = FIR_ABLATE(4) ? fir_i4{(int)lane, k, 1, 2} : amat[k * 64];   // (probe: what the tap fragments' L2 traffic costs)
     if (FIR_ABLATE(1)) {
     } else if (whole) {
         const unsigned char* src = reinterpret_cast<const unsigned char*>(reinterpret_cast<const uint32_t*>((uintptr_t)H.iq) + (uint64_t)c * H.stride_w + (w0 - H.Hw)) + 16u * (SWZ ? fir_swz_slot(tid) : tid);
