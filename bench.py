@@ -251,6 +251,15 @@ def extra_config4(fmd, torch, dev, stream, fused, bounds=None):
         res["note"] = ("33 % of the bytes are outputs; reads alone stream at ~6.7 TB/s, written bytes at ~4.9 TB/s, the matrix phase is "
                        "hidden (-1.9 % without it): profiles/r05_experiments.md section 12")
         del outs
+        # the same shape with an 8-bit filter (every |tap| <= 127): one i8 digit per tap, eight outputs per operand column -- the
+        # same matrix instructions and LDS operand reads cover twice the outputs
+        taps8 = rng.integers(-127, 128, T).astype(np.int16)
+        bank8 = fmd.FirBank(taps8, M, nch, device_id=dev.index)
+        ms8, lo8, hi8, _ = time_calls(torch, lambda i: bank8.filter_device(bufs[i % 3].data_ptr(), n, out.data_ptr(), cap, stream),
+                                      settle=60, steps=60, regions=3)
+        res["taps_8bit_one_digit"] = {"tap_digits": bank8.tap_digits(), "ms_per_call": round(ms8, 4), "frac": round(alg / ms8 / 1e6 / HBM_PEAK_GBS, 4)}
+        res["tap_digits"] = bank.tap_digits()
+        del bank8
     del bank, out, bufs
     return res
 

@@ -214,6 +214,10 @@ int fmd_fir_new(const int16_t *taps, uint32_t n_taps, uint32_t decim, const fmd_
                 fmd_fir **out);
 void fmd_fir_free(fmd_fir *f);
 int fmd_fir_reset(fmd_fir *f);
+/* Which form the handle runs (introspection for tests and bench lines): 1 = matrix cores with one i8 digit per tap (every
+ * |tap| <= 127: eight outputs per operand column), 2 = two digits (|tap| <= 2047: four), 0 = the vector-pipe kernel
+ * (decim > 64 or a filter too long for the matrix-core form). */
+int fmd_fir_tap_digits(const fmd_fir *f);
 /* Complex outputs one call of nbytes can produce per channel (upper bound). */
 size_t fmd_fir_out_cap(uint32_t n_taps, uint32_t decim, size_t nbytes);
 /* HOST buffers: iq [n_channels][nbytes]; out [n_channels][out_cap][2] int32 (re, im);

@@ -90,6 +90,7 @@ PROTOTYPES = {
     "fmd_fir_new": (C.c_int, [_i16p, C.c_uint32, C.c_uint32, C.POINTER(DeviceConfig), C.POINTER(_vp)]),
     "fmd_fir_free": (None, [_vp]),
     "fmd_fir_reset": (C.c_int, [_vp]),
+    "fmd_fir_tap_digits": (C.c_int, [_vp]),
     "fmd_fir_out_cap": (_sz, [C.c_uint32, C.c_uint32, _sz]),
     "fmd_fir_filter_batch": (C.c_int, [_vp, _vp, _sz, _vp, _sz, _szp]),
     "fmd_fir_filter_device": (C.c_int, [_vp, _vp, _sz, _vp, _sz, _szp, _vp]),

@@ -195,7 +195,10 @@ __device__ __forceinline__ void fir_dma16(const unsigned char* g, unsigned char*
 // which lane fetches which 16 bytes.  (PMC: SQ_LDS_BANK_CONFLICT 10.5 M cycles per launch without it.)
 __device__ __forceinline__ uint32_t fir_swz_slot(uint32_t slot) { return slot ^ (((slot >> 4) & 1u) << 1); }
 
-template <int NKU, bool SWZ>
+// DIGITS: tap digits of the A fragments (fmd_fir_common.h).  2: a column is four outputs, lane (j, q) ends up with (re_lo, re_hi,
+// im_lo, im_hi) of output 4j + q; 1 (every |tap| <= 127): a column is EIGHT outputs, lane (j, q) ends up with (re, im) of outputs
+// 8j + 2q and 8j + 2q + 1 -- the same matrix instructions and operand reads cover twice the outputs.
+template <int NKU, bool SWZ, int DIGITS>
 // (8 blocks per CU = 64 VGPRs per lane hold up to six operand fragments beside the accumulators; the two longest filter shapes
 //  -- NKU 7, 8: beyond ~190 taps at decimate 8 -- spilled 4 ... 32 registers to scratch memory under that bound, which
 //  tests/test_isa_invariants.py now forbids for every kernel: they take 6 and 4 blocks per CU)
@@ -279,7 +282,7 @@ __global__ void __launch_bounds__(kFirThreads, NKU <= 6 ? 8 : (NKU == 7 ? 6 : 4)
 #pragma unroll
         for (int gi = 0; gi < kFirGroupsPerWave; ++gi) {
             const uint32_t g = wave + 4u * gi;
-            if (g < L.groups && 64u * g < no) {                     // wave-uniform
+            if (g < L.groups && (DIGITS == 1 ? 128u : 64u) * g < no) {   // wave-uniform
                 const uint8_t* col = lb + (16u * g + j) * L.col_bytes + 64u * NKU * pass;
 #pragma unroll
                 for (int k = 0; k < NKU; ++k) {
@@ -302,30 +305,56 @@ __global__ void __launch_bounds__(kFirThreads, NKU <= 6 ? 8 : (NKU == 7 ? 6 : 4)
     }
     if (FIR_ABLATE(9)) __builtin_amdgcn_s_sleep(16);                // ... or in front of the output stores
     if (FIR_ABLATE(10)) __builtin_amdgcn_s_sleep(8);
-    // lane (j, q) holds rows 4q..4q+3 of column j: (re_lo, re_hi, im_lo, im_hi) of output 4j + q
-    const uint32_t par = (L.par_first ^ (L.half_M * q)) & 1u;
-    const int cre = L.mre[par], cim = L.mim[par];
+    if constexpr (DIGITS == 2) {
+        // lane (j, q) holds rows 4q..4q+3 of column j: (re_lo, re_hi, im_lo, im_hi) of output 4j + q
+        const uint32_t par = (L.par_first ^ (L.half_M * q)) & 1u;
+        const int cre = L.mre[par], cim = L.mim[par];
 #pragma unroll
-    for (int gi = 0; gi < kFirGroupsPerWave; ++gi) {
-        const uint32_t g = wave + 4u * gi;
-        const uint32_t o = 64u * g + 4u * j + q;
-        if (g < L.groups && o < no && !FIR_ABLATE(2)) {
-            int re = acc[gi].x + (acc[gi].y << 7), im = acc[gi].z + (acc[gi].w << 7);
-            if (L.par_first) { re = -re; im = -im; }
-            int2* dst = reinterpret_cast<int2*>(L.out) + ((uint64_t)c * L.out_cap + o0 + o);
-            *dst = make_int2(re + cre, im + cim);
+        for (int gi = 0; gi < kFirGroupsPerWave; ++gi) {
+            const uint32_t g = wave + 4u * gi;
+            const uint32_t o = 64u * g + 4u * j + q;
+            if (g < L.groups && o < no && !FIR_ABLATE(2)) {
+                int re = acc[gi].x + (acc[gi].y << 7), im = acc[gi].z + (acc[gi].w << 7);
+                if (L.par_first) { re = -re; im = -im; }
+                int2* dst = reinterpret_cast<int2*>(L.out) + ((uint64_t)c * L.out_cap + o0 + o);
+                *dst = make_int2(re + cre, im + cim);
+            }
+        }
+    } else {
+        // lane (j, q) holds rows 4q..4q+3 of column j: (re, im) of output 8j + 2q and of output 8j + 2q + 1; the first one's window
+        // has the column's parity (an even number of windows further on), the second one's is half_M dwords later
+        const uint32_t par0 = L.par_first & 1u, par1 = (L.par_first ^ L.half_M) & 1u;
+        const int cre0 = L.mre[par0], cim0 = L.mim[par0], cre1 = L.mre[par1], cim1 = L.mim[par1];
+#pragma unroll
+        for (int gi = 0; gi < kFirGroupsPerWave; ++gi) {
+            const uint32_t g = wave + 4u * gi;
+            const uint32_t o = 128u * g + 8u * j + 2u * q;
+            if (g < L.groups && o < no && !FIR_ABLATE(2)) {
+                int re0 = acc[gi].x, im0 = acc[gi].y, re1 = acc[gi].z, im1 = acc[gi].w;
+                if (L.par_first) { re0 = -re0; im0 = -im0; re1 = -re1; im1 = -im1; }
+                int2* dst = reinterpret_cast<int2*>(L.out) + ((uint64_t)c * L.out_cap + o0 + o);   // (8-byte aligned; a channel's row need not be 16)
+                dst[0] = make_int2(re0 + cre0, im0 + cim0);
+                if (o + 1u < no) dst[1] = make_int2(re1 + cre1, im1 + cim1);
+            }
         }
     }
 }
 
-template <int NKU>
-void launch_mfma(const FirLaunch& L, dim3 g, size_t lds, hipStream_t stream, bool swz)
+template <int NKU, int DIGITS>
+void launch_mfma_d(const FirLaunch& L, dim3 g, size_t lds, hipStream_t stream, bool swz)
 {
     // The conflict-free LDS layout (SWZ) removes every bank conflict of the fragment reads (PMC: 10.5 M -> 0 cycles
     // per launch) but the lane-permuted DMA that produces it costs more than the conflicts did: 0.1365 vs 0.1344 ms
     // per config-4 call, loads alone 0.0996 vs 0.0973 ms.  Off unless FMD_FIR_SWZ=1 (experiment build, read at creation).
-    if (L.col_bytes == 64u && swz) hipLaunchKernelGGL((fmd_fir_mfma_kernel<NKU, true>), g, dim3(kFirThreads), lds, stream, L);
-    else hipLaunchKernelGGL((fmd_fir_mfma_kernel<NKU, false>), g, dim3(kFirThreads), lds, stream, L);
+    if (L.col_bytes == 64u && swz) hipLaunchKernelGGL((fmd_fir_mfma_kernel<NKU, true, DIGITS>), g, dim3(kFirThreads), lds, stream, L);
+    else hipLaunchKernelGGL((fmd_fir_mfma_kernel<NKU, false, DIGITS>), g, dim3(kFirThreads), lds, stream, L);
+}
+
+template <int NKU>
+void launch_mfma(const FirLaunch& L, dim3 g, size_t lds, hipStream_t stream, bool swz, uint32_t digits)
+{
+    if (digits == 1u) launch_mfma_d<NKU, 1>(L, g, lds, stream, swz);
+    else launch_mfma_d<NKU, 2>(L, g, lds, stream, swz);
 }
 
 // hist_out[c][k] = virtual dword (stride_w + k): the last Hw dwords of history ++ call
@@ -366,6 +395,7 @@ struct fmd_fir {
     uint32_t* d_wre = nullptr; uint32_t* d_wim = nullptr;
     uint32_t* d_amat = nullptr;                           // MFMA form: banded tap matrix, fragment order
     uint32_t n_pass = 0, nku = 0, groups = 0;             // n_pass == 0: VALU kernel only
+    uint32_t digits = 0;                                  // tap digits of the matrix-core form (1: every |tap| <= 127; 2); 0 without it
     uint32_t dbg = 0;                                     // ablation bits of the -DFMD_EXPERIMENT build (fmd_host.h), read at creation
     bool swz = false;
     int32_t mre[2] = {0, 0}, mim[2] = {0, 0};
@@ -420,9 +450,10 @@ int fir_enqueue(fmd_fir* f, const void* d_iq, size_t nbytes, void* d_out, size_t
     L.out_tile = (uint32_t)ot;
     L.dbg = f->dbg;
     if (n_out && f->n_pass) {
-        L.amat = f->d_amat; L.n_pass = f->n_pass; L.nku = f->nku; L.groups = f->groups; L.col_bytes = 8u * f->M;
+        const uint32_t opc = f->digits == 1u ? 8u : 4u;              // outputs per column
+        L.amat = f->d_amat; L.n_pass = f->n_pass; L.nku = f->nku; L.groups = f->groups; L.col_bytes = 2u * opc * f->M;
         L.mre[0] = f->mre[0]; L.mre[1] = f->mre[1]; L.mim[0] = f->mim[0]; L.mim[1] = f->mim[1];
-        L.out_tile = 64u * f->groups;
+        L.out_tile = 16u * opc * f->groups;
         // staged bytes of a full tile, and the furthest byte any fragment read touches
         const size_t staged = (((((size_t)(L.out_tile - 1) * L.half_M + L.NP + 3) / 4) + 3) & ~(size_t)3) * 16;
         const size_t touched = (size_t)16 * f->groups * L.col_bytes + (size_t)64 * f->n_pass * f->nku;
@@ -435,14 +466,14 @@ int fir_enqueue(fmd_fir* f, const void* d_iq, size_t nbytes, void* d_out, size_t
         H.n_channels = L.n_channels; H.n_out = L.n_out; H.out_tile = L.out_tile;
         H.Hw = L.Hw; H.NP = L.NP; H.half_M = L.half_M; H.wd_first = L.wd_first;
         switch (f->nku) {
-            case 1: launch_mfma<1>(L, g, lds, stream, f->swz); break;
-            case 2: launch_mfma<2>(L, g, lds, stream, f->swz); break;
-            case 3: launch_mfma<3>(L, g, lds, stream, f->swz); break;
-            case 4: launch_mfma<4>(L, g, lds, stream, f->swz); break;
-            case 5: launch_mfma<5>(L, g, lds, stream, f->swz); break;
-            case 6: launch_mfma<6>(L, g, lds, stream, f->swz); break;
-            case 7: launch_mfma<7>(L, g, lds, stream, f->swz); break;
-            default: launch_mfma<8>(L, g, lds, stream, f->swz); break;
+            case 1: launch_mfma<1>(L, g, lds, stream, f->swz, f->digits); break;
+            case 2: launch_mfma<2>(L, g, lds, stream, f->swz, f->digits); break;
+            case 3: launch_mfma<3>(L, g, lds, stream, f->swz, f->digits); break;
+            case 4: launch_mfma<4>(L, g, lds, stream, f->swz, f->digits); break;
+            case 5: launch_mfma<5>(L, g, lds, stream, f->swz, f->digits); break;
+            case 6: launch_mfma<6>(L, g, lds, stream, f->swz, f->digits); break;
+            case 7: launch_mfma<7>(L, g, lds, stream, f->swz, f->digits); break;
+            default: launch_mfma<8>(L, g, lds, stream, f->swz, f->digits); break;
         }
         FIR_TRY(hipGetLastError());
     } else if (n_out) {
@@ -522,9 +553,14 @@ int fmd_fir_new(const int16_t* taps, uint32_t n_taps, uint32_t decim, const fmd_
     f->dbg = fmd_knob_u32("FMD_DBG", 0);
     f->swz = fmd_knob_u32("FMD_FIR_SWZ", 0) == 1u;
     FmdFirMfmaPlan plan;
-    if (!(env_mfma && env_mfma[0] == '0') && fmd_fir_build_mfma(taps, n_taps, decim, plan)) {
-        f->n_pass = plan.n_pass; f->nku = plan.nku;
-        uint32_t groups = 16384u / (128u * decim);
+    // an 8-bit filter (every |tap| <= 127) takes the one-digit form: twice the outputs per matrix instruction (FMD_FIR_DIGITS=2, experiment
+    // build: the two-digit form for an A/B)
+    uint32_t digits = 1u;
+    for (uint32_t t = 0; t < n_taps; ++t) if (taps[t] > 127 || taps[t] < -127) digits = 2u;
+    if (fmd_knob_u32("FMD_FIR_DIGITS", 0) == 2u) digits = 2u;
+    if (!(env_mfma && env_mfma[0] == '0') && fmd_fir_build_mfma(taps, n_taps, decim, plan, digits)) {
+        f->n_pass = plan.n_pass; f->nku = plan.nku; f->digits = plan.digits;
+        uint32_t groups = 16384u / ((plan.digits == 1u ? 256u : 128u) * decim);   // ~16 KB of input per tile
         f->groups = groups < 1u ? 1u : (groups > 16u ? 16u : groups);
         if (const char* eg = fmd_knob("FMD_FIR_GROUPS")) { const uint32_t g = (uint32_t)atoi(eg); if (g >= 1 && g <= 4u * kFirGroupsPerWave) f->groups = g; }   // tuning
         amat.swap(plan.amat);
@@ -566,6 +602,8 @@ void fmd_fir_free(fmd_fir* f)
     if (f->stream) (void)hipStreamDestroy(f->stream);
     delete f;
 }
+
+int fmd_fir_tap_digits(const fmd_fir* f) { return f ? (int)f->digits : FMD_ERR_INVALID_ARG; }
 
 int fmd_fir_reset(fmd_fir* f)
 {

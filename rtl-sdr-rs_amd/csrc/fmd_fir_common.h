@@ -10,16 +10,21 @@
 struct FmdFirMfmaPlan {
     std::vector<uint32_t> amat;   // [n_pass * nku][64 lanes][4 dwords]: A fragments, K index = byte offset from the window start of output 0
     uint32_t n_pass = 0, nku = 0; // K-chunks of 64 bytes = n_pass * nku
+    uint32_t digits = 2;          // tap digits (1: every |tap| <= 127, eight outputs per column; 2: four)
     int32_t mre[2] = {0, 0}, mim[2] = {0, 0};   // additive constants (s8 domain) by window parity
 };
 
-// Rows r = 4*i + reg (i: output within the quad, reg: re_lo, re_hi, im_lo, im_hi), taps split as h = 128*hi + lo with
-// |lo| <= 64, |hi| <= 16 (both i8), rotate_90's signs (simple_fm.rs:276-299) and the re / im byte selection folded in.
+// Two tap digits (any |tap| <= 2047): rows r = 4*i + reg (i: output within the quad, reg: re_lo, re_hi, im_lo, im_hi), taps split as
+// h = 128*hi + lo with |lo| <= 64, |hi| <= 16 (both i8).  One digit (every |tap| <= 127: an 8-bit filter): rows r = 2*i + reg (i: output
+// within the OCTET, reg: re, im) -- eight outputs per column instead of four, so a column group covers 128 outputs with the matrix
+// instructions of 64.  rotate_90's signs (simple_fm.rs:276-299) and the re / im byte selection are folded in either way.
 // Returns false when the shape does not fit the matrix-core form (decim > 64 or more than 64 K-chunks).
-inline bool fmd_fir_build_mfma(const int16_t* taps, uint32_t n_taps, uint32_t decim, FmdFirMfmaPlan& P)
+inline bool fmd_fir_build_mfma(const int16_t* taps, uint32_t n_taps, uint32_t decim, FmdFirMfmaPlan& P, uint32_t digits = 2)
 {
-    const uint32_t nk_tot = (2u * (3u * decim + n_taps) + 63u) / 64u;
+    const uint32_t opc = digits == 1u ? 8u : 4u;          // outputs per column
+    const uint32_t nk_tot = (2u * ((opc - 1u) * decim + n_taps) + 63u) / 64u;
     if (decim > 64 || nk_tot > 64) return false;
+    P.digits = digits == 1u ? 1u : 2u;
     P.n_pass = (nk_tot + 7u) / 8u;
     P.nku = (nk_tot + P.n_pass - 1u) / P.n_pass;
     const uint32_t chunks = P.n_pass * P.nku;
@@ -28,19 +33,22 @@ inline bool fmd_fir_build_mfma(const int16_t* taps, uint32_t n_taps, uint32_t de
     for (uint32_t kk = 0; kk < chunks; ++kk)
         for (uint32_t lane = 0; lane < 64; ++lane)
             for (uint32_t b = 0; b < 16; ++b) {
-                const uint32_t r = lane & 15u, i = r >> 2, reg = r & 3u;
+                const uint32_t r = lane & 15u;
+                const uint32_t i = P.digits == 1u ? r >> 1 : r >> 2;                   // output within the column
+                const uint32_t comp = P.digits == 1u ? r & 1u : (r >> 1) & 1u;         // 0: re, 1: im
                 const int64_t rel = (int64_t)(64u * kk + 16u * (lane >> 4) + b) - 2ll * decim * i;
                 if (rel < 0 || rel >= 2ll * n_taps) continue;
                 const uint32_t t = (uint32_t)rel >> 1, sg = (uint32_t)rel & 1u;
                 const uint32_t phase = (t + 2u * ((decim / 2u * i) & 1u)) & 3u;
                 int sign;
-                if ((reg >> 1) == 0) sign = (phase == 0 && sg == 0) || (phase == 3 && sg == 1) ? 1
-                                          : (phase == 1 && sg == 1) || (phase == 2 && sg == 0) ? -1 : 0;
+                if (comp == 0) sign = (phase == 0 && sg == 0) || (phase == 3 && sg == 1) ? 1
+                                    : (phase == 1 && sg == 1) || (phase == 2 && sg == 0) ? -1 : 0;
                 else sign = (phase == 0 && sg == 1) || (phase == 1 && sg == 0) ? 1
                           : (phase == 2 && sg == 1) || (phase == 3 && sg == 0) ? -1 : 0;
                 const int h = taps[t];
                 const int lo = ((h + 64) & 127) - 64, hi = (h - lo) / 128;      // h = 128*hi + lo, both i8
-                ab[((size_t)kk * 64 + lane) * 16 + b] = (uint8_t)(int8_t)(sign * ((reg & 1u) ? hi : lo));
+                const int digit = P.digits == 1u ? h : ((r & 1u) ? hi : lo);
+                ab[((size_t)kk * 64 + lane) * 16 + b] = (uint8_t)(int8_t)(sign * digit);
             }
     for (int par = 0; par < 2; ++par) {
         int64_t sr = 0, si = 0;

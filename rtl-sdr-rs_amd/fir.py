@@ -32,6 +32,10 @@ class FirBank:
     def out_cap(self, nbytes):
         return int(lib().fmd_fir_out_cap(self.taps.size, self.decim, nbytes))
 
+    def tap_digits(self):
+        """1 / 2: the matrix-core form with one (every |tap| <= 127) or two i8 digits per tap; 0: the vector-pipe kernel."""
+        return int(lib().fmd_fir_tap_digits(self._h))
+
     def filter_batch(self, iq):
         """iq uint8 [n_channels, nbytes] -> int32 array [n_channels, n_out, 2] (re, im)."""
         iq = np.ascontiguousarray(iq, dtype=np.uint8)

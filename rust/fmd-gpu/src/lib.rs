@@ -116,6 +116,7 @@ extern "C" {
     pub fn fmd_fir_new(taps: *const i16, n_taps: u32, decim: u32, dev: *const DeviceConfig, out: *mut *mut fmd_fir) -> c_int;
     pub fn fmd_fir_free(f: *mut fmd_fir);
     pub fn fmd_fir_reset(f: *mut fmd_fir) -> c_int;
+    pub fn fmd_fir_tap_digits(f: *const fmd_fir) -> c_int;
     pub fn fmd_fir_out_cap(n_taps: u32, decim: u32, nbytes: usize) -> usize;
     pub fn fmd_fir_filter_batch(f: *mut fmd_fir, iq: *const u8, nbytes: usize, out: *mut i32, out_cap: usize, out_len: *mut usize) -> c_int;
     pub fn fmd_fir_filter_device(f: *mut fmd_fir, d_iq: *const c_void, nbytes: usize, d_out: *mut c_void, out_cap: usize, out_len_each: *mut usize, stream: *mut c_void) -> c_int;

@@ -99,18 +99,65 @@ def test_gpu_fir_matches_oracle(fmd, oracle, T, M):
     fir_stream_case(fmd, oracle, T, M)
 
 
+def fir_stream_case_8bit(fmd, oracle, T, M, want_digits):
+    """The same streaming walk with an 8-bit filter (every |tap| <= 127; the extremes +-127 among them)."""
+    rng = np.random.default_rng(T * 11 + M)
+    taps = rng.integers(-127, 128, T).astype(np.int16)
+    taps[rng.integers(0, T)] = 127
+    taps[rng.integers(0, T)] = -127
+    nch = 3
+    bank = fmd.FirBank(taps, M, nch)
+    assert bank.tap_digits() == want_digits, (T, M, bank.tap_digits())
+    hs = [oracle.fir_new(taps, M) for _ in range(nch)]
+    for call in range(5):
+        n = int(rng.integers(1, 400)) * 8 if call else 8
+        if call == 3:
+            n = 8 * int(rng.integers(6000, 9000))                 # several tiles per channel
+        iq = rng.integers(0, 256, (nch, n), dtype=np.uint8)
+        if call == 2:
+            iq[:] = np.where(rng.integers(0, 2, (nch, n)) > 0, 255, 0)   # full scale
+        got = bank.filter_batch(iq)
+        for c in range(nch):
+            exp = oracle.fir_filter(hs[c], iq[c])
+            assert got[c].shape == exp.shape and np.array_equal(got[c], exp), (T, M, call, c)
+    for h in hs:
+        oracle.lib.fmo_fir_free(h)
+
+
 @pytest.mark.gpu
-@pytest.mark.parametrize("form", ["valu", "mfma_swz"])
+@pytest.mark.parametrize("T,M", FIR_SHAPES)
+def test_gpu_fir_one_digit_form_matches_oracle(fmd, oracle, T, M):
+    """Every |tap| <= 127: the matrix-core kernel takes ONE i8 digit per tap and eight outputs per operand column
+    (fmd_fir_mfma_kernel<NKU, SWZ, 1>); decim > 64 keeps the vector-pipe kernel.  Same shapes as the two-digit test: one and several K
+    passes, both window parities (an odd decim / 2 gives the two outputs of a lane different additive constants)."""
+    fir_stream_case_8bit(fmd, oracle, T, M, 1 if M <= 64 else 0)
+
+
+@pytest.mark.gpu
+def test_gpu_fir_digits_follow_the_taps(fmd):
+    assert fmd.FirBank(np.full(9, 127, np.int16), 8).tap_digits() == 1
+    assert fmd.FirBank(np.array([5, -128, 3], np.int16), 8).tap_digits() == 2      # -128 is one too many for the sign-flipped rows
+    assert fmd.FirBank(np.array([5, 2047, 3], np.int16), 8).tap_digits() == 2
+    assert fmd.FirBank(np.ones(4, np.int16), 128).tap_digits() == 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("form", ["valu", "mfma_swz", "two_digits"])
 def test_gpu_fir_forced_forms(fmd, oracle, request, form):
     """The VALU form forced for small decim (FMD_FIR_MFMA=0) and the conflict-free LDS layout of the matrix-core form
     (FMD_FIR_SWZ=1, decim 8 only) are knobs of the -DFMD_EXPERIMENT build: each form re-runs itself ONCE in a child process
     on that library and walks through all its shapes there."""
-    if run_in_exp_child(request, {"FMD_FIR_MFMA": "0"} if form == "valu" else {"FMD_FIR_SWZ": "1"}):
+    if run_in_exp_child(request, {"FMD_FIR_MFMA": "0"} if form == "valu" else {"FMD_FIR_SWZ": "1"} if form == "mfma_swz" else {"FMD_FIR_DIGITS": "2"}):
         return
     for T, M in FIR_SHAPES:
         if form == "mfma_swz" and M != 8:
             continue
+        if form == "two_digits":                                  # an 8-bit filter forced through the two-digit form (the A/B knob)
+            fir_stream_case_8bit(fmd, oracle, T, M, 2 if M <= 64 else 0)
+            continue
         fir_stream_case(fmd, oracle, T, M)
+        if form == "mfma_swz":
+            fir_stream_case_8bit(fmd, oracle, T, M, 1)            # the swizzled layout under the one-digit form (decim 8: columns 128 bytes apart: plain)
 
 
 @pytest.mark.gpu
