@@ -240,6 +240,17 @@ def extra_config4(fmd, torch, dev, stream, fused, bounds=None):
            "iq_msamples_per_s": round(nch * (n // 2) / ms / 1e3, 1), "outputs_per_channel": int(nout),
            "algorithmic_bytes_per_launch": alg, "GBps": round(alg / ms / 1e6, 1), "frac": round(alg / ms / 1e6 / HBM_PEAK_GBS, 4)}
     res.update(bound_fields(bounds, None, res["frac"], section="config4_fir_demod_fused" if fused else "config4_fir"))
+    if fused:
+        # the same shape with an 8-bit filter (every |tap| <= 127): one i8 digit per tap, (re, im) of eight outputs per operand fragment,
+        # 24 instead of 40 matrix instructions per wave (fmd_firdemod_reg1_kernel) -- here, where the outputs are
+        # 0.3 % of the bytes and the matrix phase is the largest region, it pays
+        taps8 = rng.integers(-127, 128, T).astype(np.int16)
+        bank8 = fmd.FirDemodBank(taps8, M, fast, slow, nch, device_id=dev.index)
+        ms8, lo8, hi8, _ = time_calls(torch, lambda i: bank8.demodulate_device(bufs[i % 3].data_ptr(), n, out.data_ptr(), cap, stream),
+                                      settle=60, steps=60, regions=3)
+        bank8.check()
+        res["taps_8bit_one_digit"] = {"kernel": bank8.kernel_name(), "ms_per_call": round(ms8, 4), "frac": round(alg / ms8 / 1e6 / HBM_PEAK_GBS, 4)}
+        del bank8
     if not fused:
         # A third of this operator's bytes are WRITTEN (int32 re, im), and one 268 MB output buffer written again by every call
         # partly stays in the 256 MB memory-side cache.  The same calls rotating over four output buffers (1.07 GB: every written

@@ -236,7 +236,8 @@ int fmd_fir_filter_device(fmd_fir *f, const void *d_iq, size_t nbytes, void *d_o
  * followed by the reference's own fm_demod (:355-367, the f64 sample at the first filter output of every call) and
  * low_pass_real (:408-426, rate_out -> rate_resample).  With taps = 1...1, n_taps == decim == downsample, shift == 0
  * it returns exactly what fmd_demod_* (and the oracle of the reference chain) return -- tested bit for bit; that is
- * its anchor.
+ * its anchor.  (An 8-bit filter -- every |tap| <= 127 -- takes a form of the matrix-core kernels with one i8 digit per tap and
+ * eight outputs per operand column, here and in fmd_fir_*: same results, fewer matrix instructions.)
  * Domain: decim even and <= 64, 1 <= n_taps <= 1024, |taps| <= 2047, (128 * sum|taps|) >> shift <= 16384 (so that
  * |lp| stays in the discriminator's range, the boxcar's bound at downsample 128), shift <= 24.  A shift that brings
  * (128 * sum|taps|) >> shift down to 2048 -- the boxcar's range at downsample 16 -- selects the kernel's f32 form of

@@ -106,6 +106,7 @@ struct FirDemodLaunch {
     uint32_t reuse;            // host only: decim / 8 selects the fragment-reuse instantiation (decim == 8, one pass; 16 in the experiment build), 0 the plain one
     uint32_t f32_disc;         // 1: |lp| <= 2048 (the boxcar's range at downsample 16): the f32 discriminator is exact (fmd_device.h)
     uint32_t reg_ng;           // host only: > 0 selects fmd_firdemod_reg_kernel<NKU, reg_ng> (discriminator out of the matrix-core result registers)
+    uint32_t digits;           // host only: tap digits of the A fragments (1: fmd_firdemod_reg1_kernel)
     FmdMagic magic_fr;         // fmd_udiv_magic(x, magic_fr) == x / fr for x < 2^24
     FdRow rows[kFdRows];
 };
@@ -432,9 +433,15 @@ constexpr int fd_reg_blocks(int nku, int ng, bool rows)
     if (nku >= 7 || !rows) return ng <= 6 ? 6 : (ng <= 8 ? 4 : 3);
     return ng <= 6 ? 8 : (ng <= 8 ? 5 : 3);
 }
-template <int NKU, int NG, bool ROWS>
-__global__ void __launch_bounds__(kThreads, fd_reg_blocks(NKU, NG, ROWS)) fmd_firdemod_reg_kernel(const FirDemodLaunch L)
+// DIGITS = 1 (every |tap| <= 127, fmd_fir_common.h): the 16 rows of an operand fragment are (re, im) of EIGHT consecutive outputs, so
+// a lane's NG outputs of its column come out of NG / 2 accumulators -- lane (j, q) holds outputs 8 g + 2q and 8 g + 2q + 1 of column j
+// in acc[g] -- fed by NKU + NG - 2 operand fragments (two chunks per accumulator step); the columns, the tiles and everything behind
+// the discriminators are the two-digit form's.  The odd outputs' predecessors are the lane's own even ones; the even ones' sit 16
+// lanes down (lane (j, 3)'s previous accumulator for q = 0, column j - 1's last output -- lane (j - 1, 2) -- for the first).
+template <int NKU, int NG, bool ROWS, int DIGITS>
+__device__ __forceinline__ void fd_reg_body(const FirDemodLaunch& L)
 {
+    static_assert(DIGITS == 2 || (DIGITS == 1 && NG % 2 == 0), "one digit: two outputs per accumulator row group");
     constexpr int PC = 4 * NG - 2;                           // outputs per column
     constexpr int WSTEP = 16 * PC - 1;                       // tile outputs from one wave's first column to the next wave's
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
@@ -544,21 +551,23 @@ __global__ void __launch_bounds__(kThreads, fd_reg_blocks(NKU, NG, ROWS)) fmd_fi
     if (FD_ABLATE(27)) __builtin_amdgcn_s_sleep(16);                     // pacing probes: 1024 clocks behind the staging barrier ...
     if (FD_ABLATE(24)) __builtin_amdgcn_s_setprio(3);                    // knob: the matrix phase's dependent LDS -> xor -> MFMA chains at raised priority
     if (FD_ABLATE(25)) __builtin_amdgcn_s_setprio(1);
-    fd_i4 acc[NG];
+    constexpr int NA = DIGITS == 1 ? NG / 2 : NG;            // accumulators per lane
+    constexpr int AS = DIGITS == 1 ? 2 : 1;                  // K-chunks from one accumulator's column to the next (8 / 4 outputs of 16 bytes)
+    fd_i4 acc[NA];
 #pragma unroll
-    for (int gi = 0; gi < NG; ++gi) acc[gi] = fd_i4{0, 0, 0, 0};     // (all zero: the first matrix instruction takes the inline constant, no v_mov)
+    for (int gi = 0; gi < NA; ++gi) acc[gi] = fd_i4{0, 0, 0, 0};     // (all zero: the first matrix instruction takes the inline constant, no v_mov)
     {
         const uint8_t* col = reinterpret_cast<const uint8_t*>(lds) + 16u * tcol + 16u * q;   // decimate 8: 16 bytes per output
 #pragma unroll
-        for (int sft = 0; sft < NKU + NG - 1; ++sft) {
+        for (int sft = 0; sft < NKU + AS * (NA - 1); ++sft) {
             if (FD_ABLATE(16)) continue;                                                    // ablation: no operand reads, no matrix instructions
             fd_i4 B = *reinterpret_cast<const fd_i4*>(col + 64 * sft);
             B = B ^ (int)0x80808080;                                                       // u8 -> s8
 #pragma unroll
-            for (int jj = 0; jj < NG; ++jj)
-                if (sft - jj >= 0 && sft - jj < NKU) {
-                    if (!FD_ABLATE(17)) acc[jj] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A[sft - jj], B, acc[jj], 0, 0, 0);
-                    else acc[jj].x ^= B.x + A[sft - jj].y;                                 // ablation: operand reads kept, every matrix instruction replaced by two vector ones
+            for (int jj = 0; jj < NA; ++jj)
+                if (sft - AS * jj >= 0 && sft - AS * jj < NKU) {
+                    if (!FD_ABLATE(17)) acc[jj] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A[sft - AS * jj], B, acc[jj], 0, 0, 0);
+                    else acc[jj].x ^= B.x + A[sft - AS * jj].y;                            // ablation: operand reads kept, every matrix instruction replaced by two vector ones
                 }
         }
     }
@@ -570,41 +579,65 @@ __global__ void __launch_bounds__(kThreads, fd_reg_blocks(NKU, NG, ROWS)) fmd_fi
     const int cre = L.mre[0], cim = L.mim[0];
     if (FD_ABLATE(24) || FD_ABLATE(25)) __builtin_amdgcn_s_setprio(0);
     if (FD_ABLATE(26)) __builtin_amdgcn_s_setprio(2);                    // knob: the discriminator phase at raised priority instead
+    // fr[k], fi[k]: the lane's k-th output of its column, at column index CI(k) = 4 k + q (two digits) or 8 (k / 2) + 2 q + k % 2 (one)
     float fr[NG], fi[NG];
+    if constexpr (DIGITS == 2) {
 #pragma unroll
-    for (int gi = 0; gi < NG; ++gi) {
-        if (FD_ABLATE(18)) { fr[gi] = u2f((uint32_t)acc[gi].x & 0x3F800FFFu); fi[gi] = u2f((uint32_t)acc[gi].z & 0x3F800FFFu); continue; }   // ablation: no digit combine / shift / conversion
-        const int re = (int)((uint32_t)acc[gi].x + ((uint32_t)acc[gi].y << 7) + (uint32_t)cre) >> L.shift;     // floor(y / 2^shift)
-        const int im = (int)((uint32_t)acc[gi].z + ((uint32_t)acc[gi].w << 7) + (uint32_t)cim) >> L.shift;
-        fr[gi] = (float)re; fi[gi] = (float)im;
+        for (int gi = 0; gi < NG; ++gi) {
+            if (FD_ABLATE(18)) { fr[gi] = u2f((uint32_t)acc[gi].x & 0x3F800FFFu); fi[gi] = u2f((uint32_t)acc[gi].z & 0x3F800FFFu); continue; }   // ablation: no digit combine / shift / conversion
+            const int re = (int)((uint32_t)acc[gi].x + ((uint32_t)acc[gi].y << 7) + (uint32_t)cre) >> L.shift;     // floor(y / 2^shift)
+            const int im = (int)((uint32_t)acc[gi].z + ((uint32_t)acc[gi].w << 7) + (uint32_t)cim) >> L.shift;
+            fr[gi] = (float)re; fi[gi] = (float)im;
+        }
+    } else {
+#pragma unroll
+        for (int g = 0; g < NA; ++g) {                       // (re, im) of two outputs per accumulator: nothing to combine
+            fr[2 * g] = (float)((int)((uint32_t)acc[g].x + (uint32_t)cre) >> L.shift);
+            fi[2 * g] = (float)((int)((uint32_t)acc[g].y + (uint32_t)cim) >> L.shift);
+            fr[2 * g + 1] = (float)((int)((uint32_t)acc[g].z + (uint32_t)cre) >> L.shift);
+            fi[2 * g + 1] = (float)((int)((uint32_t)acc[g].w + (uint32_t)cim) >> L.shift);
+        }
     }
     if (last) {                                              // block-uniform, one tile per channel: the output that becomes demod_pre
-        const int dl = (int)no - 1 - (int)(tcol + q);        // (tiles overlap by one output: two lanes may hold it, with the same value)
-        if (dl >= 0 && (dl & 3) == 0 && (dl >> 2) < (q < 2u ? NG : NG - 1)) {
+        if constexpr (DIGITS == 2) {
+            const int dl = (int)no - 1 - (int)(tcol + q);    // (tiles overlap by one output: two lanes may hold it, with the same value)
+            if (dl >= 0 && (dl & 3) == 0 && (dl >> 2) < (q < 2u ? NG : NG - 1)) {
 #pragma unroll
-            for (int gi = 0; gi < NG; ++gi)
-                if ((dl >> 2) == gi) { tail[0] = (int)fr[gi]; tail[1] = (int)fi[gi]; }
+                for (int gi = 0; gi < NG; ++gi)
+                    if ((dl >> 2) == gi) { tail[0] = (int)fr[gi]; tail[1] = (int)fi[gi]; }
+            }
+        } else {
+            const int dlc = (int)no - 1 - (int)tcol;         // the tile's last output as a column index of this lane's column
+#pragma unroll
+            for (int k = 0; k < NG; ++k) {
+                const int ci = 8 * (k >> 1) + 2 * (int)q + (k & 1);
+                if (ci == dlc && ci < PC) { tail[0] = (int)fr[k]; tail[1] = (int)fi[k]; }
+            }
         }
     }
     // predecessors: 16 lanes down (q - 1, same column); lane (j, 0) takes the previous register of lane (j, 3), and for its
     // first output the last output of column j - 1 (lane (j - 1, 1), register NG - 1: PC - 1 = 4 (NG - 1) + 1)
     const int down = (int)(((lane + 48u) & 63u) << 2);       // byte address of lane - 16 (mod 64)
     const int left = (int)((16u + ((j + 15u) & 15u)) << 2);  // byte address of lane (j - 1, 1)
-    float pr[NG], pi[NG];
+    // (one digit: only the lane's EVEN outputs have their predecessor in another lane -- the odd output of the same accumulator 16
+    //  lanes down; column j - 1's last output, index PC - 1 = 8 (NG / 2 - 1) + 2 * 2 + 1, is lane (j - 1, 2)'s last one)
+    const int left1 = (int)((32u + ((j + 15u) & 15u)) << 2);
+    float pr[NA], pi[NA];
 #pragma unroll
-    for (int gi = 0; gi < NG; ++gi) {
-        if (FD_ABLATE(19)) { pr[gi] = fi[gi]; pi[gi] = fr[gi]; continue; }                  // ablation: no predecessor moves
-        pr[gi] = u2f((uint32_t)__builtin_amdgcn_ds_bpermute(down, (int)f2u(fr[gi])));
-        pi[gi] = u2f((uint32_t)__builtin_amdgcn_ds_bpermute(down, (int)f2u(fi[gi])));
+    for (int gi = 0; gi < NA; ++gi) {
+        const int src = DIGITS == 1 ? 2 * gi + 1 : gi;
+        if (FD_ABLATE(19)) { pr[gi] = fi[src]; pi[gi] = fr[src]; continue; }                // ablation: no predecessor moves
+        pr[gi] = u2f((uint32_t)__builtin_amdgcn_ds_bpermute(down, (int)f2u(fr[src])));
+        pi[gi] = u2f((uint32_t)__builtin_amdgcn_ds_bpermute(down, (int)f2u(fi[src])));
     }
-    const float xr = FD_ABLATE(19) ? fi[0] : u2f((uint32_t)__builtin_amdgcn_ds_bpermute(left, (int)f2u(fr[NG - 1])));
-    const float xi = FD_ABLATE(19) ? fr[0] : u2f((uint32_t)__builtin_amdgcn_ds_bpermute(left, (int)f2u(fi[NG - 1])));
+    const float xr = FD_ABLATE(19) ? fi[0] : u2f((uint32_t)__builtin_amdgcn_ds_bpermute(DIGITS == 1 ? left1 : left, (int)f2u(fr[NG - 1])));
+    const float xi = FD_ABLATE(19) ? fr[0] : u2f((uint32_t)__builtin_amdgcn_ds_bpermute(DIGITS == 1 ? left1 : left, (int)f2u(fi[NG - 1])));
     const bool q0 = q == 0u;
     // (every lane takes part in every move: ds_bpermute returns 0 for a source lane that is masked off, so the row-0 lanes
     //  cannot fetch their previous-register values under an EXEC mask of their own -- they select instead)
     // ---- fm_demod (:355-367) per output, summed per audio group (:408-417) -------------------------------------------
     const uint32_t tmin = jfirst < 0 ? 0u : 1u;              // tile output 0 is only a predecessor (except at the call start)
-    const uint32_t t_first = tcol + q;                       // the lane's first tile output; sample index m = o0 + t
+    const uint32_t t_first = tcol + (DIGITS == 1 ? 2u * q : q);   // the lane's first tile output; sample index m = o0 + t
     // audio group of the lane's first output and that group's last sample
     const int dm = (int)(o0 + t_first) - jA;                 // >= -1
     const uint32_t kq = (uint32_t)fmd_sdiv_magic((int)(x0 + (uint32_t)(dm > 0 ? dm : 0) * r.sr), L.magic_fr);
@@ -623,8 +656,16 @@ __global__ void __launch_bounds__(kThreads, fd_reg_blocks(NKU, NG, ROWS)) fmd_fi
     bool any_guard = false;
 #pragma unroll
     for (int gi = 0; gi < NG; ++gi) {
-        const float br = q0 ? (gi == 0 ? xr : pr[gi - 1]) : pr[gi];
-        const float bi = q0 ? (gi == 0 ? xi : pi[gi - 1]) : pi[gi];
+        float br, bi;
+        if constexpr (DIGITS == 2) {
+            br = q0 ? (gi == 0 ? xr : pr[gi - 1]) : pr[gi];
+            bi = q0 ? (gi == 0 ? xi : pi[gi - 1]) : pi[gi];
+        } else if (gi & 1) {                                 // the odd output of an accumulator: its predecessor is the lane's own even one
+            br = fr[gi - 1]; bi = fi[gi - 1];
+        } else {
+            br = q0 ? (gi == 0 ? xr : pr[gi / 2 - 1]) : pr[gi / 2];
+            bi = q0 ? (gi == 0 ? xi : pi[gi / 2 - 1]) : pi[gi / 2];
+        }
         int d = FD_ABLATE(20) ? (int)(f2u(fr[gi]) ^ f2u(bi)) + (int)f2u(br) : disc_f32_c(fr[gi], fi[gi], br, bi);   // (:362); the value fits i16, `as i16` changes nothing (ablation 20: no discriminator)
         if (gi == 0 && jfirst < 0 && tid == 0) {             // the first sample of the call takes the f64 path (:359) against demod_pre
             fmd_mul_conj((int)fr[0], (int)fi[0], st.demod_pre_re, st.demod_pre_im, cr0, ci0);
@@ -637,9 +678,18 @@ __global__ void __launch_bounds__(kThreads, fd_reg_blocks(NKU, NG, ROWS)) fmd_fi
             d = (int)(int16_t)d;
             d_first = d;
         }
-        const int dv = (gi < g_hi && !(gi == 0 && skip0)) ? d : 0;
+        int dv, dlo;
+        if constexpr (DIGITS == 2) {
+            dv = (gi < g_hi && !(gi == 0 && skip0)) ? d : 0;
+            dlo = gi < g_split ? dv : 0;
+        } else {                                             // the lane's outputs are not equally spaced: each by its own column index
+            const int ci = 8 * (gi >> 1) + 2 * (int)q + (gi & 1);
+            const int tt = (int)tcol + ci;                   // tile output index; sample index m = o0 + tt
+            dv = (ci < PC && tt < (int)no && !(gi == 0 && skip0)) ? d : 0;
+            dlo = (int)o0 + tt <= e_lo ? dv : 0;
+        }
         sum_all += dv;
-        sum_lo += gi < g_split ? dv : 0;
+        sum_lo += dlo;
     }
     // (a lane whose outputs are all beyond the tile or not owned adds zeros: harmless)
     if (FD_ABLATE(21)) { if (sum_all == 0x7fffffff) gsum[0] = sum_lo; }                   // ablation: no group sums in LDS
@@ -672,9 +722,31 @@ __global__ void __launch_bounds__(kThreads, fd_reg_blocks(NKU, NG, ROWS)) fmd_fi
     }
 }
 
+template <int NKU, int NG, bool ROWS>
+__global__ void __launch_bounds__(kThreads, fd_reg_blocks(NKU, NG, ROWS)) fmd_firdemod_reg_kernel(const FirDemodLaunch L)
+{
+    fd_reg_body<NKU, NG, ROWS, 2>(L);
+}
+
+// the one-digit form (every |tap| <= 127): see fd_reg_body
+template <int NKU, int NG, bool ROWS>
+__global__ void __launch_bounds__(kThreads, fd_reg_blocks(NKU, NG, ROWS)) fmd_firdemod_reg1_kernel(const FirDemodLaunch L)
+{
+    fd_reg_body<NKU, NG, ROWS, 1>(L);
+}
+
 template <int NKU>
 void launch(const FirDemodLaunch& L, dim3 g, size_t lds, hipStream_t s)
 {
+#define FD_REG1(N) if (L.use_rows) hipLaunchKernelGGL((fmd_firdemod_reg1_kernel<NKU, N, true>), g, dim3(kThreads), lds, s, L); \
+                   else hipLaunchKernelGGL((fmd_firdemod_reg1_kernel<NKU, N, false>), g, dim3(kThreads), lds, s, L)
+    if (L.reg_ng && L.digits == 1u) {                       // (even column parameters only: the host falls back to two digits otherwise)
+        if (L.reg_ng == 4u) { FD_REG1(4); }
+        else if (L.reg_ng == 6u) { FD_REG1(6); }
+        else { FD_REG1(8); }
+        return;
+    }
+#undef FD_REG1
 #define FD_REG(N) if (L.use_rows) hipLaunchKernelGGL((fmd_firdemod_reg_kernel<NKU, N, true>), g, dim3(kThreads), lds, s, L); \
                   else hipLaunchKernelGGL((fmd_firdemod_reg_kernel<NKU, N, false>), g, dim3(kThreads), lds, s, L)
     if (L.reg_ng == 4u) { FD_REG(4); }
@@ -842,6 +914,7 @@ int fd_enqueue(fmd_firdemod* f, const void* d_iq, size_t nbytes, void* d_out, si
     L.dbg = f->dbg;
     fd_lanes(L.fa, r.kt, &L.lg, &L.lg_magic, &L.ch);
     L.reg_ng = f->reg_ng;
+    L.digits = f->plan.digits;
     L.magic_fr = fmd_make_magic(r.fr);
     L.reuse = (f->M == 8u || (f->M == 16u && f->reuse16)) && f->plan.n_pass == 1u && !f->no_reuse ? f->M / 8u : 0u;
     L.f32_disc = f->lp_bound <= 2048u && !f->int_disc ? 1u : 0u;
@@ -988,6 +1061,15 @@ int fmd_firdemod_new(const int16_t* taps, uint32_t n_taps, uint32_t decim, uint3
         // far worse -- the planner then cuts the tile until it fits)
         static const uint32_t budget[13] = {0, 0, 0, 0, 20480, 20480, 26880, 32000, 32000, 32000, 40960, 40960, 53760};
         if (f->reg_ng && !lds_knob) f->lds_budget = budget[f->reg_ng];
+        // an 8-bit filter (every |tap| <= 127) in the register form with an even column parameter: one digit per tap, (re, im) of eight
+        // outputs per operand fragment -- NG / 2 accumulators and 24 instead of 40 matrix instructions per wave at config 4's shape
+        // (fmd_firdemod_reg1_kernel; FMD_FD_DIGITS=2, experiment build: keep two digits for an A/B)
+        bool small = true;
+        for (uint32_t t = 0; t < n_taps; ++t) if (taps[t] > 127 || taps[t] < -127) small = false;
+        if (small && (f->reg_ng == 4u || f->reg_ng == 6u || f->reg_ng == 8u) && fmd_knob_u32("FMD_FD_DIGITS", 0) != 2u) {
+            FmdFirMfmaPlan one;
+            if (fmd_fir_build_mfma(taps, n_taps, decim, one, 1u) && one.n_pass == 1u) f->plan = one;
+        }
     }
     for (uint32_t kt = 1; kt <= 1024; ++kt) {
         if ((uint64_t)r.sr * (kt + 2) >= (1u << 24)) break;
@@ -1230,7 +1312,7 @@ int fmd_firdemod_kernel_name(const fmd_firdemod* f, char* name, size_t cap)
     // the launch had a per-tile table (every call of at most kFdRows tiles: a 2 MiB config-4 buffer has 26) -- so the name is
     // that of the most recent launch; before the first one, of a launch with a table.
     const bool rows = f->last_rows < 0 ? !f->no_rows : f->last_rows != 0;
-    const int n = f->reg_ng ? snprintf(name, cap, "(anonymous namespace)::fmd_firdemod_reg_kernel<%u, %u, %s>", nku, f->reg_ng, rows ? "true" : "false")
+    const int n = f->reg_ng ? snprintf(name, cap, "(anonymous namespace)::fmd_firdemod_reg%s_kernel<%u, %u, %s>", f->plan.digits == 1u ? "1" : "", nku, f->reg_ng, rows ? "true" : "false")
                             : snprintf(name, cap, "(anonymous namespace)::fmd_firdemod_kernel<%u, %u>", nku, reuse ? 1u : 0u);
     return n < 0 || (size_t)n >= cap ? FMD_ERR_CAPACITY : FMD_OK;
 }

@@ -117,9 +117,41 @@ def test_gpu_fused_register_form_variants(fmd, oracle, request, ng):
         assert kn.startswith("(anonymous namespace)::fmd_firdemod_reg_kernel<") == want_reg and (not want_reg or kn.endswith(", %s, true>" % ng)), kn
 
 
-def fused_case(fmd, oracle, T, M, fast, slow, f32_only=False):
+REG1_SHAPES = [(127, 8, 2500000, 48000), (200, 8, 480000, 8000), (64, 8, 768000, 48000), (100, 8, 1200000, 48000), (8, 8, 256000, 8000),
+               (1, 8, 1280000, 32000)]                          # column parameter NG = 8, 8, 4, 6, 8, 8
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("T,M,fast,slow", REG1_SHAPES)
+def test_gpu_fused_register_form_one_digit(fmd, oracle, T, M, fast, slow):
+    """An 8-bit filter (every |tap| <= 127, +-127 among them) in the register form with an even column parameter: one i8 digit per tap,
+    (re, im) of eight outputs per operand fragment, half the accumulators (fmd_firdemod_reg1_kernel).  Same walk as the two-digit test:
+    tiny first calls, many tiles per channel, full scale, state carried over six calls."""
+    kn = fused_case(fmd, oracle, T, M, fast, slow, f32_only=True, taps_max=127)
+    assert kn.startswith("(anonymous namespace)::fmd_firdemod_reg1_kernel<") and kn.endswith(", true>"), kn
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("knobs", [{"FMD_FD_DIGITS": "2"}, {"FMD_FD_REG": "4"}, {"FMD_FD_REG": "6"}, {"FMD_FD_REG": "5"}, {"FMD_FD_ROWS": "0"}])
+def test_gpu_fused_one_digit_variants(fmd, oracle, request, knobs):
+    """8-bit filters with the two-digit form forced, with shorter columns (4 / 6: one digit; 5: odd, so two digits) and without the
+    per-tile table: knobs of the -DFMD_EXPERIMENT build."""
+    from conftest import run_in_exp_child
+    if run_in_exp_child(request, knobs):
+        return
+    for T, M, fast, slow in REG1_SHAPES[:3]:
+        kn = fused_case(fmd, oracle, T, M, fast, slow, f32_only=True, taps_max=127)
+        ng = knobs.get("FMD_FD_REG")
+        one = "FMD_FD_DIGITS" not in knobs and ng != "5" and (ng is None or fast // slow >= 4 * int(ng))
+        assert kn.startswith("(anonymous namespace)::fmd_firdemod_reg1_kernel<") == one, (knobs, kn)
+
+
+def fused_case(fmd, oracle, T, M, fast, slow, f32_only=False, taps_max=2047):
     rng = np.random.default_rng(T * 11 + M)
-    taps = rng.integers(-2047, 2048, T).astype(np.int16)
+    taps = rng.integers(-taps_max, taps_max + 1, T).astype(np.int16)
+    if taps_max < 2047:
+        taps[rng.integers(0, T)] = taps_max
+        taps[rng.integers(0, T)] = -taps_max
     shift = fmd.auto_shift(taps, 16384) + int(rng.integers(0, 6))     # both discriminator forms (|lp| <= 2048: f32)
     if f32_only:
         shift = fmd.auto_shift(taps, 2048) + int(rng.integers(0, 3))

@@ -56,7 +56,7 @@ def firdemod(a):
     builds = [(n_, l_) for n_, l_, _ in parsed]
     envs = [e_ for _, _, e_ in parsed]
     nch, n, T, M, fast, slow = 256, 2 << 20, 127, 8, 2500000, 48000
-    taps = np.random.default_rng(1).integers(-2047, 2048, T).astype(np.int16)
+    taps = np.random.default_rng(1).integers(-a.fir_taps_max, a.fir_taps_max + 1, T).astype(np.int16)
     shift = fmd.auto_shift(taps)
     stream = torch.cuda.current_stream().cuda_stream
     bufs = []
@@ -93,7 +93,7 @@ def firdemod(a):
     for (name, l), h in zip(builds, hs):
         ts = sorted(res[name]); med = ts[len(ts) // 2]
         base = base or med
-        print(json.dumps({"cfg": "config4 fused FIR", "build": name, "ms": [round(t, 4) for t in res[name]], "median_ms": round(med, 4),
+        print(json.dumps({"cfg": "config4 fused FIR, |tap| <= %d" % a.fir_taps_max, "build": name, "ms": [round(t, 4) for t in res[name]], "median_ms": round(med, 4),
                           "frac": round(alg / med / 1e6 / 8000, 4), "vs_first_pct": round(100 * (med / base - 1), 2)}), flush=True)
         l.fmd_firdemod_free(h)
 
