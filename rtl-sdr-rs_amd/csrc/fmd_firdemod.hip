@@ -107,6 +107,7 @@ struct FirDemodLaunch {
     uint32_t f32_disc;         // 1: |lp| <= 2048 (the boxcar's range at downsample 16): the f32 discriminator is exact (fmd_device.h)
     uint32_t reg_ng;           // host only: > 0 selects fmd_firdemod_reg_kernel<NKU, reg_ng> (discriminator out of the matrix-core result registers)
     uint32_t digits;           // host only: tap digits of the A fragments (1: fmd_firdemod_reg1_kernel)
+    uint32_t sparse;           // host only: 1 = `amat` is the 4:2-compressed matrix (fmd_firdemod_regs_kernel / _reg1s_kernel)
     FmdMagic magic_fr;         // fmd_udiv_magic(x, magic_fr) == x / fr for x < 2^24
     FdRow rows[kFdRows];
 };
@@ -438,10 +439,18 @@ constexpr int fd_reg_blocks(int nku, int ng, bool rows)
 // in acc[g] -- fed by NKU + NG - 2 operand fragments (two chunks per accumulator step); the columns, the tiles and everything behind
 // the discriminators are the two-digit form's.  The odd outputs' predecessors are the lane's own even ones; the even ones' sit 16
 // lanes down (lane (j, 3)'s previous accumulator for q = 0, column j - 1's last output -- lane (j - 1, 2) -- for the first).
-template <int NKU, int NG, bool ROWS, int DIGITS>
+// SP: the matrix phase on the 4:2 structured-sparse instruction (v_smfmac_i32_16x16x128_i8: a 128-byte K chunk for the cost of a dense
+// 64-byte one -- 17 against 18 clocks, tools/smfmac_probe.hip).  rotate_90 leaves every re row with bytes 0 / 3 and every im row with
+// bytes 1 / 2 of each stream dword: the tap matrix IS 4:2 sparse, with one fixed pattern per row (fmd_fir_common.h).  Lane (j, q)
+// supplies the 32 stream bytes at 32 q of the chunk as the B operand; an accumulator's chunks are 128 bytes apart, consecutive
+// accumulators 64 (two digits) or 128 (one), so fragment s = AS gi + 2 kc -- in 64-byte units from the column -- serves every
+// (accumulator gi, chunk kc) on that diagonal: (NKU + 1) / 2 instead of NKU matrix instructions per accumulator.
+template <int NKU, int NG, bool ROWS, int DIGITS, bool SP>
 __device__ __forceinline__ void fd_reg_body(const FirDemodLaunch& L)
 {
     static_assert(DIGITS == 2 || (DIGITS == 1 && NG % 2 == 0), "one digit: two outputs per accumulator row group");
+    constexpr int NKS = (NKU + 1) / 2;                       // 128-byte chunks of the sparse form
+    constexpr int NAF = SP ? NKS : NKU;                      // tap fragments a lane holds
     constexpr int PC = 4 * NG - 2;                           // outputs per column
     constexpr int WSTEP = 16 * PC - 1;                       // tile outputs from one wave's first column to the next wave's
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
@@ -495,9 +504,9 @@ __device__ __forceinline__ void fd_reg_body(const FirDemodLaunch& L)
     // the tap fragments FIRST (five small L2-resident loads per lane: behind the DMAs they queue behind 30 KB of staging
     // traffic and every wave waits for them at the barrier -- measured on the stand-alone FIR kernel: 2 % per call)
     const gq amat = (gq)(uintptr_t)H.amat + lane;
-    fd_i4 A[NKU];
+    fd_i4 A[NAF];
 #pragma unroll
-    for (int k = 0; k < NKU; ++k) A[k] = amat[k * 64];
+    for (int k = 0; k < NAF; ++k) A[k] = amat[k * 64];
     if (whole) {
         const unsigned char* src = reinterpret_cast<const unsigned char*>(iq_w + (uint64_t)c * H.stride_w + (w0 - H.Hw)) + 16u * tid;
         unsigned char* dst = reinterpret_cast<unsigned char*>(lds) + 1024u * wave;
@@ -556,7 +565,24 @@ __device__ __forceinline__ void fd_reg_body(const FirDemodLaunch& L)
     fd_i4 acc[NA];
 #pragma unroll
     for (int gi = 0; gi < NA; ++gi) acc[gi] = fd_i4{0, 0, 0, 0};     // (all zero: the first matrix instruction takes the inline constant, no v_mov)
-    {
+    if constexpr (SP) {
+        typedef int fd_i8 __attribute__((ext_vector_type(8)));
+        const uint8_t* col = reinterpret_cast<const uint8_t*>(lds) + 16u * tcol + 32u * q;   // the lane's 32 bytes of a 128-byte chunk
+        // (re rows keep bytes 0 and 3 of every dword: index pairs (0, 3); im rows bytes 1 and 2: (1, 2))
+        const uint32_t row = lane & 15u;
+        const int idx = ((DIGITS == 1 ? row & 1u : (row >> 1) & 1u) != 0u) ? (int)0x99999999u : (int)0xCCCCCCCCu;
+#pragma unroll
+        for (int s = 0; s <= AS * (NA - 1) + 2 * (NKS - 1); s += (AS == 2 ? 2 : 1)) {
+            if (FD_ABLATE(16)) continue;
+            const fd_i4 b0 = *reinterpret_cast<const fd_i4*>(col + 64 * s) ^ (int)0x80808080;          // u8 -> s8
+            const fd_i4 b1 = *reinterpret_cast<const fd_i4*>(col + 64 * s + 16) ^ (int)0x80808080;
+            const fd_i8 B = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+#pragma unroll
+            for (int kc = 0; kc < NKS; ++kc)
+                if ((s - 2 * kc) >= 0 && (s - 2 * kc) % AS == 0 && (s - 2 * kc) / AS < NA)
+                    acc[(s - 2 * kc) / AS] = __builtin_amdgcn_smfmac_i32_16x16x128_i8(A[kc], B, acc[(s - 2 * kc) / AS], idx, 0, 0);
+        }
+    } else {
         const uint8_t* col = reinterpret_cast<const uint8_t*>(lds) + 16u * tcol + 16u * q;   // decimate 8: 16 bytes per output
 #pragma unroll
         for (int sft = 0; sft < NKU + AS * (NA - 1); ++sft) {
@@ -725,28 +751,59 @@ __device__ __forceinline__ void fd_reg_body(const FirDemodLaunch& L)
 template <int NKU, int NG, bool ROWS>
 __global__ void __launch_bounds__(kThreads, fd_reg_blocks(NKU, NG, ROWS)) fmd_firdemod_reg_kernel(const FirDemodLaunch L)
 {
-    fd_reg_body<NKU, NG, ROWS, 2>(L);
+    fd_reg_body<NKU, NG, ROWS, 2, false>(L);
 }
 
 // the one-digit form (every |tap| <= 127): see fd_reg_body
 template <int NKU, int NG, bool ROWS>
 __global__ void __launch_bounds__(kThreads, fd_reg_blocks(NKU, NG, ROWS)) fmd_firdemod_reg1_kernel(const FirDemodLaunch L)
 {
-    fd_reg_body<NKU, NG, ROWS, 1>(L);
+    fd_reg_body<NKU, NG, ROWS, 1, false>(L);
+}
+
+// both with the matrix phase on the 4:2 sparse instruction (NKU stays the DENSE chunk count of the shape: the kernel derives its own)
+template <int NKU, int NG, bool ROWS>
+__global__ void __launch_bounds__(kThreads, fd_reg_blocks(NKU, NG, ROWS)) fmd_firdemod_regs_kernel(const FirDemodLaunch L)
+{
+    fd_reg_body<NKU, NG, ROWS, 2, true>(L);
+}
+
+template <int NKU, int NG, bool ROWS>
+__global__ void __launch_bounds__(kThreads, fd_reg_blocks(NKU, NG, ROWS)) fmd_firdemod_reg1s_kernel(const FirDemodLaunch L)
+{
+    fd_reg_body<NKU, NG, ROWS, 1, true>(L);
 }
 
 template <int NKU>
 void launch(const FirDemodLaunch& L, dim3 g, size_t lds, hipStream_t s)
 {
-#define FD_REG1(N) if (L.use_rows) hipLaunchKernelGGL((fmd_firdemod_reg1_kernel<NKU, N, true>), g, dim3(kThreads), lds, s, L); \
-                   else hipLaunchKernelGGL((fmd_firdemod_reg1_kernel<NKU, N, false>), g, dim3(kThreads), lds, s, L)
+#define FD_REGX(K, N) if (L.use_rows) hipLaunchKernelGGL((K<NKU, N, true>), g, dim3(kThreads), lds, s, L); \
+                      else hipLaunchKernelGGL((K<NKU, N, false>), g, dim3(kThreads), lds, s, L)
     if (L.reg_ng && L.digits == 1u) {                       // (even column parameters only: the host falls back to two digits otherwise)
-        if (L.reg_ng == 4u) { FD_REG1(4); }
-        else if (L.reg_ng == 6u) { FD_REG1(6); }
-        else { FD_REG1(8); }
+#ifdef FMD_EXPERIMENT
+        if (!L.sparse) {
+            if (L.reg_ng == 4u) { FD_REGX(fmd_firdemod_reg1_kernel, 4); }
+            else if (L.reg_ng == 6u) { FD_REGX(fmd_firdemod_reg1_kernel, 6); }
+            else { FD_REGX(fmd_firdemod_reg1_kernel, 8); }
+            return;
+        }
+#endif
+        if (L.reg_ng == 4u) { FD_REGX(fmd_firdemod_reg1s_kernel, 4); }
+        else if (L.reg_ng == 6u) { FD_REGX(fmd_firdemod_reg1s_kernel, 6); }
+        else { FD_REGX(fmd_firdemod_reg1s_kernel, 8); }
         return;
     }
-#undef FD_REG1
+#ifdef FMD_EXPERIMENT
+    if (L.reg_ng && L.sparse && L.reg_ng <= 8u) {
+        if (L.reg_ng == 4u) { FD_REGX(fmd_firdemod_regs_kernel, 4); }
+        else if (L.reg_ng == 5u) { FD_REGX(fmd_firdemod_regs_kernel, 5); }
+        else if (L.reg_ng == 6u) { FD_REGX(fmd_firdemod_regs_kernel, 6); }
+        else if (L.reg_ng == 7u) { FD_REGX(fmd_firdemod_regs_kernel, 7); }
+        else { FD_REGX(fmd_firdemod_regs_kernel, 8); }
+        return;
+    }
+#endif
+#undef FD_REGX
 #define FD_REG(N) if (L.use_rows) hipLaunchKernelGGL((fmd_firdemod_reg_kernel<NKU, N, true>), g, dim3(kThreads), lds, s, L); \
                   else hipLaunchKernelGGL((fmd_firdemod_reg_kernel<NKU, N, false>), g, dim3(kThreads), lds, s, L)
     if (L.reg_ng == 4u) { FD_REG(4); }
@@ -811,6 +868,7 @@ struct fmd_firdemod {
     bool no_reuse = false, int_disc = false;              // FMD_FD_NOREUSE / FMD_FD_INT_DISC: plain MFMA mapping / integer discriminator (A/B), read at creation
     int last_rows = -1;                                   // the most recent launch's `use_rows` (-1: none yet) -- part of the kernel's name
     uint32_t reg_ng = 0;                                  // > 0: fmd_firdemod_reg_kernel with this many output groups per column (decimate 8, f32 discriminator)
+    bool sparse = false;                                  // the register form's matrix phase on v_smfmac (d_amat holds the compressed matrix)
     size_t lds_budget = 20480;                            // LDS per tile (8 tiles per CU); FMD_FD_LDS (tuning)
     hipStream_t stream = nullptr;
     uint8_t* d_iq = nullptr; size_t d_iq_cap = 0;
@@ -859,7 +917,7 @@ bool fd_sizes(const fmd_firdemod* f, uint32_t kt, uint32_t* lp_cap, uint32_t* ra
         const uint64_t staged = (((((uint64_t)(cap - 1) * half_M + f->NP + 3) / 4) + 3) & ~(uint64_t)3) * 16;
         const uint32_t pc = 4u * f->reg_ng - 2u;
         if (cap > 64u * pc - 3u) return false;
-        const uint64_t touched = 16ull * (63u * pc - 3u) + 64ull * (f->plan.nku + f->reg_ng - 1u);
+        const uint64_t touched = 16ull * (63u * pc - 3u) + 64ull * (f->plan.nku + f->reg_ng);   // (the sparse form's 128-byte chunks: one 64-byte unit further for an odd chunk count)
         const uint64_t raw = ((staged > touched ? staged : touched) + 15) & ~(uint64_t)15;
         const uint64_t total = raw + 12ull * (kt + 2) + 8 + 16;               // + group sums, the (first, last) table, the tail sample
         if (total > 60 * 1024) return false;
@@ -915,6 +973,7 @@ int fd_enqueue(fmd_firdemod* f, const void* d_iq, size_t nbytes, void* d_out, si
     fd_lanes(L.fa, r.kt, &L.lg, &L.lg_magic, &L.ch);
     L.reg_ng = f->reg_ng;
     L.digits = f->plan.digits;
+    L.sparse = f->sparse ? 1u : 0u;
     L.magic_fr = fmd_make_magic(r.fr);
     L.reuse = (f->M == 8u || (f->M == 16u && f->reuse16)) && f->plan.n_pass == 1u && !f->no_reuse ? f->M / 8u : 0u;
     L.f32_disc = f->lp_bound <= 2048u && !f->int_disc ? 1u : 0u;
@@ -1070,6 +1129,15 @@ int fmd_firdemod_new(const int16_t* taps, uint32_t n_taps, uint32_t decim, uint3
             FmdFirMfmaPlan one;
             if (fmd_fir_build_mfma(taps, n_taps, decim, one, 1u) && one.n_pass == 1u) f->plan = one;
         }
+        // The ONE-digit form's matrix phase runs on the 4:2 sparse matrix instruction: 12 instead of 24 matrix instructions per wave at
+        // config 4's shape with the same 12 operand reads (-4.3 %).  The two-digit form's accumulators are 64 bytes apart, half a sparse
+        // chunk, so its fragments double (24 reads for 24 instead of 40 matrix instructions): +4.5 % -- it keeps the dense instruction.
+        // FMD_FD_SPARSE (experiment build): 0 / 1 = dense / sparse for both.
+#ifdef FMD_EXPERIMENT
+        f->sparse = f->reg_ng != 0u && f->reg_ng <= 8u && fmd_knob_u32("FMD_FD_SPARSE", f->plan.digits == 1u ? 1u : 0u) != 0u;
+#else
+        f->sparse = f->reg_ng != 0u && f->plan.digits == 1u;
+#endif
     }
     for (uint32_t kt = 1; kt <= 1024; ++kt) {
         if ((uint64_t)r.sr * (kt + 2) >= (1u << 24)) break;
@@ -1088,8 +1156,9 @@ int fmd_firdemod_new(const int16_t* taps, uint32_t n_taps, uint32_t decim, uint3
     auto fail = [&](const char* what) { fmd_internal_set_err(what); fmd_firdemod_free(f); return FMD_ERR_HIP; };
     FmdDeviceGuard guard(device);
     if (guard.error() != hipSuccess) return fail("hipSetDevice");
-    if (hipMalloc(&f->d_amat, f->plan.amat.size() * 4) != hipSuccess) return fail("hipMalloc(tap matrix)");
-    if (hipMemcpy(f->d_amat, f->plan.amat.data(), f->plan.amat.size() * 4, hipMemcpyHostToDevice) != hipSuccess) return fail("hipMemcpy(tap matrix)");
+    const std::vector<uint32_t>& amat = f->sparse ? f->plan.amat_s : f->plan.amat;
+    if (hipMalloc(&f->d_amat, amat.size() * 4) != hipSuccess) return fail("hipMalloc(tap matrix)");
+    if (hipMemcpy(f->d_amat, amat.data(), amat.size() * 4, hipMemcpyHostToDevice) != hipSuccess) return fail("hipMemcpy(tap matrix)");
     const size_t hb = (size_t)f->C * (f->Hw ? f->Hw : 1) * 4, sb = (size_t)f->C * sizeof(FmdChanState);
     for (int i = 0; i < 2; ++i) {
         if (hipMalloc(&f->d_hist[i], hb) != hipSuccess || hipMemset(f->d_hist[i], 0, hb) != hipSuccess) return fail("hipMalloc(history)");
@@ -1312,7 +1381,7 @@ int fmd_firdemod_kernel_name(const fmd_firdemod* f, char* name, size_t cap)
     // the launch had a per-tile table (every call of at most kFdRows tiles: a 2 MiB config-4 buffer has 26) -- so the name is
     // that of the most recent launch; before the first one, of a launch with a table.
     const bool rows = f->last_rows < 0 ? !f->no_rows : f->last_rows != 0;
-    const int n = f->reg_ng ? snprintf(name, cap, "(anonymous namespace)::fmd_firdemod_reg%s_kernel<%u, %u, %s>", f->plan.digits == 1u ? "1" : "", nku, f->reg_ng, rows ? "true" : "false")
+    const int n = f->reg_ng ? snprintf(name, cap, "(anonymous namespace)::fmd_firdemod_reg%s%s_kernel<%u, %u, %s>", f->plan.digits == 1u ? "1" : "", f->sparse ? "s" : "", nku, f->reg_ng, rows ? "true" : "false")
                             : snprintf(name, cap, "(anonymous namespace)::fmd_firdemod_kernel<%u, %u>", nku, reuse ? 1u : 0u);
     return n < 0 || (size_t)n >= cap ? FMD_ERR_CAPACITY : FMD_OK;
 }

@@ -125,25 +125,36 @@ REG1_SHAPES = [(127, 8, 2500000, 48000), (200, 8, 480000, 8000), (64, 8, 768000,
 @pytest.mark.parametrize("T,M,fast,slow", REG1_SHAPES)
 def test_gpu_fused_register_form_one_digit(fmd, oracle, T, M, fast, slow):
     """An 8-bit filter (every |tap| <= 127, +-127 among them) in the register form with an even column parameter: one i8 digit per tap,
-    (re, im) of eight outputs per operand fragment, half the accumulators (fmd_firdemod_reg1_kernel).  Same walk as the two-digit test:
+    (re, im) of eight outputs per operand fragment, half the accumulators, the matrix phase on the 4:2 sparse instruction
+    (fmd_firdemod_reg1s_kernel).  Same walk as the two-digit test:
     tiny first calls, many tiles per channel, full scale, state carried over six calls."""
     kn = fused_case(fmd, oracle, T, M, fast, slow, f32_only=True, taps_max=127)
-    assert kn.startswith("(anonymous namespace)::fmd_firdemod_reg1_kernel<") and kn.endswith(", true>"), kn
+    assert kn.startswith("(anonymous namespace)::fmd_firdemod_reg1s_kernel<") and kn.endswith(", true>"), kn
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("knobs", [{"FMD_FD_DIGITS": "2"}, {"FMD_FD_REG": "4"}, {"FMD_FD_REG": "6"}, {"FMD_FD_REG": "5"}, {"FMD_FD_ROWS": "0"}])
+@pytest.mark.parametrize("knobs", [{"FMD_FD_DIGITS": "2"}, {"FMD_FD_REG": "4"}, {"FMD_FD_REG": "6"}, {"FMD_FD_REG": "5"}, {"FMD_FD_ROWS": "0"},
+                                   {"FMD_FD_SPARSE": "0"}, {"FMD_FD_SPARSE": "0", "FMD_FD_REG": "6"}, {"FMD_FD_SPARSE": "1"},
+                                   {"FMD_FD_SPARSE": "1", "FMD_FD_REG": "5"}])
 def test_gpu_fused_one_digit_variants(fmd, oracle, request, knobs):
-    """8-bit filters with the two-digit form forced, with shorter columns (4 / 6: one digit; 5: odd, so two digits) and without the
-    per-tile table: knobs of the -DFMD_EXPERIMENT build."""
+    """8-bit filters with the two-digit form forced, with shorter columns (4 / 6: one digit; 5: odd, so two digits), without the
+    per-tile table, and with the matrix phase on the dense / the sparse instruction for BOTH digit forms (FMD_FD_SPARSE = 0 / 1; the
+    shipped rule is sparse for one digit, dense for two): knobs of the -DFMD_EXPERIMENT build.  The 12-bit filters run beside them."""
     from conftest import run_in_exp_child
     if run_in_exp_child(request, knobs):
         return
     for T, M, fast, slow in REG1_SHAPES[:3]:
+        ng, sp = knobs.get("FMD_FD_REG"), knobs.get("FMD_FD_SPARSE")
+        want_reg = ng is None or fast // slow >= 4 * int(ng)
+        one = "FMD_FD_DIGITS" not in knobs and ng != "5" and want_reg
         kn = fused_case(fmd, oracle, T, M, fast, slow, f32_only=True, taps_max=127)
-        ng = knobs.get("FMD_FD_REG")
-        one = "FMD_FD_DIGITS" not in knobs and ng != "5" and (ng is None or fast // slow >= 4 * int(ng))
-        assert kn.startswith("(anonymous namespace)::fmd_firdemod_reg1_kernel<") == one, (knobs, kn)
+        kn2 = fused_case(fmd, oracle, T, M, fast, slow, f32_only=True)                       # 12-bit taps: two digits
+        pre = "(anonymous namespace)::fmd_firdemod_"
+        if not want_reg:
+            assert kn.startswith(pre + "kernel<") and kn2.startswith(pre + "kernel<"), (knobs, kn, kn2)
+            continue
+        assert kn.startswith(pre + ("reg1" if one else "reg") + ("s" if (sp == "1" or (sp is None and one)) else "") + "_kernel<"), (knobs, kn)
+        assert kn2.startswith(pre + "reg" + ("s" if sp == "1" else "") + "_kernel<"), (knobs, kn2)
 
 
 def fused_case(fmd, oracle, T, M, fast, slow, f32_only=False, taps_max=2047):

@@ -172,7 +172,7 @@ def test_round_loops_have_no_vcc_selects(code_objects):
 def test_fused_fir_kernels_name_the_conversion(code_objects):
     n_kern = 0
     for n, k in code_objects.items():
-        m = re.search(r"fmd_firdemod_reg1?_kernel<(\d+), (\d+), (true|false)>", n)
+        m = re.search(r"fmd_firdemod_reg1?s?_kernel<(\d+), (\d+), (true|false)>", n)
         if not m:
             continue
         ng = int(m.group(2))
