@@ -76,7 +76,7 @@ int main()
     printf("A: stored byte (lane L, byte s), every index field = code -> row m (from the C layout lane (n, q): rows 4q..4q+3), K position k*\n");
     for (int e = 0; e < NA; ++e) {
         const int L = e / 64, s = (e / 4) % 16, code = e % 4;
-        if (!(L < 2 || L == 16 || L == 17 || L == 33 || L == 63) ) continue;       // (a readable sample; the rule is checked below)
+        if (!((L == 0 || L == 16 || L == 33 || L == 63) && (s < 3 || s == 8 || s == 9 || s == 15) && (code == 0 || code == 3))) continue;   // (a readable sample; the rule is checked below)
         // all 16 columns should agree: take column 0 = lanes with (l & 15) == 0
         int m = -1, k = -1, n_nz = 0;
         for (int l = 0; l < 64; ++l)
@@ -86,11 +86,13 @@ int main()
             }
         printf("L=%2d s=%2d code=%d -> nonzeros=%3d row=%2d k=%3d\n", L, s, code, n_nz, m, k);
     }
-    // rule check: row = L & 15, k = 32 (L >> 4) + 4 (s / 2) + code ?
+    // the rule the first run of this probe showed (a dense-like "k = 32 q + ..." guess had 49152 mismatches): lane (row, q) holds 16
+    // stored bytes; bytes 8 h ... 8 h + 7 cover the 16 dense K positions from 64 (q & 1) + 16 (q >> 1) + 32 h, two per group of four
     int bad = 0;
     for (int e = 0; e < NA; ++e) {
         const int L = e / 64, s = (e / 4) % 16, code = e % 4;
-        const int want_m = L & 15, want_k = 32 * (L >> 4) + 4 * (s / 2) + code;
+        const int q = L >> 4;
+        const int want_m = L & 15, want_k = 64 * (q & 1) + 16 * (q >> 1) + 32 * (s >> 3) + 4 * ((s & 7) >> 1) + code;
         for (int l = 0; l < 64; ++l)
             for (int r = 0; r < 4; ++r) {
                 const int v = hc[((size_t)e * 64 + l) * 4 + r];
@@ -99,7 +101,7 @@ int main()
                 if (v != want) ++bad;
             }
     }
-    printf("rule A (row = L & 15, k = 32 (L >> 4) + 4 (s / 2) + code, C lane (n, q) reg r = row 4 q + r col n): %d mismatches\n", bad);
+    printf("rule A (A lane (row, q) stored byte s, index field = code -> row = L & 15, k = 64 (q & 1) + 16 (q >> 1) + 32 (s >> 3) + 4 ((s & 7) >> 1) + code; C lane (n, q) reg r = row 4 q + r col n): %d mismatches\n", bad);
 
     // ---- experiment B: A = 1 at positions {0, 3} of every group (stored pair (first, second) with indices (0, 3)), one B byte = 1 ------
     const int NB = 64 * 32;
