@@ -448,9 +448,13 @@ constexpr int fd_reg_blocks(int nku, int ng, bool rows)
 template <int NKU, int NG, bool ROWS, int DIGITS, bool SP>
 __device__ __forceinline__ void fd_reg_body(const FirDemodLaunch& L)
 {
-    static_assert(DIGITS == 2 || (DIGITS == 1 && NG % 2 == 0), "one digit: two outputs per accumulator row group");
+    // GEO8: a column is EIGHT outputs per accumulator step -- the one-digit forms, and the two-digit sparse form, which keeps re and
+    // im in accumulators of their own (rows = (lo, hi) of eight outputs): its accumulators then sit a whole sparse chunk apart like
+    // the one-digit form's, 12 fragment reads for 24 matrix instructions per wave where the interleaved rows would need 24 reads.
+    constexpr bool GEO8 = DIGITS == 1 || SP;
+    static_assert(!GEO8 || NG % 2 == 0, "eight outputs per accumulator step: two outputs per lane and accumulator");
     constexpr int NKS = (NKU + 1) / 2;                       // 128-byte chunks of the sparse form
-    constexpr int NAF = SP ? NKS : NKU;                      // tap fragments a lane holds
+    constexpr int NAF = SP ? (DIGITS == 2 ? 2 * NKS : NKS) : NKU;   // tap fragments a lane holds (two digits, sparse: re set, then im set)
     constexpr int PC = 4 * NG - 2;                           // outputs per column
     constexpr int WSTEP = 16 * PC - 1;                       // tile outputs from one wave's first column to the next wave's
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
@@ -560,11 +564,12 @@ __device__ __forceinline__ void fd_reg_body(const FirDemodLaunch& L)
     if (FD_ABLATE(27)) __builtin_amdgcn_s_sleep(16);                     // pacing probes: 1024 clocks behind the staging barrier ...
     if (FD_ABLATE(24)) __builtin_amdgcn_s_setprio(3);                    // knob: the matrix phase's dependent LDS -> xor -> MFMA chains at raised priority
     if (FD_ABLATE(25)) __builtin_amdgcn_s_setprio(1);
-    constexpr int NA = DIGITS == 1 ? NG / 2 : NG;            // accumulators per lane
-    constexpr int AS = DIGITS == 1 ? 2 : 1;                  // K-chunks from one accumulator's column to the next (8 / 4 outputs of 16 bytes)
-    fd_i4 acc[NA];
+    constexpr int NA = GEO8 ? NG / 2 : NG;                   // accumulators per lane (and component, in the two-digit sparse form)
+    constexpr int AS = GEO8 ? 2 : 1;                         // K-chunks from one accumulator's column to the next (8 / 4 outputs of 16 bytes)
+    constexpr int NACC = (SP && DIGITS == 2) ? 2 * NA : NA;  // (two digits, sparse: acc[0 .. NA) re, acc[NA .. 2 NA) im)
+    fd_i4 acc[NACC];
 #pragma unroll
-    for (int gi = 0; gi < NA; ++gi) acc[gi] = fd_i4{0, 0, 0, 0};     // (all zero: the first matrix instruction takes the inline constant, no v_mov)
+    for (int gi = 0; gi < NACC; ++gi) acc[gi] = fd_i4{0, 0, 0, 0};   // (all zero: the first matrix instruction takes the inline constant, no v_mov)
     if constexpr (SP) {
         typedef int fd_i8 __attribute__((ext_vector_type(8)));
         const uint8_t* col = reinterpret_cast<const uint8_t*>(lds) + 16u * tcol + 32u * q;   // the lane's 32 bytes of a 128-byte chunk
@@ -579,8 +584,16 @@ __device__ __forceinline__ void fd_reg_body(const FirDemodLaunch& L)
             const fd_i8 B = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
 #pragma unroll
             for (int kc = 0; kc < NKS; ++kc)
-                if ((s - 2 * kc) >= 0 && (s - 2 * kc) % AS == 0 && (s - 2 * kc) / AS < NA)
-                    acc[(s - 2 * kc) / AS] = __builtin_amdgcn_smfmac_i32_16x16x128_i8(A[kc], B, acc[(s - 2 * kc) / AS], idx, 0, 0);
+                if ((s - 2 * kc) >= 0 && (s - 2 * kc) % AS == 0 && (s - 2 * kc) / AS < NA) {
+                    constexpr int dummy = 0; (void)dummy;
+                    const int g = (s - 2 * kc) / AS;
+                    if constexpr (DIGITS == 2) {             // one fragment, both components: every re row keeps bytes 0 / 3, every im row 1 / 2
+                        acc[g] = __builtin_amdgcn_smfmac_i32_16x16x128_i8(A[kc], B, acc[g], (int)0xCCCCCCCCu, 0, 0);
+                        acc[NA + g] = __builtin_amdgcn_smfmac_i32_16x16x128_i8(A[NKS + kc], B, acc[NA + g], (int)0x99999999u, 0, 0);
+                    } else {
+                        acc[g] = __builtin_amdgcn_smfmac_i32_16x16x128_i8(A[kc], B, acc[g], idx, 0, 0);
+                    }
+                }
         }
     } else {
         const uint8_t* col = reinterpret_cast<const uint8_t*>(lds) + 16u * tcol + 16u * q;   // decimate 8: 16 bytes per output
@@ -607,7 +620,15 @@ __device__ __forceinline__ void fd_reg_body(const FirDemodLaunch& L)
     if (FD_ABLATE(26)) __builtin_amdgcn_s_setprio(2);                    // knob: the discriminator phase at raised priority instead
     // fr[k], fi[k]: the lane's k-th output of its column, at column index CI(k) = 4 k + q (two digits) or 8 (k / 2) + 2 q + k % 2 (one)
     float fr[NG], fi[NG];
-    if constexpr (DIGITS == 2) {
+    if constexpr (SP && DIGITS == 2) {
+#pragma unroll
+        for (int g = 0; g < NA; ++g) {                       // (lo, hi) of two outputs per accumulator, re and im in accumulators of their own
+            fr[2 * g] = (float)((int)((uint32_t)acc[g].x + ((uint32_t)acc[g].y << 7) + (uint32_t)cre) >> L.shift);
+            fr[2 * g + 1] = (float)((int)((uint32_t)acc[g].z + ((uint32_t)acc[g].w << 7) + (uint32_t)cre) >> L.shift);
+            fi[2 * g] = (float)((int)((uint32_t)acc[NA + g].x + ((uint32_t)acc[NA + g].y << 7) + (uint32_t)cim) >> L.shift);
+            fi[2 * g + 1] = (float)((int)((uint32_t)acc[NA + g].z + ((uint32_t)acc[NA + g].w << 7) + (uint32_t)cim) >> L.shift);
+        }
+    } else if constexpr (DIGITS == 2) {
 #pragma unroll
         for (int gi = 0; gi < NG; ++gi) {
             if (FD_ABLATE(18)) { fr[gi] = u2f((uint32_t)acc[gi].x & 0x3F800FFFu); fi[gi] = u2f((uint32_t)acc[gi].z & 0x3F800FFFu); continue; }   // ablation: no digit combine / shift / conversion
@@ -625,7 +646,7 @@ __device__ __forceinline__ void fd_reg_body(const FirDemodLaunch& L)
         }
     }
     if (last) {                                              // block-uniform, one tile per channel: the output that becomes demod_pre
-        if constexpr (DIGITS == 2) {
+        if constexpr (!GEO8) {
             const int dl = (int)no - 1 - (int)(tcol + q);    // (tiles overlap by one output: two lanes may hold it, with the same value)
             if (dl >= 0 && (dl & 3) == 0 && (dl >> 2) < (q < 2u ? NG : NG - 1)) {
 #pragma unroll
@@ -651,19 +672,19 @@ __device__ __forceinline__ void fd_reg_body(const FirDemodLaunch& L)
     float pr[NA], pi[NA];
 #pragma unroll
     for (int gi = 0; gi < NA; ++gi) {
-        const int src = DIGITS == 1 ? 2 * gi + 1 : gi;
+        const int src = GEO8 ? 2 * gi + 1 : gi;
         if (FD_ABLATE(19)) { pr[gi] = fi[src]; pi[gi] = fr[src]; continue; }                // ablation: no predecessor moves
         pr[gi] = u2f((uint32_t)__builtin_amdgcn_ds_bpermute(down, (int)f2u(fr[src])));
         pi[gi] = u2f((uint32_t)__builtin_amdgcn_ds_bpermute(down, (int)f2u(fi[src])));
     }
-    const float xr = FD_ABLATE(19) ? fi[0] : u2f((uint32_t)__builtin_amdgcn_ds_bpermute(DIGITS == 1 ? left1 : left, (int)f2u(fr[NG - 1])));
-    const float xi = FD_ABLATE(19) ? fr[0] : u2f((uint32_t)__builtin_amdgcn_ds_bpermute(DIGITS == 1 ? left1 : left, (int)f2u(fi[NG - 1])));
+    const float xr = FD_ABLATE(19) ? fi[0] : u2f((uint32_t)__builtin_amdgcn_ds_bpermute(GEO8 ? left1 : left, (int)f2u(fr[NG - 1])));
+    const float xi = FD_ABLATE(19) ? fr[0] : u2f((uint32_t)__builtin_amdgcn_ds_bpermute(GEO8 ? left1 : left, (int)f2u(fi[NG - 1])));
     const bool q0 = q == 0u;
     // (every lane takes part in every move: ds_bpermute returns 0 for a source lane that is masked off, so the row-0 lanes
     //  cannot fetch their previous-register values under an EXEC mask of their own -- they select instead)
     // ---- fm_demod (:355-367) per output, summed per audio group (:408-417) -------------------------------------------
     const uint32_t tmin = jfirst < 0 ? 0u : 1u;              // tile output 0 is only a predecessor (except at the call start)
-    const uint32_t t_first = tcol + (DIGITS == 1 ? 2u * q : q);   // the lane's first tile output; sample index m = o0 + t
+    const uint32_t t_first = tcol + (GEO8 ? 2u * q : q);     // the lane's first tile output; sample index m = o0 + t
     // audio group of the lane's first output and that group's last sample
     const int dm = (int)(o0 + t_first) - jA;                 // >= -1
     const uint32_t kq = (uint32_t)fmd_sdiv_magic((int)(x0 + (uint32_t)(dm > 0 ? dm : 0) * r.sr), L.magic_fr);
@@ -683,7 +704,7 @@ __device__ __forceinline__ void fd_reg_body(const FirDemodLaunch& L)
 #pragma unroll
     for (int gi = 0; gi < NG; ++gi) {
         float br, bi;
-        if constexpr (DIGITS == 2) {
+        if constexpr (!GEO8) {
             br = q0 ? (gi == 0 ? xr : pr[gi - 1]) : pr[gi];
             bi = q0 ? (gi == 0 ? xi : pi[gi - 1]) : pi[gi];
         } else if (gi & 1) {                                 // the odd output of an accumulator: its predecessor is the lane's own even one
@@ -705,7 +726,7 @@ __device__ __forceinline__ void fd_reg_body(const FirDemodLaunch& L)
             d_first = d;
         }
         int dv, dlo;
-        if constexpr (DIGITS == 2) {
+        if constexpr (!GEO8) {
             dv = (gi < g_hi && !(gi == 0 && skip0)) ? d : 0;
             dlo = gi < g_split ? dv : 0;
         } else {                                             // the lane's outputs are not equally spaced: each by its own column index
@@ -762,8 +783,9 @@ __global__ void __launch_bounds__(kThreads, fd_reg_blocks(NKU, NG, ROWS)) fmd_fi
 }
 
 // both with the matrix phase on the 4:2 sparse instruction (NKU stays the DENSE chunk count of the shape: the kernel derives its own)
+// (two digits, sparse: two tap-fragment sets and two accumulator sets -- NG = 6 takes the 6 blocks per CU its LDS budget leaves anyway)
 template <int NKU, int NG, bool ROWS>
-__global__ void __launch_bounds__(kThreads, fd_reg_blocks(NKU, NG, ROWS)) fmd_firdemod_regs_kernel(const FirDemodLaunch L)
+__global__ void __launch_bounds__(kThreads, NG == 6 && fd_reg_blocks(NKU, NG, ROWS) > 6 ? 6 : fd_reg_blocks(NKU, NG, ROWS)) fmd_firdemod_regs_kernel(const FirDemodLaunch L)
 {
     fd_reg_body<NKU, NG, ROWS, 2, true>(L);
 }
@@ -780,29 +802,25 @@ void launch(const FirDemodLaunch& L, dim3 g, size_t lds, hipStream_t s)
 #define FD_REGX(K, N) if (L.use_rows) hipLaunchKernelGGL((K<NKU, N, true>), g, dim3(kThreads), lds, s, L); \
                       else hipLaunchKernelGGL((K<NKU, N, false>), g, dim3(kThreads), lds, s, L)
     if (L.reg_ng && L.digits == 1u) {                       // (even column parameters only: the host falls back to two digits otherwise)
-#ifdef FMD_EXPERIMENT
-        if (!L.sparse) {
-            if (L.reg_ng == 4u) { FD_REGX(fmd_firdemod_reg1_kernel, 4); }
-            else if (L.reg_ng == 6u) { FD_REGX(fmd_firdemod_reg1_kernel, 6); }
-            else { FD_REGX(fmd_firdemod_reg1_kernel, 8); }
+        if (L.sparse) {
+            if (L.reg_ng == 4u) { FD_REGX(fmd_firdemod_reg1s_kernel, 4); }
+            else if (L.reg_ng == 6u) { FD_REGX(fmd_firdemod_reg1s_kernel, 6); }
+            else { FD_REGX(fmd_firdemod_reg1s_kernel, 8); }
             return;
         }
-#endif
-        if (L.reg_ng == 4u) { FD_REGX(fmd_firdemod_reg1s_kernel, 4); }
-        else if (L.reg_ng == 6u) { FD_REGX(fmd_firdemod_reg1s_kernel, 6); }
-        else { FD_REGX(fmd_firdemod_reg1s_kernel, 8); }
-        return;
-    }
 #ifdef FMD_EXPERIMENT
-    if (L.reg_ng && L.sparse && L.reg_ng <= 8u) {
+        if (L.reg_ng == 4u) { FD_REGX(fmd_firdemod_reg1_kernel, 4); }
+        else if (L.reg_ng == 6u) { FD_REGX(fmd_firdemod_reg1_kernel, 6); }
+        else { FD_REGX(fmd_firdemod_reg1_kernel, 8); }
+        return;
+#endif
+    }
+    if (L.reg_ng && L.sparse) {                             // two digits, re / im split (even column parameters)
         if (L.reg_ng == 4u) { FD_REGX(fmd_firdemod_regs_kernel, 4); }
-        else if (L.reg_ng == 5u) { FD_REGX(fmd_firdemod_regs_kernel, 5); }
         else if (L.reg_ng == 6u) { FD_REGX(fmd_firdemod_regs_kernel, 6); }
-        else if (L.reg_ng == 7u) { FD_REGX(fmd_firdemod_regs_kernel, 7); }
         else { FD_REGX(fmd_firdemod_regs_kernel, 8); }
         return;
     }
-#endif
 #undef FD_REGX
 #define FD_REG(N) if (L.use_rows) hipLaunchKernelGGL((fmd_firdemod_reg_kernel<NKU, N, true>), g, dim3(kThreads), lds, s, L); \
                   else hipLaunchKernelGGL((fmd_firdemod_reg_kernel<NKU, N, false>), g, dim3(kThreads), lds, s, L)
@@ -1123,21 +1141,33 @@ int fmd_firdemod_new(const int16_t* taps, uint32_t n_taps, uint32_t decim, uint3
         // an 8-bit filter (every |tap| <= 127) in the register form with an even column parameter: one digit per tap, (re, im) of eight
         // outputs per operand fragment -- NG / 2 accumulators and 24 instead of 40 matrix instructions per wave at config 4's shape
         // (fmd_firdemod_reg1_kernel; FMD_FD_DIGITS=2, experiment build: keep two digits for an A/B)
+#ifndef FMD_FD_SPARSE_DEFAULT
+#define FMD_FD_SPARSE_DEFAULT 1
+#endif
+        const bool even_ng = f->reg_ng == 4u || f->reg_ng == 6u || f->reg_ng == 8u;
+        const bool sparse_on = fmd_knob_u32("FMD_FD_SPARSE", FMD_FD_SPARSE_DEFAULT) != 0u;
+#ifdef FMD_EXPERIMENT
+        const bool dense_one_digit = true;                    // (fmd_firdemod_reg1_kernel: instantiated in the experiment build only)
+#else
+        const bool dense_one_digit = false;
+#endif
         bool small = true;
         for (uint32_t t = 0; t < n_taps; ++t) if (taps[t] > 127 || taps[t] < -127) small = false;
-        if (small && (f->reg_ng == 4u || f->reg_ng == 6u || f->reg_ng == 8u) && fmd_knob_u32("FMD_FD_DIGITS", 0) != 2u) {
+        if (small && even_ng && (sparse_on || dense_one_digit) && fmd_knob_u32("FMD_FD_DIGITS", 0) != 2u) {
             FmdFirMfmaPlan one;
             if (fmd_fir_build_mfma(taps, n_taps, decim, one, 1u) && one.n_pass == 1u) f->plan = one;
         }
-        // The ONE-digit form's matrix phase runs on the 4:2 sparse matrix instruction: 12 instead of 24 matrix instructions per wave at
-        // config 4's shape with the same 12 operand reads (-4.3 %).  The two-digit form's accumulators are 64 bytes apart, half a sparse
-        // chunk, so its fragments double (24 reads for 24 instead of 40 matrix instructions): +4.5 % -- it keeps the dense instruction.
-        // FMD_FD_SPARSE (experiment build): 0 / 1 = dense / sparse for both.
-#ifdef FMD_EXPERIMENT
-        f->sparse = f->reg_ng != 0u && f->reg_ng <= 8u && fmd_knob_u32("FMD_FD_SPARSE", f->plan.digits == 1u ? 1u : 0u) != 0u;
-#else
-        f->sparse = f->reg_ng != 0u && f->plan.digits == 1u;
-#endif
+        // The register form's matrix phase runs on the 4:2 sparse matrix instruction when the column parameter is even: one digit -- 12
+        // instead of 24 matrix instructions per wave at config 4's shape for the same 12 operand reads (-4.3 %); two digits -- re and
+        // im in accumulators of their own (fmd_fir_common.h `split`), 24 instead of 40 for the same 12 reads.  (Two digits with the
+        // components interleaved in one accumulator, 64 bytes = half a sparse chunk apart, needed 24 reads: +4.5 %, dropped.)
+        // FMD_FD_SPARSE=0 (experiment build): the dense instruction.
+        f->sparse = even_ng && sparse_on;
+        if (f->sparse && f->plan.digits == 2u) {
+            FmdFirMfmaPlan sp;
+            if (fmd_fir_build_mfma(taps, n_taps, decim, sp, 2u, true) && sp.n_pass == 1u) f->plan = sp;
+            else f->sparse = false;
+        }
     }
     for (uint32_t kt = 1; kt <= 1024; ++kt) {
         if ((uint64_t)r.sr * (kt + 2) >= (1u << 24)) break;

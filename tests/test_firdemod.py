@@ -88,6 +88,22 @@ def test_gpu_fused_reuse_at_decim_16(fmd, oracle, request):
         fused_case(fmd, oracle, T, M, fast, slow)
 
 
+def reg_kernel_prefix(fast, slow, taps_8bit, knobs=None):
+    """Which kernel the library reports for a decimate-8 bank with the f32 discriminator (csrc/fmd_firdemod.hip): the register form
+    needs audio groups of >= 4 NG outputs (NG = the longest column parameter <= 8 they admit, or FMD_FD_REG); an even NG runs the
+    matrix phase on the 4:2 sparse instruction (`s`; FMD_FD_SPARSE=0: dense), an 8-bit filter with an even NG one tap digit (`1`)."""
+    knobs = knobs or {}
+    fa = fast // slow
+    ng = int(knobs["FMD_FD_REG"]) if "FMD_FD_REG" in knobs else min(fa // 4, 8)
+    pre = "(anonymous namespace)::fmd_firdemod_"
+    if ng < 4 or fa < 4 * ng:
+        return pre + "kernel<"
+    even = ng in (4, 6, 8)
+    one = taps_8bit and even and knobs.get("FMD_FD_DIGITS") != "2"
+    sparse = even and knobs.get("FMD_FD_SPARSE") != "0"
+    return pre + "reg" + ("1" if one else "") + ("s" if sparse else "") + "_kernel<"
+
+
 REG_SHAPES = [(127, 8, 2500000, 48000), (127, 8, 1000000, 44100), (8, 8, 250000, 8000), (200, 8, 480000, 8000), (33, 8, 960000, 48000),
               (1, 8, 640000, 32000)]
 
@@ -99,7 +115,7 @@ def test_gpu_fused_register_form(fmd, oracle, T, M, fast, slow):
     the discriminator straight out of the matrix-core result registers (fmd_firdemod_reg_kernel): tiny first calls, many
     tiles per channel, full scale, state carried over six calls."""
     kn = fused_case(fmd, oracle, T, M, fast, slow, f32_only=True)
-    assert kn.startswith("(anonymous namespace)::fmd_firdemod_reg_kernel<") and kn.endswith(", true>"), kn
+    assert kn.startswith(reg_kernel_prefix(fast, slow, False)) and "reg" in kn and kn.endswith(", true>"), kn
 
 
 @pytest.mark.gpu
@@ -114,7 +130,8 @@ def test_gpu_fused_register_form_variants(fmd, oracle, request, ng):
     for T, M, fast, slow in REG_SHAPES[:4]:
         kn = fused_case(fmd, oracle, T, M, fast, slow, f32_only=True)
         want_reg = ng != "0" and fast // slow >= 4 * int(ng)         # an audio group must hold a lane's 4 ng - 3 consecutive outputs
-        assert kn.startswith("(anonymous namespace)::fmd_firdemod_reg_kernel<") == want_reg and (not want_reg or kn.endswith(", %s, true>" % ng)), kn
+        assert kn.startswith(reg_kernel_prefix(fast, slow, False, {"FMD_FD_REG": ng})) and ("reg" in kn) == want_reg, kn
+        assert not want_reg or kn.endswith(", %s, true>" % ng), kn
 
 
 REG1_SHAPES = [(127, 8, 2500000, 48000), (200, 8, 480000, 8000), (64, 8, 768000, 48000), (100, 8, 1200000, 48000), (8, 8, 256000, 8000),
@@ -130,31 +147,24 @@ def test_gpu_fused_register_form_one_digit(fmd, oracle, T, M, fast, slow):
     tiny first calls, many tiles per channel, full scale, state carried over six calls."""
     kn = fused_case(fmd, oracle, T, M, fast, slow, f32_only=True, taps_max=127)
     assert kn.startswith("(anonymous namespace)::fmd_firdemod_reg1s_kernel<") and kn.endswith(", true>"), kn
+    assert kn.startswith(reg_kernel_prefix(fast, slow, True)), kn
 
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("knobs", [{"FMD_FD_DIGITS": "2"}, {"FMD_FD_REG": "4"}, {"FMD_FD_REG": "6"}, {"FMD_FD_REG": "5"}, {"FMD_FD_ROWS": "0"},
-                                   {"FMD_FD_SPARSE": "0"}, {"FMD_FD_SPARSE": "0", "FMD_FD_REG": "6"}, {"FMD_FD_SPARSE": "1"},
-                                   {"FMD_FD_SPARSE": "1", "FMD_FD_REG": "5"}])
-def test_gpu_fused_one_digit_variants(fmd, oracle, request, knobs):
-    """8-bit filters with the two-digit form forced, with shorter columns (4 / 6: one digit; 5: odd, so two digits), without the
-    per-tile table, and with the matrix phase on the dense / the sparse instruction for BOTH digit forms (FMD_FD_SPARSE = 0 / 1; the
-    shipped rule is sparse for one digit, dense for two): knobs of the -DFMD_EXPERIMENT build.  The 12-bit filters run beside them."""
+                                   {"FMD_FD_SPARSE": "0"}, {"FMD_FD_SPARSE": "0", "FMD_FD_REG": "6"}, {"FMD_FD_SPARSE": "0", "FMD_FD_DIGITS": "2"}])
+def test_gpu_fused_digit_and_sparse_variants(fmd, oracle, request, knobs):
+    """8-bit and 12-bit filters side by side with the two-digit form forced, with shorter columns (4 / 6: sparse, one digit for the 8-bit
+    filter; 5: odd, so dense and two digits), without the per-tile table, and with the matrix phase on the dense instruction
+    (FMD_FD_SPARSE=0): knobs of the -DFMD_EXPERIMENT build."""
     from conftest import run_in_exp_child
     if run_in_exp_child(request, knobs):
         return
     for T, M, fast, slow in REG1_SHAPES[:3]:
-        ng, sp = knobs.get("FMD_FD_REG"), knobs.get("FMD_FD_SPARSE")
-        want_reg = ng is None or fast // slow >= 4 * int(ng)
-        one = "FMD_FD_DIGITS" not in knobs and ng != "5" and want_reg
         kn = fused_case(fmd, oracle, T, M, fast, slow, f32_only=True, taps_max=127)
         kn2 = fused_case(fmd, oracle, T, M, fast, slow, f32_only=True)                       # 12-bit taps: two digits
-        pre = "(anonymous namespace)::fmd_firdemod_"
-        if not want_reg:
-            assert kn.startswith(pre + "kernel<") and kn2.startswith(pre + "kernel<"), (knobs, kn, kn2)
-            continue
-        assert kn.startswith(pre + ("reg1" if one else "reg") + ("s" if (sp == "1" or (sp is None and one)) else "") + "_kernel<"), (knobs, kn)
-        assert kn2.startswith(pre + "reg" + ("s" if sp == "1" else "") + "_kernel<"), (knobs, kn2)
+        assert kn.startswith(reg_kernel_prefix(fast, slow, True, knobs)), (knobs, kn)
+        assert kn2.startswith(reg_kernel_prefix(fast, slow, False, knobs)), (knobs, kn2)
 
 
 def fused_case(fmd, oracle, T, M, fast, slow, f32_only=False, taps_max=2047):
