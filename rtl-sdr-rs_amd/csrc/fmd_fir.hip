@@ -234,9 +234,14 @@ __global__ void __launch_bounds__(kFirThreads, NKU <= 6 ? 8 : (NKU == 7 ? 6 : 4)
     // behind the 16 KB of DMAs they queue behind them and every wave waits for them at the barrier (+2 % measured)
     typedef const FMD_AS_GLOBAL fir_i4* gq;
     const gq amat = (gq)(uintptr_t)H.amat + lane;
-    fir_i4 A[NKU];
+    // DIGITS == 3: two digits on the 4:2 sparse matrix instruction, re and im rows in fragment sets of their own ((lo, hi) of EIGHT
+    // outputs per fragment: fmd_fir_common.h `split`) -- a lane then ends up with two complete adjacent outputs, like the one-digit
+    // form, and stores them as 16 bytes.  NKU stays the dense chunk count of that shape; the form has (NKU + 1) / 2 128-byte chunks.
+    constexpr int NKS = (NKU + 1) / 2;
+    constexpr int NAF = DIGITS == 3 ? 2 * NKS : NKU;
+    fir_i4 A[NAF];
 #pragma unroll
-    for (int k = 0; k < NKU; ++k) A[k] = FIR_ABLATE(4) ? fir_i4{(int)lane, k, 1, 2} : amat[k * 64];   // (probe: what the tap fragments' L2 traffic costs)
+    for (int k = 0; k < NAF; ++k) A[k] = FIR_ABLATE(4) ? fir_i4{(int)lane, k, 1, 2} : amat[k * 64];   // (probe: what the tap fragments' L2 traffic costs)
     if (FIR_ABLATE(1)) {
     } else if (whole) {
         const unsigned char* src = reinterpret_cast<const unsigned char*>(reinterpret_cast<const uint32_t*>((uintptr_t)H.iq) + (uint64_t)c * H.stride_w + (w0 - H.Hw)) + 16u * (SWZ ? fir_swz_slot(tid) : tid);
@@ -271,16 +276,36 @@ __global__ void __launch_bounds__(kFirThreads, NKU <= 6 ? 8 : (NKU == 7 ? 6 : 4)
 
     if (FIR_ABLATE(8)) __builtin_amdgcn_s_sleep(16);                // pacing probes (experiment build): 1024 clocks behind the staging barrier ...
     const uint8_t* lb = reinterpret_cast<const uint8_t*>(lds);
-    fir_i4 acc[kFirGroupsPerWave];
+    constexpr int GPW = DIGITS == 3 ? 2 : kFirGroupsPerWave;       // (sparse form: the host keeps the tile at <= 8 groups of 128 outputs)
+    fir_i4 acc[DIGITS == 3 ? 2 * GPW : GPW];                        // (sparse form: acc[gi] re, acc[GPW + gi] im)
 #pragma unroll
-    for (int gi = 0; gi < kFirGroupsPerWave; ++gi) acc[gi] = fir_i4{0, 0, 0, 0};
-    for (uint32_t pass = 0; pass < L.n_pass && !FIR_ABLATE(0); ++pass) {
+    for (int gi = 0; gi < (DIGITS == 3 ? 2 * GPW : GPW); ++gi) acc[gi] = fir_i4{0, 0, 0, 0};
+    if constexpr (DIGITS == 3) {
+        typedef int fir_i8 __attribute__((ext_vector_type(8)));
+#pragma unroll
+        for (int gi = 0; gi < GPW; ++gi) {
+            const uint32_t g = wave + 4u * gi;
+            if (g < L.groups && 128u * g < no && !FIR_ABLATE(0)) {  // wave-uniform
+                const uint8_t* col = lb + (16u * g + j) * L.col_bytes + 32u * q;     // the lane's 32 bytes of a 128-byte chunk
+#pragma unroll
+                for (int kc = 0; kc < NKS; ++kc) {
+                    const fir_i4 b0 = *reinterpret_cast<const fir_i4*>(col + 128 * kc) ^ (int)0x80808080;          // u8 -> s8
+                    const fir_i4 b1 = *reinterpret_cast<const fir_i4*>(col + 128 * kc + 16) ^ (int)0x80808080;
+                    const fir_i8 B = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+                    // every re row keeps bytes 0 and 3 of each stream dword (index pairs (0, 3)), every im row bytes 1 and 2
+                    acc[gi] = __builtin_amdgcn_smfmac_i32_16x16x128_i8(A[kc], B, acc[gi], (int)0xCCCCCCCCu, 0, 0);
+                    acc[GPW + gi] = __builtin_amdgcn_smfmac_i32_16x16x128_i8(A[NKS + kc], B, acc[GPW + gi], (int)0x99999999u, 0, 0);
+                }
+            }
+        }
+    }
+    for (uint32_t pass = 0; pass < L.n_pass && !FIR_ABLATE(0) && DIGITS != 3; ++pass) {
         if (pass) {
 #pragma unroll
             for (int k = 0; k < NKU; ++k) A[k] = amat[(pass * NKU + k) * 64u];
         }
 #pragma unroll
-        for (int gi = 0; gi < kFirGroupsPerWave; ++gi) {
+        for (int gi = 0; gi < GPW; ++gi) {
             const uint32_t g = wave + 4u * gi;
             if (g < L.groups && (DIGITS == 1 ? 128u : 64u) * g < no) {   // wave-uniform
                 const uint8_t* col = lb + (16u * g + j) * L.col_bytes + 64u * NKU * pass;
@@ -326,15 +351,27 @@ __global__ void __launch_bounds__(kFirThreads, NKU <= 6 ? 8 : (NKU == 7 ? 6 : 4)
         const uint32_t par0 = L.par_first & 1u, par1 = (L.par_first ^ L.half_M) & 1u;
         const int cre0 = L.mre[par0], cim0 = L.mim[par0], cre1 = L.mre[par1], cim1 = L.mim[par1];
 #pragma unroll
-        for (int gi = 0; gi < kFirGroupsPerWave; ++gi) {
+        for (int gi = 0; gi < GPW; ++gi) {
             const uint32_t g = wave + 4u * gi;
             const uint32_t o = 128u * g + 8u * j + 2u * q;
             if (g < L.groups && o < no && !FIR_ABLATE(2)) {
-                int re0 = acc[gi].x, im0 = acc[gi].y, re1 = acc[gi].z, im1 = acc[gi].w;
+                int re0, im0, re1, im1;
+                if constexpr (DIGITS == 3) {                 // (lo, hi) of the two outputs, re and im in accumulators of their own
+                    re0 = acc[gi].x + (acc[gi].y << 7); re1 = acc[gi].z + (acc[gi].w << 7);
+                    im0 = acc[GPW + gi].x + (acc[GPW + gi].y << 7); im1 = acc[GPW + gi].z + (acc[GPW + gi].w << 7);
+                } else {
+                    re0 = acc[gi].x; im0 = acc[gi].y; re1 = acc[gi].z; im1 = acc[gi].w;
+                }
                 if (L.par_first) { re0 = -re0; im0 = -im0; re1 = -re1; im1 = -im1; }
-                int2* dst = reinterpret_cast<int2*>(L.out) + ((uint64_t)c * L.out_cap + o0 + o);   // (8-byte aligned; a channel's row need not be 16)
-                dst[0] = make_int2(re0 + cre0, im0 + cim0);
-                if (o + 1u < no) dst[1] = make_int2(re1 + cre1, im1 + cim1);
+                // both outputs as ONE 16-byte store where the row allows it (an even out_cap: every channel's row 16-byte aligned) -- two
+                // 8-byte stores 16 bytes apart per lane touch every line twice
+                int2* dst = reinterpret_cast<int2*>(L.out) + ((uint64_t)c * L.out_cap + o0 + o);
+                if (o + 1u < no && (reinterpret_cast<uintptr_t>(dst) & 15u) == 0u) {
+                    *reinterpret_cast<int4*>(dst) = make_int4(re0 + cre0, im0 + cim0, re1 + cre1, im1 + cim1);
+                } else {
+                    dst[0] = make_int2(re0 + cre0, im0 + cim0);
+                    if (o + 1u < no) dst[1] = make_int2(re1 + cre1, im1 + cim1);
+                }
             }
         }
     }
@@ -354,6 +391,7 @@ template <int NKU>
 void launch_mfma(const FirLaunch& L, dim3 g, size_t lds, hipStream_t stream, bool swz, uint32_t digits)
 {
     if (digits == 1u) launch_mfma_d<NKU, 1>(L, g, lds, stream, swz);
+    else if (digits == 3u) hipLaunchKernelGGL((fmd_fir_mfma_kernel<NKU, false, 3>), g, dim3(kFirThreads), lds, stream, L);
     else launch_mfma_d<NKU, 2>(L, g, lds, stream, swz);
 }
 
@@ -450,13 +488,13 @@ int fir_enqueue(fmd_fir* f, const void* d_iq, size_t nbytes, void* d_out, size_t
     L.out_tile = (uint32_t)ot;
     L.dbg = f->dbg;
     if (n_out && f->n_pass) {
-        const uint32_t opc = f->digits == 1u ? 8u : 4u;              // outputs per column
+        const uint32_t opc = f->digits != 2u ? 8u : 4u;              // outputs per column (one digit, or two on the sparse instruction: eight)
         L.amat = f->d_amat; L.n_pass = f->n_pass; L.nku = f->nku; L.groups = f->groups; L.col_bytes = 2u * opc * f->M;
         L.mre[0] = f->mre[0]; L.mre[1] = f->mre[1]; L.mim[0] = f->mim[0]; L.mim[1] = f->mim[1];
         L.out_tile = 16u * opc * f->groups;
         // staged bytes of a full tile, and the furthest byte any fragment read touches
         const size_t staged = (((((size_t)(L.out_tile - 1) * L.half_M + L.NP + 3) / 4) + 3) & ~(size_t)3) * 16;
-        const size_t touched = (size_t)16 * f->groups * L.col_bytes + (size_t)64 * f->n_pass * f->nku;
+        const size_t touched = (size_t)16 * f->groups * L.col_bytes + (size_t)64 * f->n_pass * (f->nku + 1u);   // (+1: the sparse form's 128-byte chunks)
         const size_t lds = staged > touched ? staged : touched;
         const uint32_t tiles = (uint32_t)((n_out + L.out_tile - 1) / L.out_tile), per = (f->C + 7u) / 8u;
         if (tiles > 65535u || per > 65535u) { fmd_internal_set_err("call too large for the matrix-core FIR grid"); return FMD_ERR_UNSUPPORTED; }
@@ -558,12 +596,21 @@ int fmd_fir_new(const int16_t* taps, uint32_t n_taps, uint32_t decim, const fmd_
     uint32_t digits = 1u;
     for (uint32_t t = 0; t < n_taps; ++t) if (taps[t] > 127 || taps[t] < -127) digits = 2u;
     if (fmd_knob_u32("FMD_FIR_DIGITS", 0) == 2u) digits = 2u;
-    if (!(env_mfma && env_mfma[0] == '0') && fmd_fir_build_mfma(taps, n_taps, decim, plan, digits)) {
-        f->n_pass = plan.n_pass; f->nku = plan.nku; f->digits = plan.digits;
-        uint32_t groups = 16384u / ((plan.digits == 1u ? 256u : 128u) * decim);   // ~16 KB of input per tile
+    // two digits at decim >= 8 with all K chunks in one pass: the sparse form with re / im split (fmd_fir_common.h) -- its lanes hold
+    // two adjacent outputs each and store 16 bytes, which is what this store-bound operator is paid for (FMD_FIR_SPARSE=0, experiment
+    // build: the dense interleaved form)
+    bool split = false;
+    if (digits == 2u && decim >= 8u && fmd_knob_u32("FMD_FIR_SPARSE", 1) != 0u && !(env_mfma && env_mfma[0] == '0')) {
+        FmdFirMfmaPlan sp;
+        if (fmd_fir_build_mfma(taps, n_taps, decim, sp, 2u, true) && sp.n_pass == 1u) { plan = sp; split = true; }
+    }
+    if (!(env_mfma && env_mfma[0] == '0') && (split || fmd_fir_build_mfma(taps, n_taps, decim, plan, digits))) {
+        f->n_pass = plan.n_pass; f->nku = plan.nku; f->digits = split ? 3u : plan.digits;
+        uint32_t groups = 16384u / ((f->digits != 2u ? 256u : 128u) * decim);   // ~16 KB of input per tile
         f->groups = groups < 1u ? 1u : (groups > 16u ? 16u : groups);
         if (const char* eg = fmd_knob("FMD_FIR_GROUPS")) { const uint32_t g = (uint32_t)atoi(eg); if (g >= 1 && g <= 4u * kFirGroupsPerWave) f->groups = g; }   // tuning
-        amat.swap(plan.amat);
+        if (f->digits == 3u && f->groups > 8u) f->groups = 8u;      // (sparse form: two accumulator pairs per wave)
+        if (split) amat.swap(plan.amat_s); else amat.swap(plan.amat);
         for (int par = 0; par < 2; ++par) { f->mre[par] = plan.mre[par]; f->mim[par] = plan.mim[par]; }
     }
     auto fail = [&](const char* what) { fmd_internal_set_err(what); fmd_fir_free(f); return FMD_ERR_HIP; };
@@ -603,7 +650,7 @@ void fmd_fir_free(fmd_fir* f)
     delete f;
 }
 
-int fmd_fir_tap_digits(const fmd_fir* f) { return f ? (int)f->digits : FMD_ERR_INVALID_ARG; }
+int fmd_fir_tap_digits(const fmd_fir* f) { return f ? (int)(f->digits == 3u ? 2u : f->digits) : FMD_ERR_INVALID_ARG; }
 
 int fmd_fir_reset(fmd_fir* f)
 {

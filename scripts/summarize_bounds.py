@@ -58,7 +58,7 @@ for name, sub in (("config4_fir", tag + "_pmc_fir"), ("config4_fir_demod_fused",
         continue
     cyc = c["SQ_BUSY_CYCLES"] / N_SE
     o = {"launch_cycles_under_pmc": round(cyc), "waves_per_launch": round(c.get("SQ_WAVES", 0))}
-    kname = {"config4_fir": "(anonymous namespace)::fmd_fir_mfma_kernel<5, false, 2>", "config4_fir_demod_fused": "(anonymous namespace)::fmd_firdemod_regs_kernel<6, 8, true>"}[name]
+    kname = {"config4_fir": "(anonymous namespace)::fmd_fir_mfma_kernel<6, false, 3>", "config4_fir_demod_fused": "(anonymous namespace)::fmd_firdemod_regs_kernel<6, 8, true>"}[name]
     kw = kernel_weight(kname)
     o["kernel"], o["valu_clocks_per_instruction"] = kname, round(kw, 3)
     if "SQ_INSTS_VALU" in c:

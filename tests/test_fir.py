@@ -63,7 +63,8 @@ def test_oracle_fir_equals_numpy_convolution(oracle, T, M):
 
 
 FIR_SHAPES = [(127, 8), (6, 6), (10, 10), (5, 2), (16, 16), (33, 4), (1, 2), (64, 6), (255, 32),
-              (300, 8), (1024, 2), (129, 64), (77, 66), (31, 128)]
+              (300, 8), (1024, 2), (129, 64), (77, 66), (31, 128),
+              (63, 8), (200, 8), (64, 16), (31, 12), (100, 10), (9, 26)]      # 12-bit taps at decim >= 8 in one K pass: the sparse two-digit form
 
 
 def fir_stream_case(fmd, oracle, T, M):
@@ -142,12 +143,14 @@ def test_gpu_fir_digits_follow_the_taps(fmd):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("form", ["valu", "mfma_swz", "two_digits"])
+@pytest.mark.parametrize("form", ["valu", "mfma_swz", "two_digits", "dense"])
 def test_gpu_fir_forced_forms(fmd, oracle, request, form):
-    """The VALU form forced for small decim (FMD_FIR_MFMA=0) and the conflict-free LDS layout of the matrix-core form
-    (FMD_FIR_SWZ=1, decim 8 only) are knobs of the -DFMD_EXPERIMENT build: each form re-runs itself ONCE in a child process
+    """The VALU form forced for small decim (FMD_FIR_MFMA=0), the conflict-free LDS layout of the dense matrix-core form
+    (FMD_FIR_SWZ=1, decim 8 only), an 8-bit filter through two digits (FMD_FIR_DIGITS=2) and the dense interleaved two-digit form where
+    the library now takes the sparse one (FMD_FIR_SPARSE=0) are knobs of the -DFMD_EXPERIMENT build: each form re-runs itself ONCE in a child process
     on that library and walks through all its shapes there."""
-    if run_in_exp_child(request, {"FMD_FIR_MFMA": "0"} if form == "valu" else {"FMD_FIR_SWZ": "1"} if form == "mfma_swz" else {"FMD_FIR_DIGITS": "2"}):
+    if run_in_exp_child(request, {"FMD_FIR_MFMA": "0"} if form == "valu" else {"FMD_FIR_SWZ": "1", "FMD_FIR_SPARSE": "0"} if form == "mfma_swz"
+                        else {"FMD_FIR_DIGITS": "2"} if form == "two_digits" else {"FMD_FIR_SPARSE": "0"}):
         return
     for T, M in FIR_SHAPES:
         if form == "mfma_swz" and M != 8:
