@@ -585,7 +585,6 @@ __device__ __forceinline__ void fd_reg_body(const FirDemodLaunch& L)
 #pragma unroll
             for (int kc = 0; kc < NKS; ++kc)
                 if ((s - 2 * kc) >= 0 && (s - 2 * kc) % AS == 0 && (s - 2 * kc) / AS < NA) {
-                    constexpr int dummy = 0; (void)dummy;
                     const int g = (s - 2 * kc) / AS;
                     if constexpr (DIGITS == 2) {             // one fragment, both components: every re row keeps bytes 0 / 3, every im row 1 / 2
                         acc[g] = __builtin_amdgcn_smfmac_i32_16x16x128_i8(A[kc], B, acc[g], (int)0xCCCCCCCCu, 0, 0);
@@ -1144,15 +1143,21 @@ int fmd_firdemod_new(const int16_t* taps, uint32_t n_taps, uint32_t decim, uint3
 #ifndef FMD_FD_SPARSE_DEFAULT
 #define FMD_FD_SPARSE_DEFAULT 1
 #endif
-        const bool even_ng = f->reg_ng == 4u || f->reg_ng == 6u || f->reg_ng == 8u;
         const bool sparse_on = fmd_knob_u32("FMD_FD_SPARSE", FMD_FD_SPARSE_DEFAULT) != 0u;
+        bool small = true;
+        for (uint32_t t = 0; t < n_taps; ++t) if (taps[t] > 127 || taps[t] < -127) small = false;
+        // (an 8-bit filter whose audio groups admit an ODD column parameter -- 5 or 7 -- takes the even one below it: the one-digit
+        //  sparse form with slightly shorter columns beats two dense digits by more than the columns cost)
+        if (small && sparse_on && (f->reg_ng == 5u || f->reg_ng == 7u) && fmd_knob("FMD_FD_REG") == nullptr && fmd_knob_u32("FMD_FD_DIGITS", 0) != 2u) {
+            f->reg_ng -= 1u;
+            if (!lds_knob) f->lds_budget = budget[f->reg_ng];
+        }
+        const bool even_ng = f->reg_ng == 4u || f->reg_ng == 6u || f->reg_ng == 8u;
 #ifdef FMD_EXPERIMENT
         const bool dense_one_digit = true;                    // (fmd_firdemod_reg1_kernel: instantiated in the experiment build only)
 #else
         const bool dense_one_digit = false;
 #endif
-        bool small = true;
-        for (uint32_t t = 0; t < n_taps; ++t) if (taps[t] > 127 || taps[t] < -127) small = false;
         if (small && even_ng && (sparse_on || dense_one_digit) && fmd_knob_u32("FMD_FD_DIGITS", 0) != 2u) {
             FmdFirMfmaPlan one;
             if (fmd_fir_build_mfma(taps, n_taps, decim, one, 1u) && one.n_pass == 1u) f->plan = one;

@@ -95,6 +95,8 @@ def reg_kernel_prefix(fast, slow, taps_8bit, knobs=None):
     knobs = knobs or {}
     fa = fast // slow
     ng = int(knobs["FMD_FD_REG"]) if "FMD_FD_REG" in knobs else min(fa // 4, 8)
+    if taps_8bit and ng in (5, 7) and "FMD_FD_REG" not in knobs and knobs.get("FMD_FD_SPARSE") != "0" and knobs.get("FMD_FD_DIGITS") != "2":
+        ng -= 1                                                   # an 8-bit filter takes the even column parameter below an odd one
     pre = "(anonymous namespace)::fmd_firdemod_"
     if ng < 4 or fa < 4 * ng:
         return pre + "kernel<"
@@ -135,7 +137,7 @@ def test_gpu_fused_register_form_variants(fmd, oracle, request, ng):
 
 
 REG1_SHAPES = [(127, 8, 2500000, 48000), (200, 8, 480000, 8000), (64, 8, 768000, 48000), (100, 8, 1200000, 48000), (8, 8, 256000, 8000),
-               (1, 8, 1280000, 32000)]                          # column parameter NG = 8, 8, 4, 6, 8, 8
+               (1, 8, 1280000, 32000), (127, 8, 1000000, 44100), (33, 8, 960000, 32000)]   # column parameter NG = 8, 8, 4, 6, 8, 8, 5 -> 4, 7 -> 6
 
 
 @pytest.mark.gpu

@@ -55,7 +55,7 @@ def firdemod(a):
     parsed = [parse_build(b) for b in a.builds]
     builds = [(n_, l_) for n_, l_, _ in parsed]
     envs = [e_ for _, _, e_ in parsed]
-    nch, n, T, M, fast, slow = 256, 2 << 20, 127, 8, 2500000, 48000
+    nch, n, T, M, fast, slow = 256, 2 << 20, 127, 8, a.fd_fast, a.fd_slow
     taps = np.random.default_rng(1).integers(-a.fir_taps_max, a.fir_taps_max + 1, T).astype(np.int16)
     shift = fmd.auto_shift(taps)
     stream = torch.cuda.current_stream().cuda_stream
@@ -93,7 +93,7 @@ def firdemod(a):
     for (name, l), h in zip(builds, hs):
         ts = sorted(res[name]); med = ts[len(ts) // 2]
         base = base or med
-        print(json.dumps({"cfg": "config4 fused FIR, |tap| <= %d" % a.fir_taps_max, "build": name, "ms": [round(t, 4) for t in res[name]], "median_ms": round(med, 4),
+        print(json.dumps({"cfg": "fused FIR 127 / 8, %d -> %d Hz, |tap| <= %d" % (fast, slow, a.fir_taps_max), "build": name, "ms": [round(t, 4) for t in res[name]], "median_ms": round(med, 4),
                           "frac": round(alg / med / 1e6 / 8000, 4), "vs_first_pct": round(100 * (med / base - 1), 2)}), flush=True)
         l.fmd_firdemod_free(h)
 
@@ -157,6 +157,8 @@ def main():
     ap.add_argument("--fir", action="store_true", help="BASELINE configs[3] through the stand-alone FIR kernel")
     ap.add_argument("--fir-taps-max", type=int, default=2047)
     ap.add_argument("--fir-bytes", type=int, default=2 << 20)
+    ap.add_argument("--fd-fast", type=int, default=2500000, help="--firdemod: rate after the FIR")
+    ap.add_argument("--fd-slow", type=int, default=48000, help="--firdemod: audio rate")
     ap.add_argument("--out-bufs", type=int, default=1, help="rotate the calls over this many output buffers (more than the 256 MB memory-side cache holds: every written byte goes to HBM)")
     ap.add_argument("--fir-channels", type=int, default=256)
     ap.add_argument("builds", nargs="+")
