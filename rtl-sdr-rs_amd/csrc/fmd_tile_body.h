@@ -460,7 +460,13 @@ __device__ __forceinline__ void stream_pair_rounds(const unsigned char* __restri
                                                    int jfirst, uint32_t hp, int cnt, uint32_t lane, uint32_t wave)
 {
     constexpr int NDW = 2 * DH;
-    constexpr int P = NDW <= 6 ? 4 : (NDW <= 10 ? 3 : 2);   // rounds in flight per wave (register budget: 64 VGPRs)
+#ifdef FMD_STREAM_P
+    constexpr int P = FMD_STREAM_P;                          // (variant builds: rounds in flight per wave)
+#else
+    // rounds in flight per wave (register budget: 64 VGPRs; the kernel runs downsample 2 and 4 -- 2 / 4 dwords per lane and round, 32 / 46
+    // VGPRs at 8 rounds: session r05bk, 3 / 4 / 5 / 6 / 8 rounds: +0.9 ... 0 / 0 / -0.3 ... -1.0 / -0.3 ... -1.2 / -0.4 ... -1.7 %)
+    constexpr int P = NDW <= 4 ? 8 : (NDW <= 6 ? 4 : (NDW <= 10 ? 3 : 2));
+#endif
     constexpr int32_t STRIDE = 4 * DH * NW * RS;             // bytes from one round of a wave to its next
     wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)wave);
     const int last = cnt - 1;
