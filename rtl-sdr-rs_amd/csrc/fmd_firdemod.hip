@@ -1148,6 +1148,7 @@ int fmd_firdemod_new(const int16_t* taps, uint32_t n_taps, uint32_t decim, uint3
         for (uint32_t t = 0; t < n_taps; ++t) if (taps[t] > 127 || taps[t] < -127) small = false;
         // (an 8-bit filter whose audio groups admit an ODD column parameter -- 5 or 7 -- takes the even one below it: the one-digit
         //  sparse form with slightly shorter columns beats two dense digits by more than the columns cost)
+        // (12-bit filters keep the odd parameter: session r05bl, 5 -> 4 sparse +6 ... +7 %, 7 -> 6 sparse -1 %)
         if (small && sparse_on && (f->reg_ng == 5u || f->reg_ng == 7u) && fmd_knob("FMD_FD_REG") == nullptr && fmd_knob_u32("FMD_FD_DIGITS", 0) != 2u) {
             f->reg_ng -= 1u;
             if (!lds_knob) f->lds_budget = budget[f->reg_ng];
