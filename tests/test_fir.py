@@ -221,9 +221,11 @@ def test_gpu_fir_fuzz(fmd, oracle):
     for _ in range(n_cases):
         M = 2 * int(rng.choice([1, 2, 3, 4, 5, 8, 16, 25, 32, 33, 40]))
         T = int(rng.choice([1, 2, 3, 7, 16, 31, 64, 127, 128, 200, 513, 1024]))
-        taps = rng.integers(-2047, 2048, T).astype(np.int16)
+        lim = 127 if rng.integers(0, 3) == 0 else 2047                 # a third of the cases: an 8-bit filter (the one-digit form)
+        taps = rng.integers(-lim, lim + 1, T).astype(np.int16)
         nch = int(rng.integers(1, 5))
         bank = fmd.FirBank(taps, M, nch)
+        assert bank.tap_digits() == (0 if M > 64 else 1 if np.abs(taps).max() <= 127 else 2), (T, M, bank.tap_digits())
         hs = [oracle.fir_new(taps, M) for _ in range(nch)]
         for _ in range(int(rng.integers(1, 5))):
             n = 8 * int(rng.integers(1, 3000))

@@ -254,18 +254,24 @@ def test_gpu_fused_fuzz(fmd, oracle):
     import os
     n_cases = int(os.environ.get("FMD_FUZZ_CASES", "30"))
     rng = np.random.default_rng(int(os.environ.get("FMD_FUZZ_SEED", "777")))
+    n_refused, kernels = 0, {}
     for case in range(n_cases):
-        M = 2 * int(rng.choice([1, 2, 3, 4, 5, 8, 16, 25, 32]))
+        M = 2 * int(rng.choice([1, 2, 3, 4, 4, 4, 5, 8, 16, 25, 32]))      # (decimate 8 -- the register forms -- three times as often)
         T = int(rng.choice([1, 2, 3, 7, 16, 31, 64, 127, 128, 200, 513]))
-        taps = rng.integers(-2047, 2048, T).astype(np.int16) if rng.integers(0, 4) else np.ones(T, np.int16)
+        kind = int(rng.integers(0, 5))                                    # 12-bit taps, 8-bit taps (one tap digit), all ones
+        taps = np.ones(T, np.int16) if kind == 0 else rng.integers(-127, 128, T).astype(np.int16) if kind <= 2 else rng.integers(-2047, 2048, T).astype(np.int16)
         shift = fmd.auto_shift(taps, 16384) + int(rng.integers(0, 7))     # both discriminator forms (|lp| <= 2048: f32)
         slow = int(rng.choice([8000, 32000, 44100, 48000]))
         fast = slow * int(rng.integers(1, 60)) + int(rng.integers(0, slow)) * int(rng.integers(0, 2))
+        if M == 8 and rng.integers(0, 10) < 7:                            # most decimate-8 cases: inside the register forms' domain
+            fast = slow * int(rng.integers(16, 60)) + int(rng.integers(0, slow)) * int(rng.integers(0, 2))
+            shift = fmd.auto_shift(taps, 2048) + int(rng.integers(0, 3))
         nch = int(rng.integers(1, 5))
         try:
             fd = fmd.FirDemodBank(taps, M, fast, slow, nch, shift=shift)
         except fmd.FmdError as e:
             assert e.status == -6, (T, M, fast, slow, e)                     # outside the documented domain only
+            n_refused += 1
             continue
         hs = [oracle.firdemod_new(taps, M, shift, fast, slow) for _ in range(nch)]
         first = 8 * ((T + 2 * M) // 4 + 2)
@@ -281,7 +287,13 @@ def test_gpu_fused_fuzz(fmd, oracle):
         for c in range(nch):
             assert state_tuple(fd.get_state(c).as_dict()) == state_tuple(oracle.firdemod_state(hs[c])), (case, c)
             oracle.lib.fmo_firdemod_free(hs[c])
+        kn = fd.kernel_name().split("::")[-1].split("<")[0]
+        kernels[kn] = kernels.get(kn, 0) + 1
         fd.close()
+    print("fused fuzz: %d cases, %d outside the domain, kernels %s" % (n_cases, n_refused, kernels))
+    assert n_refused * 2 <= n_cases, (n_refused, kernels)           # the fuzz must mostly RUN ...
+    if n_cases >= 30:                                               # ... and reach the LDS-array kernel and the register forms
+        assert "fmd_firdemod_kernel" in kernels and sum(v for k, v in kernels.items() if "reg" in k) >= n_cases // 8, kernels
 
 
 @pytest.mark.gpu
