@@ -11,7 +11,7 @@ instruction: session r05g), not pipe time -- a SIMD-32 starts a 2-clock instruct
     launch_cycles   = SQ_BUSY_CYCLES / 32
     valu_issue_frac = SQ_INSTS_VALU x w / 1024 / launch_cycles    w = average issue clocks per vector instruction of the kernel's rounds, from the
                       SHIPPED code object (tools/valu_weights.py: 2 clocks add / logic / f32 add-mul, 8 v_rcp_f32, 4 everything else; ~3.0 here)
-    salu_issue_frac = SQ_INSTS_SALU x 4.7 / 1024 / launch_cycles  (an s_add_u32 costs a SIMD 2.23 ns = 4.7 clocks at 8 waves: profiles/r04_salubench.txt)
+    salu_issue_frac = SQ_INSTS_SALU x 4.7 / 1024 / launch_cycles  (an s_add_u32 costs a SIMD 2.23 ns = 4.7 clocks at 8 waves: profiles/archive/r04_salubench.txt)
     mfma_busy_frac  = SQ_VALU_MFMA_BUSY_CYCLES / 1024 / launch_cycles   (shader clocks the matrix pipes were busy, summed over SIMDs)
 `bound` in bench.py = the largest of (HBM fraction of the launch, valu_issue_frac, salu_issue_frac, mfma_busy_frac)."""
 import json, os, sys

@@ -2,7 +2,7 @@
 """Average issue cost (shader clocks on a SIMD-32 vector pipe) of the vector instructions in a kernel's hot code, from the SHIPPED code
 object -- the weight scripts/summarize_bounds.py multiplies SQ_INSTS_VALU with to turn an instruction count into vector-pipe time.
 
-Cost classes (issue cycles, tools/valubench.hip on one MI355X, profiles/r04_valubench.txt; a wave64 instruction takes 2 clocks on the
+Cost classes (issue cycles, tools/valubench.hip on one MI355X, profiles/archive/r04_valubench.txt; a wave64 instruction takes 2 clocks on the
 SIMD-32 at full rate):
     2 clocks  v_add/sub[rev]_{u32,f32}, v_mul_f32, v_and/or/xor/not, v_lshrrev, v_ashrrev, v_mov_b32 (plain), v_bitop3_b32 -- abs / neg / clamp
               modifiers are free

@@ -98,7 +98,7 @@ KERNEL(k_add_lshl,  I8S("v_add_lshl_u32", ", %8, ", "2"))
 KERNEL(k_lshl_or,   I8S("v_lshl_or_b32", ", 16, ", "%9"))
 
 // packed f32 (two floats per 64-bit register pair).  Round 4's versions of these three kernels typed the accumulators `double`
-// and reported 0.28x an add -- not a plausible issue rate (profiles/r04_valubench.txt); round 5: float2 operands as in
+// and reported 0.28x an add -- not a plausible issue rate (profiles/archive/r04_valubench.txt); round 5: float2 operands as in
 // tools/pkbench.hip, finite values that stay finite (b = 1 +- 2^-23, c tiny), and tools/valubench_check.sh asserts from the
 // emitted ISA that each loop body holds exactly eight of the named instruction.
 typedef float vb_f2 __attribute__((ext_vector_type(2)));
