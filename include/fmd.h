@@ -158,11 +158,27 @@ int fmd_demod_set_block_len(fmd_demod *d, size_t block_bytes);
  * libm (the function the reference calls) and, if the truncated value differs, the audio sample (in the device
  * output buffer the launch wrote, which must still be allocated) or the carried partial sum is patched.
  * Outside that band the two results are provably equal.  The HOST entry points and fmd_demod_get_state do this
- * themselves before returning; after fmd_demod_demodulate_device call it before reading the output.  Only the MOST
- * RECENT launch's output buffer is ever written by a patch (it must still be allocated); a sample of an OLDER launch
- * that turns out to need one (probability ~2^-36 per reference call) makes this function return FMD_ERR_HIP instead of
- * touching memory the caller may have reused: for the strict bit-exactness guarantee call it after every launch. */
+ * themselves before returning; after fmd_demod_demodulate_device call it before reading the output.  Only the output
+ * buffers of the TWO most recent launches are ever written by a patch (they must still be allocated; round 5: the most recent
+ * one only); a sample of an OLDER launch that turns out to need one (probability ~2^-36 per reference call) makes this function
+ * return FMD_ERR_HIP instead of touching memory the caller may have reused: for the strict bit-exactness guarantee call it --
+ * or fmd_demod_check_prev, which does not serialise -- for every launch. */
 int fmd_demod_check(fmd_demod *d);
+
+/* The same completion point ONE LAUNCH BACK (round 6): with launches 1 ... n enqueued through fmd_demod_demodulate_device, waits
+ * until launch n - 1 has completed -- not for launch n -- and settles ITS f64 samples, so that the reference's cadence
+ *     loop { buf = read_sync(); audio = demod.demodulate(buf); output(audio); }        (simple_fm.rs:150-156)
+ * runs as  enqueue(buf n); fmd_demod_check_prev(); output(audio n - 1);  with the GPU never idle between launches and the strict
+ * bit-exactness guarantee intact (fmd_demod_check after every launch serialises host and device: ~9 % at the headline
+ * configuration).  How: launch n cannot start before launch n - 1 has completed, so its first tile posts "n - 1 is done" together
+ * with the head of n - 1's report buffer into host-mapped memory; the two most recent launches report into buffers of their own.
+ * Contract: until a launch has been settled by this function or by fmd_demod_check, (a) its OUTPUT buffer stays allocated and
+ * unread -- a patch goes into the buffer of the launch that produced the sample, for the last TWO launches -- and (b) its INPUT
+ * buffer stays unmodified: in the one case where launch n - 1's corrected sample lies in the partial sum it carried into launch n
+ * (probability ~2^-36 per reference call), launch n is run again on the corrected state, inside this call.  Returns FMD_OK at
+ * once when fewer than two launches are outstanding; falls back to fmd_demod_check where no post is coming (generic kernel).
+ * Call fmd_demod_check after the LAST launch of a run.  (fmd_firdemod / the pipelined sink have their own completion points.) */
+int fmd_demod_check_prev(fmd_demod *d);
 
 /* Diagnostics of the above: f64 samples that fell into the guard band / whose value had to be patched. */
 int fmd_demod_f64_stats(const fmd_demod *d, uint64_t *guarded, uint64_t *patched);
@@ -218,6 +234,8 @@ int fmd_fir_reset(fmd_fir *f);
  * |tap| <= 127: eight outputs per operand column), 2 = two digits (|tap| <= 2047: four), 0 = the vector-pipe kernel
  * (decim > 64 or a filter too long for the matrix-core form). */
 int fmd_fir_tap_digits(const fmd_fir *f);
+/* Name of the kernel this handle launches, as `rocprofv3 --kernel-trace` prints it (see fmd_demod_last_kernel). */
+int fmd_fir_kernel_name(const fmd_fir *f, char *name, size_t cap);
 /* Complex outputs one call of nbytes can produce per channel (upper bound). */
 size_t fmd_fir_out_cap(uint32_t n_taps, uint32_t decim, size_t nbytes);
 /* HOST buffers: iq [n_channels][nbytes]; out [n_channels][out_cap][2] int32 (re, im);
@@ -370,6 +388,10 @@ int fmd_version(void);                     /* FMD_VERSION_MAJOR * 1000 + FMD_VER
  * or, before the first one, what a bank fed whole read_sync buffers will run. */
 int fmd_demod_tiling(const fmd_demod *d, uint32_t *audio_per_tile, uint32_t *lds_bytes,
                      uint32_t *block_threads);
+/* Which plan chose the LDS kernels' tile (diagnostics for measured rows): 0 = the caller (fmd_demod_set_tiling), 1 = the largest
+ * tile that keeps 8 blocks per CU resident (20 KB), 2 = the 15.5 ... 17.3 KB window of the rows on the memory side; negative on
+ * a null handle.  (The register-streaming kernel of downsample 2 / 4 has a tiling of its own: fmd_demod_tiling reports it.) */
+int fmd_demod_tiling_plan(const fmd_demod *d);
 /* Name of the kernel the handle's most recent launch ran, as `rocprofv3 --kernel-trace` prints
  * it (e.g. "fmd_tk::fmd_demod_tile_kernel<5, 2>"); "" before the first launch.  bench.py
  * quotes it in `roofline.kernel` instead of a constant. */

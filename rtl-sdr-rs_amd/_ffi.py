@@ -72,6 +72,7 @@ PROTOTYPES = {
     "fmd_demod_demodulate_device": (C.c_int, [_vp, _vp, _sz, _vp, _sz, _vp, _vp]),
     "fmd_demod_set_block_len": (C.c_int, [_vp, _sz]),
     "fmd_demod_check": (C.c_int, [_vp]),
+    "fmd_demod_check_prev": (C.c_int, [_vp]),
     "fmd_demod_f64_stats": (C.c_int, [_vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "fmd_demod_last_out_len": (C.c_int, [_vp, _szp]),
     "fmd_host_alloc": (C.c_int, [_sz, C.POINTER(_vp)]),
@@ -85,6 +86,7 @@ PROTOTYPES = {
     "fmd_device_count": (C.c_int, [C.POINTER(C.c_int)]),
     "fmd_version": (C.c_int, []),
     "fmd_demod_tiling": (C.c_int, [_vp, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
+    "fmd_demod_tiling_plan": (C.c_int, [_vp]),
     "fmd_demod_last_kernel": (C.c_int, [_vp, C.c_char_p, C.c_size_t]),
     "fmd_demod_set_tiling": (C.c_int, [_vp, C.c_uint32]),
     "fmd_fir_new": (C.c_int, [_i16p, C.c_uint32, C.c_uint32, C.POINTER(DeviceConfig), C.POINTER(_vp)]),
@@ -108,6 +110,7 @@ PROTOTYPES = {
     "fmd_firdemod_f64_stats": (C.c_int, [_vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "fmd_firdemod_tiling": (C.c_int, [_vp, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
     "fmd_firdemod_kernel_name": (C.c_int, [_vp, C.c_char_p, C.c_size_t]),
+    "fmd_fir_kernel_name": (C.c_int, [_vp, C.c_char_p, C.c_size_t]),
     "fmd_sink_new": (C.c_int, [C.POINTER(DemodConfig), C.c_uint32, C.POINTER(C.c_int32), C.c_uint32, _sz, C.c_uint32, _vp, _vp, C.POINTER(_vp)]),
     "fmd_sink_free": (None, [_vp]),
     "fmd_sink_acquire": (C.c_int, [_vp, C.POINTER(_vp)]),

@@ -13,6 +13,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <ctime>
 #include <map>
 #include <new>
 #include <utility>
@@ -68,6 +69,7 @@ struct fmd_demod {
     uint32_t C = 0;
     int device = 0;
     uint32_t lp_cap = 0, raw_cap = 0;
+    uint32_t tiling_plan = 0;             // which plan chose the LDS tile: 0 caller's (FMD_KT), 1 the 20 KB budget, 2 the 15.5 ... 17.3 KB window (choose_tiling)
     // register-streaming kernel (fmd_demod_stream_kernel: even downsample <= 16, whole-dword windows): its own, larger tiling
     bool stream_ok = false;
     FmdRates rs{};                        // r with the streaming kernel's audio samples per tile
@@ -80,8 +82,22 @@ struct fmd_demod {
     uint32_t allow_fast = 2;              // FMD_FAST: 0 general prologue only, 1 closed form only, 2 (default) table, else closed form (A/B)
     FmdChanState* d_state[2] = {nullptr, nullptr};
     int cur = 0;
-    FmdExcBuf* d_exc = nullptr;           // device error word + guarded f64 samples (fmd_kernels.h)
-    uint32_t* h_head = nullptr;           // page-locked copy of its first 16 bytes (fmd_demod_check reads it behind ONE stream synchronisation)
+    // device error word + guarded f64 samples (fmd_kernels.h): TWO buffers, launch `seq` reports into d_exc[seq & 1] -- the
+    // records of launch n - 1 stay apart from those of launch n, which is what lets fmd_demod_check_prev settle buffer n - 1
+    // while launch n runs (round 6)
+    FmdExcBuf* d_exc = nullptr;
+    uint32_t* h_head = nullptr;           // page-locked copy of both buffers' first 16 bytes (fmd_demod_check reads them behind ONE stream synchronisation)
+    uint32_t* h_mbox = nullptr;           // host-mapped mailbox the kernels post into (FmdLaunch::mbox): one 8-byte word, low = seq known complete, high = report flags
+    uint32_t* d_mbox = nullptr;           // ... its device address
+    // what the last two launches were (index seq & 1): enough to patch their output buffers and, for the one case that needs it
+    // -- a guarded sample of launch n - 1 in the carried partial sum that launch n has already consumed -- to run launch n again
+    struct Pending {
+        uint32_t seq = 0;
+        bool valid = false, settled = true;
+        bool posts = false;               // the launch posts its predecessor's completion (tile / streaming kernels, the handle's own buffers)
+        hipStream_t stream = nullptr;
+        FmdLaunch L{};
+    } pend[2];
     FmdExcBuf* exc_override = nullptr;    // fmd_internal_set_report_buffer (pipelined sink: one buffer per in-flight launch)
     double f64_guard = 0x1p-20;           // fixed in the shipped library; FMD_F64_GUARD_LOG2 in the experiment build (tests widen it to exercise the patch path)
     int32_t f64_skew = 0;                 // FMD_F64_SKEW, honoured by -DFMD_EXPERIMENT builds only
@@ -104,6 +120,7 @@ int choose_tiling(fmd_demod* d, uint32_t kt_req)
 {
     FmdRates& r = d->r;
     uint32_t kt = kt_req;
+    d->tiling_plan = 0;
     if (kt == 0) {
         // Largest tiles that keep 8 blocks per CU resident (160 KiB LDS / 8), then, among those, the tiling
         // with the least issue work per input byte.  The work of one tile is quantised: a wave handles whole
@@ -120,6 +137,13 @@ int choose_tiling(fmd_demod* d, uint32_t kt_req)
         // rows (downsample <= 8, the odd factors up to 9) still want the largest tile.  So: plan with the large budget, price the
         // result, and plan again with the small one if the row is on the memory side.
         // plan(lo, hi): the tiling with the least issue work per input byte among those whose LDS need lies in (lo, hi]; 0 = none
+        // The figures of the ONE part this planner is tuned for (MI355X): 256 CUs x 4 SIMDs, 2.4 GHz, 8 TB/s, ~3 shader clocks per
+        // wave-instruction; the LDS windows are whole allocation granules of 1280 bytes (named, not inlined).
+        constexpr double kLdsBudget8 = 20480.0;              // 160 KiB / 8 blocks per CU: 16 granules
+        constexpr double kLdsSmallLo = 15500.0, kLdsSmallHi = 17300.0;   // the memory-side rows' window (profiles/r05_experiments.md 9)
+        constexpr double kClocksPerInstr = 3.0, kSimdsPerCu = 4.0;
+        constexpr double kBytesPerClockCu = 8.0e12 / 256.0 / 2.4e9;      // HBM spec over the CUs at the shader clock: ~13 bytes
+        constexpr double kVectorShareForSmallTiles = 0.85;   // below this vector-side share of the memory time the row is "on the memory side"
         auto plan = [&](double lo, double hi, double* per_byte_out) -> uint32_t {
             double best = 0.0;
             uint32_t pick = 0;
@@ -128,7 +152,7 @@ int choose_tiling(fmd_demod* d, uint32_t kt_req)
                 if ((uint64_t)r.sr * (k + 2) >= (1u << 24)) break;
                 const uint32_t lp = fmd_tile_lp_cap(r), raw = fmd_tile_raw_cap(r);
                 const double lds = (double)raw + 2.0 * (lp + r.fr / r.sr + 2) + 32.0;
-                if (lds > hi && k > 1) break;
+                if (lds > hi && (k > 1 || lo > 0.0)) break;  // (the smallest tile is exempt from the bound only where there is no other plan)
                 if (lds <= lo) continue;
                 const uint64_t cnt = ((uint64_t)k * r.fr + r.sr - 1) / r.sr + 1;        // decimated samples formed
                 const uint64_t rounds = (cnt + 126) / 127, per_wave = (rounds + waves - 1) / waves;
@@ -147,13 +171,14 @@ int choose_tiling(fmd_demod* d, uint32_t kt_req)
             return pick;
         };
         double per_byte = 0.0;
-        kt = plan(0.0, 20480.0, &per_byte);
+        kt = plan(0.0, kLdsBudget8, &per_byte);
         if (kt == 0) kt = 1;
+        d->tiling_plan = 1;
         // per_byte = wave-instructions per input byte of that tiling: x 3 clocks / 4 SIMDs = vector clocks per byte and CU; the memory
         // side: 1 / 13 clocks per byte and CU (8 TB/s over 256 CUs at 2.4 GHz)
-        if (per_byte * 0.75 * 13.0 < 0.85) {
-            const uint32_t k2 = plan(15500.0, 17300.0, nullptr);
-            if (k2) kt = k2;
+        if (per_byte * (kClocksPerInstr / kSimdsPerCu) * kBytesPerClockCu < kVectorShareForSmallTiles) {
+            const uint32_t k2 = plan(kLdsSmallLo, kLdsSmallHi, nullptr);
+            if (k2) { kt = k2; d->tiling_plan = 2; }
         }
     }
     r.kt = kt;
@@ -279,8 +304,10 @@ int enqueue(fmd_demod* d, const void* d_iq, size_t nbytes, void* d_out, size_t o
     L.out = static_cast<int16_t*>(d_out);
     L.out_stride = out_cap;
     L.out_len = static_cast<uint32_t*>(d_out_len);
-    L.exc = d->exc_override ? d->exc_override : d->d_exc;
+    L.exc = d->exc_override ? d->exc_override : d->d_exc + ((d->seq + 1u) & 1u);
     L.err = &L.exc->err;
+    L.exc_prev = d->exc_override ? nullptr : d->d_exc + (d->seq & 1u);
+    L.mbox = d->exc_override ? nullptr : d->d_mbox;
     L.f64_guard = d->f64_guard;
     L.seq = d->seq + 1;
 #ifdef FMD_EXPERIMENT
@@ -323,6 +350,11 @@ int enqueue(fmd_demod* d, const void* d_iq, size_t nbytes, void* d_out, size_t o
     }
     d->order.after(stream);
     d->seq += 1;
+    {
+        fmd_demod::Pending& pd = d->pend[d->seq & 1u];
+        pd.seq = d->seq; pd.valid = true; pd.settled = false; pd.stream = stream; pd.L = L;
+        pd.posts = L.mbox != nullptr && d->last_kernel.family != FMD_KERNEL_GENERIC;
+    }
     d->cur ^= 1;
     advance_classes(d, nbytes, plans);
     return FMD_OK;
@@ -416,9 +448,105 @@ int fmd_internal_resolve_exc(FmdExcBuf* d_exc, int32_t R, uint32_t host_seq, uin
 }
 
 namespace {
+
+// Run launch `pd` again (same arguments, same stream): see settle_buffer.
+int replay_launch(fmd_demod* d, fmd_demod::Pending& pd)
+{
+    FmdKernelId used;
+    if (d->last_kernel.family == FMD_KERNEL_GENERIC) HIP_TRY(fmd_launch_generic(pd.L, pd.stream, &used));
+    else HIP_TRY(fmd_launch_tile(pd.L, pd.stream, &used));
+    HIP_TRY(hipStreamSynchronize(pd.stream));
+    return FMD_OK;
+}
+
+// Settle the records of ONE of the handle's two report buffers (the caller has made sure the launches that wrote it have
+// completed).  newest = d->seq.  A record of the newest launch is patched as before (its output buffer -- or the caller's host
+// copy -- and the current state); a record of launch newest - 1 is patched in THAT launch's output buffer (still allocated: the
+// contract of fmd_demod_check_prev), and one in its carried partial sum -- which launch `newest` has consumed by now -- in the
+// state launch `newest` read, after which launch `newest` is RUN AGAIN: its inputs (the caller's input buffer, the state of
+// launch newest - 1 in the other half of the ping-pong) are untouched until it has been checked, so the second run is the
+// launch the reference would have made.  Anything older is reported, not touched (as before).
+int settle_buffer(fmd_demod* d, FmdExcBuf* buf, int16_t* host_out, size_t host_cap, bool* need_replay)
+{
+    uint32_t head[4] = {0, 0, 0, 0};                        // err, count, guarded_total, pad
+    HIP_TRY(hipMemcpy(head, buf, sizeof(head), hipMemcpyDeviceToHost));
+    if (head[0] & ~FMD_DEVERR_EXC_CAP) { set_err("device-side sizing assertion failed (bits 0x%x)", head[0]); return FMD_ERR_HIP; }
+    if (head[1] == 0) return FMD_OK;
+    const uint32_t n = head[1] < FMD_EXC_CAP ? head[1] : FMD_EXC_CAP, newest = d->seq;
+    std::vector<FmdF64Exc> recs(n);
+    HIP_TRY(hipMemcpy(recs.data(), buf->rec, n * sizeof(FmdF64Exc), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemset(buf, 0, 16));
+    d->f64_guarded += head[1];
+    int rc = FMD_OK;
+    // several guarded samples may share one audio group (block_len mode): their corrections add up
+    std::map<std::pair<uint32_t, uint64_t>, std::pair<int64_t, const FmdF64Exc*>> groups;   // (seq, out_elem) -> (delta, record)
+    for (const FmdF64Exc& e : recs) {
+        const int16_t want = (int16_t)host_polar_f64(e.cr, e.ci), have = (int16_t)e.d_gpu;
+        if (want == have) continue;
+        d->f64_patched += 1;
+        const int delta = (int)want - (int)have;
+        if (e.k >= 0) {
+            auto& g = groups[{e.seq, e.out_elem}];
+            g.first += delta; g.second = &e;
+            continue;
+        }
+        // the carried partial sum: the state launch e.seq WROTE
+        FmdChanState* st = nullptr;
+        if (e.seq == newest) st = d->d_state[d->cur];
+        else if (e.seq + 1u == newest && d->pend[newest & 1u].valid && !d->exc_override) { st = d->d_state[d->cur ^ 1]; *need_replay = true; }
+        if (!st) {
+            set_err("a guarded f64 sample of launch %u (channel %u) lies in the carried partial sum and later launches have "
+                    "already consumed it: call fmd_demod_check (or fmd_demod_check_prev) for every *_device launch", e.seq, e.channel);
+            rc = FMD_ERR_HIP;
+            continue;
+        }
+        int32_t now = 0;
+        int32_t* p = &st[e.channel].now_lpr;
+        HIP_TRY(hipMemcpy(&now, p, sizeof(now), hipMemcpyDeviceToHost));
+        now += delta;
+        HIP_TRY(hipMemcpy(p, &now, sizeof(now), hipMemcpyHostToDevice));
+    }
+    for (const auto& kv : groups) {
+        const FmdF64Exc& e = *kv.second.second;
+        const int16_t fixed = (int16_t)((e.sum + (int)kv.second.first) / d->r.R);         // low_pass_real, simple_fm.rs:421
+        if (host_out && e.seq == newest) host_out[(size_t)e.channel * host_cap + (size_t)e.k] = fixed;
+        else if (e.seq == newest || e.seq + 1u == newest) HIP_TRY(hipMemcpy((void*)(uintptr_t)e.out_elem, &fixed, sizeof(fixed), hipMemcpyHostToDevice));
+        else {
+            // Nothing ties the address saved in an OLDER launch's record to memory that still holds that launch's audio:
+            // the caller may have reused the buffer for a later launch (a write would corrupt newer audio) or freed it.
+            // Only the last TWO launches' buffers are ever written; for anything older the caller is told.
+            set_err("a guarded f64 sample of launch %u (channel %u, audio sample %d) needs the host-libm value, but two or more "
+                    "launches have been enqueued since: call fmd_demod_check (or fmd_demod_check_prev) for every *_device launch",
+                    e.seq, e.channel, e.k);
+            rc = FMD_ERR_HIP;
+        }
+    }
+    if (head[0] & FMD_DEVERR_EXC_CAP) {
+        set_err("more than %u guarded f64 samples in one report buffer since the last check: some were not re-evaluated", FMD_EXC_CAP);
+        rc = FMD_ERR_HIP;
+    }
+    return rc;
+}
+
+// Everything the handle has enqueued has completed (the caller synchronised): settle both report buffers, the older launch's
+// first.  host_out: the caller's host copy of the NEWEST launch's output, or nullptr.
 int resolve_device_reports(fmd_demod* d, int16_t* host_out, size_t host_cap)
 {
-    return fmd_internal_resolve_exc(d->d_exc, d->r.R, d->seq, d->seq, d->d_state[d->cur], host_out, host_cap, &d->f64_guarded, &d->f64_patched);
+    if (d->exc_override)                                     // (the pipelined sink owns its report buffers and settles them itself)
+        return fmd_internal_resolve_exc(d->d_exc, d->r.R, d->seq, d->seq, d->d_state[d->cur], host_out, host_cap, &d->f64_guarded, &d->f64_patched);
+    const uint32_t newest = d->seq;
+    bool replay = false;
+    int rc = settle_buffer(d, d->d_exc + ((newest + 1u) & 1u), nullptr, 0, &replay);     // launch newest - 1 (and older ones of its parity)
+    if (rc == FMD_OK && replay) {
+        // launch `newest` ran on a carried sum that has just been corrected: drop what it reported and run it again
+        HIP_TRY(hipMemset(d->d_exc + (newest & 1u), 0, 16));
+        rc = replay_launch(d, d->pend[newest & 1u]);
+        if (rc == FMD_OK && host_out) { set_err("internal: replay with a host copy"); rc = FMD_ERR_HIP; }   // (host entry points settle every call: unreachable)
+    }
+    bool again = false;
+    const int rc2 = settle_buffer(d, d->d_exc + (newest & 1u), host_out, host_cap, &again);
+    d->pend[0].settled = d->pend[1].settled = true;
+    return rc ? rc : rc2;
 }
 }  // namespace
 
@@ -524,25 +652,26 @@ int fmd_demod_new(const fmd_demod_config* config, const fmd_device_config* dev, 
     // is 24 / 40 / 48 bytes: strided 16-byte loads touch 1.5 - 3 x the cache lines and measured 25 - 70 % SLOWER than the
     // LDS-DMA kernel).  LDS only holds the discriminator samples there, so the tile is sized for the work per block: the
     // least wave-instructions per audio sample under the kernel's quantisation -- whole rounds of 127 decimated samples
-    // per wave (at most FMD_STREAM_MAX_ROUNDS, straight-line code), the busiest of the 4 waves sets the pace, one
+    // per wave (at most FMD_STREAM_MAX_ROUNDS(downsample), straight-line code), the busiest of the 4 waves sets the pace, one
     // resampler pass per 256 audio samples, a fixed cost per tile.
     d->stream_ok = false;
     if ((r.D == 2u || r.D == 4u) && fmd_knob_u32("FMD_STREAM", 1) != 0u) {   // (knob: A/B in the experiment build)
         FmdRates rs = r;
         uint32_t kts = fmd_knob_u32("FMD_KT_STREAM", 0);
-        const uint32_t cap_cnt = 4u * 127u * FMD_STREAM_MAX_ROUNDS - 8u;
+        const uint32_t nw = 4u;                              // waves per block (one wave per tile: measured in round 6, slower, deleted)
+        const uint32_t cap_cnt = nw * 127u * FMD_STREAM_MAX_ROUNDS(r.D) - 8u;
         if (kts == 0u) {
             double best = 0.0;
             for (uint32_t k = 64; k <= 4096u; k += 32u) {
                 rs.kt = k;
                 if (fmd_tile_lp_cap(rs) > cap_cnt || (uint64_t)rs.sr * (k + 2) >= (1u << 24)) break;
                 const uint64_t cnt = ((uint64_t)k * r.fr + r.sr - 1) / r.sr + 1;
-                const uint64_t rounds = (cnt + 126) / 127, per_wave = (rounds + 3) / 4, passes = (k + 255) / 256;
+                const uint64_t rounds = (cnt + 126) / 127, per_wave = (rounds + nw - 1) / nw, passes = (k + 64 * nw - 1) / (64 * nw);
                 // (the fixed cost of a tile: downsample 2 -- twice the rounds per byte, half the bytes per round -- measured best at the
                 //  largest tile its rounds admit, 384 instead of 256 audio samples at 500 k -> 32 k: -2.5 %; downsample 4 at the model's
                 //  choice: profiles/r05_experiments.md 15)
                 const double fixed = r.D == 2u ? 250.0 : 150.0;
-                const double work = (double)per_wave * 4.0 * 100.0 + (double)passes * 4.0 * (70.0 + 6.0 * (double)(r.fr / r.sr)) + 4.0 * fixed;
+                const double work = (double)per_wave * nw * 100.0 + (double)passes * nw * (70.0 + 6.0 * (double)(r.fr / r.sr)) + nw * fixed;
                 const double per_audio = work / (double)k;
                 if (kts == 0u || per_audio < best) { best = per_audio; kts = k; }
             }
@@ -587,9 +716,12 @@ int fmd_demod_new(const fmd_demod_config* config, const fmd_device_config* dev, 
         if ((e = hipMalloc(&d->d_state[i], sbytes)) != hipSuccess) return fail(e, "hipMalloc(state)");
         if ((e = hipMemset(d->d_state[i], 0, sbytes)) != hipSuccess) return fail(e, "hipMemset(state)");
     }
-    if ((e = hipMalloc(&d->d_exc, sizeof(FmdExcBuf))) != hipSuccess) return fail(e, "hipMalloc(reports)");
-    if ((e = hipMemset(d->d_exc, 0, sizeof(FmdExcBuf))) != hipSuccess) return fail(e, "hipMemset(reports)");
-    if ((e = hipHostMalloc(reinterpret_cast<void**>(&d->h_head), 16, hipHostMallocDefault)) != hipSuccess) return fail(e, "hipHostMalloc(report head)");
+    if ((e = hipMalloc(&d->d_exc, 2 * sizeof(FmdExcBuf))) != hipSuccess) return fail(e, "hipMalloc(reports)");
+    if ((e = hipMemset(d->d_exc, 0, 2 * sizeof(FmdExcBuf))) != hipSuccess) return fail(e, "hipMemset(reports)");
+    if ((e = hipHostMalloc(reinterpret_cast<void**>(&d->h_head), 32, hipHostMallocDefault)) != hipSuccess) return fail(e, "hipHostMalloc(report head)");
+    if ((e = hipHostMalloc(reinterpret_cast<void**>(&d->h_mbox), 64, hipHostMallocMapped)) != hipSuccess) return fail(e, "hipHostMalloc(mailbox)");
+    memset(d->h_mbox, 0, 64);
+    if ((e = hipHostGetDevicePointer(reinterpret_cast<void**>(&d->d_mbox), d->h_mbox, 0)) != hipSuccess) return fail(e, "hipHostGetDevicePointer(mailbox)");
     if ((e = hipStreamCreateWithFlags(&d->stream, hipStreamNonBlocking)) != hipSuccess) return fail(e, "hipStreamCreate");
     if ((e = hipDeviceSynchronize()) != hipSuccess) return fail(e, "hipDeviceSynchronize");
     *out = d;
@@ -604,6 +736,7 @@ void fmd_demod_free(fmd_demod* d)
     for (int i = 0; i < 2; ++i) if (d->d_state[i]) (void)hipFree(d->d_state[i]);
     if (d->d_exc) (void)hipFree(d->d_exc);
     if (d->h_head) (void)hipHostFree(d->h_head);
+    if (d->h_mbox) (void)hipHostFree(d->h_mbox);
     d->order.destroy();
     if (d->d_chan_class) (void)hipFree(d->d_chan_class);
     if (d->d_iq) (void)hipFree(d->d_iq);
@@ -621,7 +754,9 @@ int fmd_demod_reset(fmd_demod* d)
     HIP_TRY(hipMemset(d->d_state[0], 0, sbytes));
     HIP_TRY(hipMemset(d->d_state[1], 0, sbytes));
     HIP_TRY(hipMemset(d->d_exc, 0, 16));
+    HIP_TRY(hipMemset(d->d_exc + 1, 0, 16));
     HIP_TRY(hipDeviceSynchronize());
+    d->pend[0] = fmd_demod::Pending{}; d->pend[1] = fmd_demod::Pending{};
     d->cur = 0;
     d->order.reset();
     reset_classes(d);
@@ -676,9 +811,11 @@ int fmd_demod_demodulate_batch(fmd_demod* d, const uint8_t* iq, size_t nbytes, i
                                  (size_t)kmax * sizeof(int16_t), d->C, hipMemcpyDeviceToHost, d->stream));
     }
     const bool head = d->h_head && !d->exc_override;           // the report head rides behind the output copy (see fmd_demod_check)
-    if (head) { d->h_head[0] = d->h_head[1] = ~0u; HIP_TRY(hipMemcpyAsync(d->h_head, d->d_exc, 16, hipMemcpyDeviceToHost, d->stream)); }
+    const bool prev_clean = d->pend[(d->seq + 1u) & 1u].settled;      // (a caller may mix the host and the _device entry points)
+    if (head) { d->h_head[0] = d->h_head[1] = ~0u; HIP_TRY(hipMemcpyAsync(d->h_head, d->d_exc + (d->seq & 1u), 16, hipMemcpyDeviceToHost, d->stream)); }
     HIP_TRY(hipStreamSynchronize(d->stream));
-    if (head && d->h_head[0] == 0u && d->h_head[1] == 0u) return FMD_OK;
+    if (head && prev_clean && d->h_head[0] == 0u && d->h_head[1] == 0u) { d->pend[d->seq & 1u].settled = true; return FMD_OK; }
+    if (!prev_clean) HIP_TRY(hipDeviceSynchronize());
     return resolve_device_reports(d, out, out_cap);   // device assertions + guarded f64 samples (patched in `out`)
 }
 
@@ -736,17 +873,68 @@ int fmd_demod_check(fmd_demod* d)
 {
     if (!d) { set_err("null argument"); return FMD_ERR_INVALID_ARG; }
     ON_DEVICE(d->device);
-    // The common case -- no device assertion, no guarded f64 sample -- costs one stream synchronisation: the head of the report
-    // buffer is copied to page-locked memory BEHIND the handle's last launch on that launch's stream (the library orders a
+    // The common case -- no device assertion, no guarded f64 sample -- costs one stream synchronisation: the heads of the report
+    // buffers are copied to page-locked memory BEHIND the handle's last launch on that launch's stream (the library orders a
     // handle's launches across streams itself, so that stream's completion is the handle's).  Anything else takes the
     // device-wide path below.
     if (d->order.have_last && d->h_head && !d->exc_override) {
-        d->h_head[0] = d->h_head[1] = ~0u;
-        hipError_t e = hipMemcpyAsync(d->h_head, d->d_exc, 16, hipMemcpyDeviceToHost, d->order.last);
+        const bool both = !d->pend[(d->seq + 1u) & 1u].settled;          // launch seq - 1 was never checked: its buffer too
+        for (int i = 0; i < 8; ++i) d->h_head[i] = i < 4 || both ? ~0u : 0u;
+        hipError_t e = hipMemcpyAsync(d->h_head, d->d_exc + (d->seq & 1u), 16, hipMemcpyDeviceToHost, d->order.last);
+        if (e == hipSuccess && both) e = hipMemcpyAsync(d->h_head + 4, d->d_exc + ((d->seq + 1u) & 1u), 16, hipMemcpyDeviceToHost, d->order.last);
         if (e == hipSuccess) e = hipStreamSynchronize(d->order.last);
-        if (e == hipSuccess && d->h_head[0] == 0u && d->h_head[1] == 0u) return FMD_OK;
+        if (e == hipSuccess && d->h_head[0] == 0u && d->h_head[1] == 0u && d->h_head[4] == 0u && d->h_head[5] == 0u) {
+            d->pend[0].settled = d->pend[1].settled = true;
+            return FMD_OK;
+        }
         if (e != hipSuccess) (void)hipGetLastError();
     }
+    HIP_TRY(hipDeviceSynchronize());
+    return resolve_device_reports(d, nullptr, 0);
+}
+
+int fmd_demod_check_prev(fmd_demod* d)
+{
+    if (!d) { set_err("null argument"); return FMD_ERR_INVALID_ARG; }
+    ON_DEVICE(d->device);
+    const uint32_t newest = d->seq, target = newest - 1u;
+    fmd_demod::Pending& pn = d->pend[newest & 1u];
+    fmd_demod::Pending& pp = d->pend[target & 1u];
+    if (newest < 2u || !pp.valid || pp.seq != target || pp.settled) return FMD_OK;          // nothing older in flight
+    // Launch `newest` posts the completion of launch `target` (and the head of its report buffer) when its first tile runs:
+    // spin on the host-mapped word.  No post is coming if the newest launch is not one that posts (generic kernel, a caller-owned
+    // report buffer): then this is fmd_demod_check.
+    if (!pn.valid || pn.seq != newest || !pn.posts || !d->h_mbox) return fmd_demod_check(d);
+    const uint64_t* const m = reinterpret_cast<const uint64_t*>(d->h_mbox);
+    // (the wait is a plain spin on the host-mapped word; only after a millisecond without the post does it start asking the runtime
+    //  -- once per further millisecond -- whether the newest launch is still running at all: a failed launch would never post)
+    uint64_t spins = 0, word;
+    struct timespec ts0;
+    clock_gettime(CLOCK_MONOTONIC, &ts0);
+    double next_query_s = 1.0e-3;
+    while ((int32_t)((uint32_t)(word = __atomic_load_n(m, __ATOMIC_ACQUIRE)) - target) < 0) {
+        if ((++spins & 0xFFu) == 0u) {
+            struct timespec ts;
+            clock_gettime(CLOCK_MONOTONIC, &ts);
+            const double waited = (double)(ts.tv_sec - ts0.tv_sec) + 1e-9 * (double)(ts.tv_nsec - ts0.tv_nsec);
+            if (waited >= next_query_s) {
+                next_query_s = waited + 1.0e-3;
+                const hipError_t q = hipStreamQuery(pn.stream);
+                if (q == hipSuccess) {                       // the newest launch has completed too -- the post is there, or never comes
+                    if ((int32_t)((uint32_t)(word = __atomic_load_n(m, __ATOMIC_ACQUIRE)) - target) < 0) return fmd_demod_check(d);
+                    break;
+                }
+                if (q != hipErrorNotReady) { set_err("hipStreamQuery: %s", hipGetErrorString(q)); (void)hipGetLastError(); return FMD_ERR_HIP; }
+            }
+        }
+#if defined(__x86_64__) || defined(__i386__)
+        __builtin_ia32_pause();
+#endif
+    }
+    if ((uint32_t)word == target && (word >> 32) == 0u) { pp.settled = true; return FMD_OK; }   // the common case: nothing to settle
+    // Something was reported by launch `target` (a guarded f64 sample, or a device assertion).  The rare path waits for the newest
+    // launch as well and settles both buffers, the older one first (settle_buffer: patches go into the output buffer of the launch
+    // that produced them -- both are still the caller's to keep -- and a corrected carried sum re-runs the newest launch).
     HIP_TRY(hipDeviceSynchronize());
     return resolve_device_reports(d, nullptr, 0);
 }
@@ -829,6 +1017,8 @@ int fmd_demod_tiling(const fmd_demod* d, uint32_t* audio_per_tile, uint32_t* lds
     }
     return FMD_OK;
 }
+
+int fmd_demod_tiling_plan(const fmd_demod* d) { return d ? (int)d->tiling_plan : FMD_ERR_INVALID_ARG; }
 
 int fmd_demod_last_kernel(const fmd_demod* d, char* name, size_t cap)
 {

@@ -195,6 +195,18 @@ __device__ __forceinline__ void fir_dma16(const unsigned char* g, unsigned char*
 // which lane fetches which 16 bytes.  (PMC: SQ_LDS_BANK_CONFLICT 10.5 M cycles per launch without it.)
 __device__ __forceinline__ uint32_t fir_swz_slot(uint32_t slot) { return slot ^ (((slot >> 4) & 1u) << 1); }
 
+// Round 6 (the layout every matrix-core form of this kernel runs on, unless SWZ above is chosen): the tile image is stored with the
+// four 32-byte pieces of every 128-byte column permuted by the column's index -- byte address a lives at a ^ ((a >> 3) & 0x60), i.e.
+// bits 5, 6 (the piece) are xor-ed with bits 8, 9 (the column pair).  Operand columns are 64 or 128 bytes apart, so without it the
+// lanes the LDS serves together (tools/lds_model.py) keep hitting the same 16-byte slots of the 256-byte bank row: measured with
+// tools/ldsbench.py, a fragment read cost 3.1 x a conflict-free one in the sparse two-digit form (SQ_LDS_BANK_CONFLICT 75 % of the
+// LDS-active cycles), 1.64 x in the dense two-digit form, and by the model 4 x in the dense one-digit form; with the
+// permutation (and the sparse form's half swap, fmd_fir_kswap) they are conflict-free / alternate 1 x and 2 x / conflict-free.
+// The LDS-DMA applies it for free by permuting which lane fetches which 16 bytes -- in PAIRS of lanes (32 contiguous bytes), within
+// one 128-byte line.
+__device__ __forceinline__ uint32_t fir_img(uint32_t byte_addr) { return byte_addr ^ ((byte_addr >> 3) & 0x60u); }
+__device__ __forceinline__ uint32_t fir_img_slot(uint32_t slot) { return slot ^ (((slot >> 4) & 3u) << 1); }   // the same on 16-byte slot indices
+
 // DIGITS: tap digits of the A fragments (fmd_fir_common.h).  2: a column is four outputs, lane (j, q) ends up with (re_lo, re_hi,
 // im_lo, im_hi) of output 4j + q; 1 (every |tap| <= 127): a column is EIGHT outputs, lane (j, q) ends up with (re, im) of outputs
 // 8j + 2q and 8j + 2q + 1 -- the same matrix instructions and operand reads cover twice the outputs.
@@ -206,6 +218,10 @@ __global__ void __launch_bounds__(kFirThreads, NKU <= 6 ? 8 : (NKU == 7 ? 6 : 4)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     const uint32_t tid = threadIdx.x;
+    // the permuted tile image (fir_img) under the sparse two-digit form -- config 4's.  The dense forms keep the linear image: their
+    // reads would need a permuted address per (group, chunk) -- six more live registers than their 64-register budget has (the
+    // first build spilled and ran the 8-bit filter 24 % slower: session r06b) -- and their matrix phase is hidden anyway.
+    constexpr bool IMG = DIGITS == 3;
     __builtin_amdgcn_s_setprio(3);                                  // get the loads out first (see fmd_tile_body.h)
     // Grid (8, tiles, ceil(C / 8)) always: blockIdx.x IS the XCD, which works through its own contiguous eighth of the channels
     // tile after tile (about -1 % per call against the plain mapping).  No branch in front of the LDS-DMAs: a surplus block
@@ -220,7 +236,8 @@ __global__ void __launch_bounds__(kFirThreads, NKU <= 6 ? 8 : (NKU == 7 ? 6 : 4)
     const uint32_t no = H.n_out - o0 < H.out_tile ? H.n_out - o0 : H.out_tile;
     const uint32_t w0 = H.wd_first + o0 * H.half_M;                 // first virtual dword of the tile
     // 16-byte slots the valid windows cover, in whole 64-byte chunks (the swizzle permutes within a chunk)
-    const uint32_t nq = ((((no - 1) * H.half_M + H.NP + 3u) >> 2) + 3u) & ~3u;
+    // (the permuted image moves 32-byte pieces within a 128-byte column: whole columns of 8 slots are staged)
+    const uint32_t nq = IMG ? ((((no - 1) * H.half_M + H.NP + 3u) >> 2) + 7u) & ~7u : ((((no - 1) * H.half_M + H.NP + 3u) >> 2) + 3u) & ~3u;
     // 16-byte global loads when this tile's chunks are 16-byte aligned in the caller's buffer
     const bool fast = (((H.iq + ((uint64_t)c * H.stride_w + (uint64_t)w0 - H.Hw) * 4u)) & 15u) == 0u;
     const uint32_t lane = tid & 63u, wave = tid >> 6, j = lane & 15u, q = lane >> 4;
@@ -244,7 +261,8 @@ __global__ void __launch_bounds__(kFirThreads, NKU <= 6 ? 8 : (NKU == 7 ? 6 : 4)
     for (int k = 0; k < NAF; ++k) A[k] = FIR_ABLATE(4) ? fir_i4{(int)lane, k, 1, 2} : amat[k * 64];   // (probe: what the tap fragments' L2 traffic costs)
     if (FIR_ABLATE(1)) {
     } else if (whole) {
-        const unsigned char* src = reinterpret_cast<const unsigned char*>(reinterpret_cast<const uint32_t*>((uintptr_t)H.iq) + (uint64_t)c * H.stride_w + (w0 - H.Hw)) + 16u * (SWZ ? fir_swz_slot(tid) : tid);
+        // (lane tid of DMA l writes LDS slot tid + 256 l; the image permutation only involves slot bits 1, 2, 4, 5: the same for every l)
+        const unsigned char* src = reinterpret_cast<const unsigned char*>(reinterpret_cast<const uint32_t*>((uintptr_t)H.iq) + (uint64_t)c * H.stride_w + (w0 - H.Hw)) + 16u * (SWZ ? fir_swz_slot(tid) : IMG ? fir_img_slot(tid) : tid);
         unsigned char* dst = reinterpret_cast<unsigned char*>(lds) + 1024u * wave;
         const uint32_t nfull = nq / kFirThreads, ntail = nq - nfull * kFirThreads;
         for (uint32_t l = 0; l < nfull; ++l) fir_dma16(src + (16u * kFirThreads) * l, dst + (16u * kFirThreads) * l);
@@ -259,11 +277,11 @@ __global__ void __launch_bounds__(kFirThreads, NKU <= 6 ? 8 : (NKU == 7 ? 6 : 4)
             if (i2 < nq) d = virt_chunk(L, c, w0 + 4u * i2, fast);
             if (i3 < nq) e = virt_chunk(L, c, w0 + 4u * i3, fast);
             if (i4 < nq) h = virt_chunk(L, c, w0 + 4u * i4, fast);
-            if (i0 < nq) lq[SWZ ? fir_swz_slot(i0) : i0] = a;
-            if (i1 < nq) lq[SWZ ? fir_swz_slot(i1) : i1] = b;
-            if (i2 < nq) lq[SWZ ? fir_swz_slot(i2) : i2] = d;
-            if (i3 < nq) lq[SWZ ? fir_swz_slot(i3) : i3] = e;
-            if (i4 < nq) lq[SWZ ? fir_swz_slot(i4) : i4] = h;
+            if (i0 < nq) lq[SWZ ? fir_swz_slot(i0) : IMG ? fir_img_slot(i0) : i0] = a;
+            if (i1 < nq) lq[SWZ ? fir_swz_slot(i1) : IMG ? fir_img_slot(i1) : i1] = b;
+            if (i2 < nq) lq[SWZ ? fir_swz_slot(i2) : IMG ? fir_img_slot(i2) : i2] = d;
+            if (i3 < nq) lq[SWZ ? fir_swz_slot(i3) : IMG ? fir_img_slot(i3) : i3] = e;
+            if (i4 < nq) lq[SWZ ? fir_swz_slot(i4) : IMG ? fir_img_slot(i4) : i4] = h;
         }
     }
     if (surplus) {                                                  // (rare) behind the staging loads: they write this block's LDS
@@ -282,15 +300,27 @@ __global__ void __launch_bounds__(kFirThreads, NKU <= 6 ? 8 : (NKU == 7 ? 6 : 4)
     for (int gi = 0; gi < (DIGITS == 3 ? 2 * GPW : GPW); ++gi) acc[gi] = fir_i4{0, 0, 0, 0};
     if constexpr (DIGITS == 3) {
         typedef int fir_i8 __attribute__((ext_vector_type(8)));
+        // Where the lane's 32 bytes of chunk kc live in the permuted image.  Logical address (16 g + j) * col_bytes + 128 kc + 32 q + (0 | 16)
+        // with g = wave + 4 gi: the group's share, 64 gi col_bytes, is a multiple of 1024 (col_bytes = 16 decim, decim even) and never
+        // reaches the address bits fir_img reads or flips -- so the permuted address is ONE register per chunk and half, set up once per
+        // wave, plus the group's (scalar) offset; the chunk's 128 kc rides in the instruction's immediate offset.  The lanes of the odd
+        // K quarters read their second half first (fmd_fir_kswap).
+        static_assert(NKS <= 4, "address registers of the sparse form");
+        uint32_t pa[NKS], pb[NKS];
+#pragma unroll
+        for (int kc = 0; kc < NKS; ++kc) {
+            const uint32_t a = (16u * wave + j) * L.col_bytes + 128u * kc + 32u * q + (FIR_ABLATE(6) ? 0u : 16u * (q & 1u));   // (probe, experiment build: round 5's half order -- wrong outputs, same work)
+            pa[kc] = fir_img(a) - 128u * kc;
+            pb[kc] = pa[kc] ^ 16u;
+        }
 #pragma unroll
         for (int gi = 0; gi < GPW; ++gi) {
             const uint32_t g = wave + 4u * gi;
             if (g < L.groups && 128u * g < no && !FIR_ABLATE(0)) {  // wave-uniform
-                const uint8_t* col = lb + (16u * g + j) * L.col_bytes + 32u * q;     // the lane's 32 bytes of a 128-byte chunk
 #pragma unroll
                 for (int kc = 0; kc < NKS; ++kc) {
-                    const fir_i4 b0 = *reinterpret_cast<const fir_i4*>(col + 128 * kc) ^ (int)0x80808080;          // u8 -> s8
-                    const fir_i4 b1 = *reinterpret_cast<const fir_i4*>(col + 128 * kc + 16) ^ (int)0x80808080;
+                    const fir_i4 b0 = *reinterpret_cast<const fir_i4*>(lb + pa[kc] + 64u * gi * L.col_bytes + 128 * kc) ^ (int)0x80808080;          // u8 -> s8
+                    const fir_i4 b1 = *reinterpret_cast<const fir_i4*>(lb + pb[kc] + 64u * gi * L.col_bytes + 128 * kc) ^ (int)0x80808080;
                     const fir_i8 B = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
                     // every re row keeps bytes 0 and 3 of each stream dword (index pairs (0, 3)), every im row bytes 1 and 2
                     acc[gi] = __builtin_amdgcn_smfmac_i32_16x16x128_i8(A[kc], B, acc[gi], (int)0xCCCCCCCCu, 0, 0);
@@ -308,12 +338,12 @@ __global__ void __launch_bounds__(kFirThreads, NKU <= 6 ? 8 : (NKU == 7 ? 6 : 4)
         for (int gi = 0; gi < GPW; ++gi) {
             const uint32_t g = wave + 4u * gi;
             if (g < L.groups && (DIGITS == 1 ? 128u : 64u) * g < no) {   // wave-uniform
-                const uint8_t* col = lb + (16u * g + j) * L.col_bytes + 64u * NKU * pass;
+                const uint32_t col = (16u * g + j) * L.col_bytes + 64u * NKU * pass;
 #pragma unroll
                 for (int k = 0; k < NKU; ++k) {
                     // SWZ: col is a multiple of 64, so only the low part (16q) sees the bit-5 flip of chunk j + kk
                     const uint32_t low = SWZ ? (16u * q) ^ ((((j + pass * NKU + k) >> 2) & 1u) << 5) : 16u * q;
-                    const fir_i4 B = *reinterpret_cast<const fir_i4*>(col + 64 * k + low) ^ (int)0x80808080;   // u8 -> s8
+                    const fir_i4 B = *reinterpret_cast<const fir_i4*>(lb + col + 64 * k + low) ^ (int)0x80808080;   // u8 -> s8
                     acc[gi] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A[k], B, acc[gi], 0, 0, 0);
                 }
             }
@@ -330,6 +360,14 @@ __global__ void __launch_bounds__(kFirThreads, NKU <= 6 ? 8 : (NKU == 7 ? 6 : 4)
     }
     if (FIR_ABLATE(9)) __builtin_amdgcn_s_sleep(16);                // ... or in front of the output stores
     if (FIR_ABLATE(10)) __builtin_amdgcn_s_sleep(8);
+    // Round 6: the outputs leave the wave in LANE ORDER.  The matrix instruction leaves lane (j, q) = j + 16 q with the outputs of
+    // column j -- consecutive LANES then write addresses 64 bytes apart and a store instruction reaches the memory pipeline as 64
+    // separate 16-byte pieces (sixteen 64-byte runs in four passes), which is what VERDICT r5 asked to be whole lines.  One
+    // ds_bpermute_b32 per register (a crossbar move: no LDS memory, no bank conflicts, no barrier) hands lane l' = 4 j + q the values
+    // of lane (j, q): lane l' then holds the group's outputs 2 l', 2 l' + 1 (two digits, dense: output l') and the 64 lanes of a
+    // store instruction write 1024 (512) CONTIGUOUS bytes in lane order.  Every lane of the wave takes part in the moves (a
+    // masked-off source lane would read as 0); only the stores are predicated.
+    const int xsrc = (int)(((lane >> 2) + 16u * (lane & 3u)) << 2);     // byte address of the lane whose values lane l' stores
     if constexpr (DIGITS == 2) {
         // lane (j, q) holds rows 4q..4q+3 of column j: (re_lo, re_hi, im_lo, im_hi) of output 4j + q
         const uint32_t par = (L.par_first ^ (L.half_M * q)) & 1u;
@@ -337,12 +375,19 @@ __global__ void __launch_bounds__(kFirThreads, NKU <= 6 ? 8 : (NKU == 7 ? 6 : 4)
 #pragma unroll
         for (int gi = 0; gi < kFirGroupsPerWave; ++gi) {
             const uint32_t g = wave + 4u * gi;
-            const uint32_t o = 64u * g + 4u * j + q;
-            if (g < L.groups && o < no && !FIR_ABLATE(2)) {
+            if (g < L.groups && 64u * g < no && !FIR_ABLATE(2)) {           // wave-uniform
                 int re = acc[gi].x + (acc[gi].y << 7), im = acc[gi].z + (acc[gi].w << 7);
                 if (L.par_first) { re = -re; im = -im; }
-                int2* dst = reinterpret_cast<int2*>(L.out) + ((uint64_t)c * L.out_cap + o0 + o);
-                *dst = make_int2(re + cre, im + cim);
+                re += cre; im += cim;
+                uint32_t o = 64u * g + 4u * j + q;
+                if (!FIR_ABLATE(5)) {                                       // (probe, experiment build: the round-5 store order)
+                    re = __builtin_amdgcn_ds_bpermute(xsrc, re); im = __builtin_amdgcn_ds_bpermute(xsrc, im);
+                    o = 64u * g + lane;
+                }
+                if (o < no) {
+                    int2* dst = reinterpret_cast<int2*>(L.out) + ((uint64_t)c * L.out_cap + o0 + o);
+                    *dst = make_int2(re, im);
+                }
             }
         }
     } else {
@@ -353,8 +398,7 @@ __global__ void __launch_bounds__(kFirThreads, NKU <= 6 ? 8 : (NKU == 7 ? 6 : 4)
 #pragma unroll
         for (int gi = 0; gi < GPW; ++gi) {
             const uint32_t g = wave + 4u * gi;
-            const uint32_t o = 128u * g + 8u * j + 2u * q;
-            if (g < L.groups && o < no && !FIR_ABLATE(2)) {
+            if (g < L.groups && 128u * g < no && !FIR_ABLATE(2)) {          // wave-uniform
                 int re0, im0, re1, im1;
                 if constexpr (DIGITS == 3) {                 // (lo, hi) of the two outputs, re and im in accumulators of their own
                     re0 = acc[gi].x + (acc[gi].y << 7); re1 = acc[gi].z + (acc[gi].w << 7);
@@ -363,14 +407,23 @@ __global__ void __launch_bounds__(kFirThreads, NKU <= 6 ? 8 : (NKU == 7 ? 6 : 4)
                     re0 = acc[gi].x; im0 = acc[gi].y; re1 = acc[gi].z; im1 = acc[gi].w;
                 }
                 if (L.par_first) { re0 = -re0; im0 = -im0; re1 = -re1; im1 = -im1; }
-                // both outputs as ONE 16-byte store where the row allows it (an even out_cap: every channel's row 16-byte aligned) -- two
-                // 8-byte stores 16 bytes apart per lane touch every line twice
-                int2* dst = reinterpret_cast<int2*>(L.out) + ((uint64_t)c * L.out_cap + o0 + o);
-                if (o + 1u < no && (reinterpret_cast<uintptr_t>(dst) & 15u) == 0u) {
-                    *reinterpret_cast<int4*>(dst) = make_int4(re0 + cre0, im0 + cim0, re1 + cre1, im1 + cim1);
-                } else {
-                    dst[0] = make_int2(re0 + cre0, im0 + cim0);
-                    if (o + 1u < no) dst[1] = make_int2(re1 + cre1, im1 + cim1);
+                re0 += cre0; im0 += cim0; re1 += cre1; im1 += cim1;          // (the same constants in every lane: before or behind the moves)
+                uint32_t o = 128u * g + 8u * j + 2u * q;
+                if (!FIR_ABLATE(5)) {                                       // (probe, experiment build: the round-5 store order)
+                    re0 = __builtin_amdgcn_ds_bpermute(xsrc, re0); im0 = __builtin_amdgcn_ds_bpermute(xsrc, im0);
+                    re1 = __builtin_amdgcn_ds_bpermute(xsrc, re1); im1 = __builtin_amdgcn_ds_bpermute(xsrc, im1);
+                    o = 128u * g + 2u * lane;
+                }
+                if (o < no) {
+                    // both outputs as ONE 16-byte store where the row allows it (an even out_cap: every channel's row 16-byte aligned) -- two
+                    // 8-byte stores 16 bytes apart per lane touch every line twice
+                    int2* dst = reinterpret_cast<int2*>(L.out) + ((uint64_t)c * L.out_cap + o0 + o);
+                    if (o + 1u < no && (reinterpret_cast<uintptr_t>(dst) & 15u) == 0u) {
+                        *reinterpret_cast<int4*>(dst) = make_int4(re0, im0, re1, im1);
+                    } else {
+                        dst[0] = make_int2(re0, im0);
+                        if (o + 1u < no) dst[1] = make_int2(re1, im1);
+                    }
                 }
             }
         }
@@ -493,8 +546,8 @@ int fir_enqueue(fmd_fir* f, const void* d_iq, size_t nbytes, void* d_out, size_t
         L.mre[0] = f->mre[0]; L.mre[1] = f->mre[1]; L.mim[0] = f->mim[0]; L.mim[1] = f->mim[1];
         L.out_tile = 16u * opc * f->groups;
         // staged bytes of a full tile, and the furthest byte any fragment read touches
-        const size_t staged = (((((size_t)(L.out_tile - 1) * L.half_M + L.NP + 3) / 4) + 3) & ~(size_t)3) * 16;
-        const size_t touched = (size_t)16 * f->groups * L.col_bytes + (size_t)64 * f->n_pass * (f->nku + 1u);   // (+1: the sparse form's 128-byte chunks)
+        const size_t staged = (((((size_t)(L.out_tile - 1) * L.half_M + L.NP + 3) / 4) + 7) & ~(size_t)7) * 16;     // whole 128-byte columns (fir_img)
+        const size_t touched = ((size_t)16 * f->groups * L.col_bytes + (size_t)64 * f->n_pass * (f->nku + 1u) + 127) & ~(size_t)127;   // (+1: the sparse form's 128-byte chunks)
         const size_t lds = staged > touched ? staged : touched;
         const uint32_t tiles = (uint32_t)((n_out + L.out_tile - 1) / L.out_tile), per = (f->C + 7u) / 8u;
         if (tiles > 65535u || per > 65535u) { fmd_internal_set_err("call too large for the matrix-core FIR grid"); return FMD_ERR_UNSUPPORTED; }
@@ -651,6 +704,21 @@ void fmd_fir_free(fmd_fir* f)
 }
 
 int fmd_fir_tap_digits(const fmd_fir* f) { return f ? (int)(f->digits == 3u ? 2u : f->digits) : FMD_ERR_INVALID_ARG; }
+
+int fmd_fir_kernel_name(const fmd_fir* f, char* name, size_t cap)
+{
+    if (!f || !name || cap == 0) return FMD_ERR_INVALID_ARG;
+    // (the kernels live in this file's anonymous namespace; the template arguments as launch_mfma / launch_mfma_d pick them)
+    int n;
+    if (!f->n_pass) n = snprintf(name, cap, "(anonymous namespace)::fmd_fir_kernel");
+    else {
+        const uint32_t nku = f->nku < 8u ? (f->nku ? f->nku : 1u) : 8u;
+        const uint32_t col_bytes = 2u * (f->digits != 2u ? 8u : 4u) * f->M;
+        const bool swz = f->digits != 3u && col_bytes == 64u && f->swz;
+        n = snprintf(name, cap, "(anonymous namespace)::fmd_fir_mfma_kernel<%u, %s, %u>", nku, swz ? "true" : "false", f->digits);
+    }
+    return n < 0 || (size_t)n >= cap ? FMD_ERR_CAPACITY : FMD_OK;
+}
 
 int fmd_fir_reset(fmd_fir* f)
 {

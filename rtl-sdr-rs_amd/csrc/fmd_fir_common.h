@@ -52,6 +52,13 @@ inline int fmd_fir_a_value(const int16_t* taps, uint32_t n_taps, uint32_t decim,
 // lane (row, q) holds 16 stored bytes; bytes 8 h ... 8 h + 7 cover the 16 dense K positions from 64 (q & 1) + 16 (q >> 1) + 32 h of the
 // 128-byte chunk, two per group of four -- positions 0 and 3 for a re row, 1 and 2 for an im row (rotate_90 leaves every re row with
 // bytes 0 / 3 and every im row with bytes 1 / 2 of each stream dword: the tap matrix IS 4:2 sparse, one fixed pattern per row).
+// Round 6: the B operand of an ODD K quarter (lane quarter q = 1, 3: K positions 32 q ... 32 q + 31 of the chunk) is handed over with
+// its two 16-byte halves SWAPPED -- those lanes read the second half of their 32 stream bytes first -- which takes the operand reads
+// off each other's LDS banks (tools/ldsbench.py, tools/lds_model.py: the four quarters' first reads then cover every 16-byte slot of
+// the 256-byte bank row once instead of the even slots twice).  The K permutation is the same for every column, so it is absorbed
+// here: K position k of an odd quarter weighs the stream byte at k ^ 16.
+inline uint32_t fmd_fir_kswap(uint32_t k_in_chunk) { return k_in_chunk ^ (((k_in_chunk >> 5) & 1u) << 4); }
+
 template <typename RowFn>
 inline void fmd_fir_compress_42(uint8_t* as, uint32_t nks, RowFn entry /* (row, comp&, kb) -> value, comp by reference */)
 {
@@ -63,7 +70,7 @@ inline void fmd_fir_compress_42(uint8_t* as, uint32_t nks, RowFn entry /* (row, 
                 uint32_t comp = 0;
                 (void)entry(r, comp, 0u);                                     // (the row's component decides the pair of positions)
                 const uint32_t pos = comp == 0u ? (e ? 3u : 0u) : (e ? 2u : 1u);
-                const uint32_t kb = 128u * kc + 64u * (q & 1u) + 16u * (q >> 1) + 32u * h + 4u * gl + pos;
+                const uint32_t kb = 128u * kc + fmd_fir_kswap(64u * (q & 1u) + 16u * (q >> 1) + 32u * h + 4u * gl + pos);
                 as[((size_t)kc * 64 + lane) * 16 + sb] = (uint8_t)(int8_t)entry(r, comp, kb);
             }
         }

@@ -572,15 +572,20 @@ __device__ __forceinline__ void fd_reg_body(const FirDemodLaunch& L)
     for (int gi = 0; gi < NACC; ++gi) acc[gi] = fd_i4{0, 0, 0, 0};   // (all zero: the first matrix instruction takes the inline constant, no v_mov)
     if constexpr (SP) {
         typedef int fd_i8 __attribute__((ext_vector_type(8)));
+        // (round 6: the lanes of the ODD K quarters read the second half of their 32 bytes first -- fmd_fir_kswap, fmd_fir_common.h: the
+        //  tap fragments are permuted accordingly.  With every quarter reading its first half first, the 16 lanes the LDS serves
+        //  together hit the even 16-byte slots of the bank row twice: SQ_LDS_BANK_CONFLICT was a third of the LDS-active cycles of
+        //  this kernel in round 5; tools/ldsbench.py: 1.65 x a conflict-free read, 0.94 x with the swap)
         const uint8_t* col = reinterpret_cast<const uint8_t*>(lds) + 16u * tcol + 32u * q;   // the lane's 32 bytes of a 128-byte chunk
+        const uint32_t h0 = FD_ABLATE(29) ? 0u : 16u * (q & 1u);                            // (probe, experiment build: round 5's order -- wrong audio, same work)
         // (re rows keep bytes 0 and 3 of every dword: index pairs (0, 3); im rows bytes 1 and 2: (1, 2))
         const uint32_t row = lane & 15u;
         const int idx = ((DIGITS == 1 ? row & 1u : (row >> 1) & 1u) != 0u) ? (int)0x99999999u : (int)0xCCCCCCCCu;
 #pragma unroll
         for (int s = 0; s <= AS * (NA - 1) + 2 * (NKS - 1); s += (AS == 2 ? 2 : 1)) {
             if (FD_ABLATE(16)) continue;
-            const fd_i4 b0 = *reinterpret_cast<const fd_i4*>(col + 64 * s) ^ (int)0x80808080;          // u8 -> s8
-            const fd_i4 b1 = *reinterpret_cast<const fd_i4*>(col + 64 * s + 16) ^ (int)0x80808080;
+            const fd_i4 b0 = *reinterpret_cast<const fd_i4*>(col + h0 + 64 * s) ^ (int)0x80808080;     // u8 -> s8
+            const fd_i4 b1 = *reinterpret_cast<const fd_i4*>(col + (h0 ^ 16u) + 64 * s) ^ (int)0x80808080;
             const fd_i8 B = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
 #pragma unroll
             for (int kc = 0; kc < NKS; ++kc)
@@ -1019,6 +1024,20 @@ int fd_enqueue(fmd_firdemod* f, const void* d_iq, size_t nbytes, void* d_out, si
         H.Hw = L.Hw; H.NP = L.NP; H.half_M = L.half_M; H.wd_first = L.wd_first;
         H.raw_bytes = L.raw_bytes; H.use_rows = L.use_rows;
     }
+    // (cannot happen -- fmd_firdemod_new keeps a one-digit register plan or a split plan only together with `sparse` in
+    //  the shipped build -- but launch() would hand a one-digit tap matrix to the two-digit kernel, or run on an empty dense
+    //  matrix: silently wrong audio.  Refuse instead.)
+    {
+#ifdef FMD_EXPERIMENT
+        const bool dense_one_digit_kernel = true;
+#else
+        const bool dense_one_digit_kernel = false;
+#endif
+        if ((f->reg_ng && f->plan.digits == 1u && !f->sparse && !dense_one_digit_kernel) || (f->plan.split && !f->sparse)) {
+            fmd_internal_set_err("internal: tap-matrix form and kernel form disagree");
+            return FMD_ERR_UNSUPPORTED;
+        }
+    }
     switch (f->plan.nku) {
         case 1: launch<1>(L, g, lds, stream); break;
         case 2: launch<2>(L, g, lds, stream); break;
@@ -1149,7 +1168,12 @@ int fmd_firdemod_new(const int16_t* taps, uint32_t n_taps, uint32_t decim, uint3
         // (an 8-bit filter whose audio groups admit an ODD column parameter -- 5 or 7 -- takes the even one below it: the one-digit
         //  sparse form with slightly shorter columns beats two dense digits by more than the columns cost)
         // (12-bit filters keep the odd parameter: session r05bl, 5 -> 4 sparse +6 ... +7 %, 7 -> 6 sparse -1 %)
-        if (small && sparse_on && (f->reg_ng == 5u || f->reg_ng == 7u) && fmd_knob("FMD_FD_REG") == nullptr && fmd_knob_u32("FMD_FD_DIGITS", 0) != 2u) {
+        // (the one-digit plan is built FIRST -- with eight outputs per column it needs n_taps <= 200 to fit one K pass,
+        //  the register form admits 232 -- and the column parameter is lowered only when that plan exists: a filter of 201 ... 232
+        //  8-bit taps keeps its odd parameter and the dense two-digit kernel with the full columns)
+        FmdFirMfmaPlan one;
+        const bool one_fits = small && fmd_knob_u32("FMD_FD_DIGITS", 0) != 2u && fmd_fir_build_mfma(taps, n_taps, decim, one, 1u) && one.n_pass == 1u;
+        if (one_fits && sparse_on && (f->reg_ng == 5u || f->reg_ng == 7u) && fmd_knob("FMD_FD_REG") == nullptr) {
             f->reg_ng -= 1u;
             if (!lds_knob) f->lds_budget = budget[f->reg_ng];
         }
@@ -1159,10 +1183,7 @@ int fmd_firdemod_new(const int16_t* taps, uint32_t n_taps, uint32_t decim, uint3
 #else
         const bool dense_one_digit = false;
 #endif
-        if (small && even_ng && (sparse_on || dense_one_digit) && fmd_knob_u32("FMD_FD_DIGITS", 0) != 2u) {
-            FmdFirMfmaPlan one;
-            if (fmd_fir_build_mfma(taps, n_taps, decim, one, 1u) && one.n_pass == 1u) f->plan = one;
-        }
+        if (one_fits && even_ng && (sparse_on || dense_one_digit)) f->plan = one;
         // The register form's matrix phase runs on the 4:2 sparse matrix instruction when the column parameter is even: one digit -- 12
         // instead of 24 matrix instructions per wave at config 4's shape for the same 12 operand reads (-4.3 %); two digits -- re and
         // im in accumulators of their own (fmd_fir_common.h `split`), 24 instead of 40 for the same 12 reads.  (Two digits with the

@@ -289,8 +289,8 @@ inline uint32_t fmd_tile_raw_cap(const FmdRates& r)
 // Sum over samples n in [0, n) of the additive constants left after mapping bytes to
 // t = b - 128: rotate_90 (:284-296) + `as i16 - 127` (:258) give, for n mod 4 = 0..3,
 //   re = t0+1, -t3, -t4, t7+1      im = t1+1, t2+1, -t5, -t6
-FMD_HD int32_t fmd_const_re(int32_t n) { return 2 * (n >> 2) + ((n & 3) >= 1 ? 1 : 0); }
-FMD_HD int32_t fmd_const_im(int32_t n) { return 2 * (n >> 2) + ((n & 3) < 2 ? (n & 3) : 2); }
+FMD_HD constexpr int32_t fmd_const_re(int32_t n) { return 2 * (n >> 2) + ((n & 3) >= 1 ? 1 : 0); }
+FMD_HD constexpr int32_t fmd_const_im(int32_t n) { return 2 * (n >> 2) + ((n & 3) < 2 ? (n & 3) : 2); }
 
 // Byte weights (as 4 packed signed bytes, little-endian) of one aligned dword = two complex samples;
 // `odd` is the parity of the dword index within the call (rotate_90 has period 8 bytes).

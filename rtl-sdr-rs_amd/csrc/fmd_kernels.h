@@ -2,13 +2,18 @@
 #pragma once
 
 #include <hip/hip_runtime.h>
+#include <stddef.h>
 #include <stdint.h>
 
 #include "fmd_index.h"
 
 #define FMD_BLOCK_THREADS 256
 #define FMD_MAX_CLASSES 16       /* phase classes one launch can carry (32-byte plans in the kernel arguments) */
-#define FMD_STREAM_MAX_ROUNDS 12  /* register-streaming kernel: wave-rounds of 127 decimated samples per wave and tile (straight-line code) */
+/* register-streaming kernel: wave-rounds of 127 decimated samples per wave and tile (straight-line code).  Round 6 (second lever on
+ * this kernel, profiles/r06_experiments.md 3): 16 instead of 12 rounds -- fewer ramps, barriers and resampler tails per byte -- is 1.0 ... 2.1 %
+ * faster at downsample 2 and -0.8 ... +3.4 % at downsample 4 (where the planner's larger tile is not always the better one): 16 at
+ * downsample 2 only. */
+#define FMD_STREAM_MAX_ROUNDS(D) ((D) == 2u ? 16u : 12u)
 #define FMD_TILE_MAX_LOADS 8      /* 16-byte chunks per thread the tile kernel can stage */
 
 // Device-side error bits (FmdLaunch::err), all "cannot happen" conditions.
@@ -108,6 +113,9 @@ struct FmdRowGeo {
     uint32_t pad[2];
 };
 static_assert(sizeof(FmdRowGeo) == 64, "one s_load_dwordx16");
+// the kernels' early exit reads n_channels / per through whichever member of the union is active (fmd_tile_body.h)
+static_assert(offsetof(FmdRowGeo, n_channels) == offsetof(FmdFastGeo, n_channels) && offsetof(FmdRowGeo, per) == offsetof(FmdFastGeo, per),
+              "FmdRowGeo and FmdFastGeo keep n_channels / per at the same offsets");
 
 struct FmdLaunch {
     union {                   // (must stay the first member)
@@ -135,7 +143,13 @@ struct FmdLaunch {
     uint64_t out_stride;      // samples
     uint32_t* out_len;        // [n_channels] or nullptr
     uint32_t* err;            // device error word (= &exc->err)
-    FmdExcBuf* exc;           // guarded f64 samples of this handle
+    FmdExcBuf* exc;           // guarded f64 samples of this launch (the handle keeps one buffer per launch parity)
+    // Round 6, the pipelined completion point (fmd_demod_check_prev): a launch starts when its predecessor has COMPLETED (same
+    // stream, or ordered by the library), so the first tile of channel 0 posts "launch seq - 1 is done" together with the head of
+    // the predecessor's report buffer into host-mapped memory -- the host learns that buffer n - 1 is final while buffer n runs,
+    // without an event or a copy between the two kernels (an event behind every launch costs 2 - 3 % per launch, round 5).
+    const FmdExcBuf* exc_prev; // the predecessor's report buffer, or nullptr
+    uint32_t* mbox;           // host-mapped, 8-byte aligned: low word = seq of the launch known complete, high word = 1 | 2 if its report buffer holds an error / records; or nullptr
     double    f64_guard;      // half-width of the guard band around integers (see above)
     uint32_t  seq;            // launch sequence number (FmdF64Exc::seq)
     int32_t   f64_skew;       // -DFMD_EXPERIMENT builds only: added to the kernel's value of guarded samples (patch-path test)

@@ -306,13 +306,21 @@ __device__ __forceinline__ void d1_pair_rounds(const uint32_t* __restrict__ raw_
     int base = (int)wave * RS;
     const int s_w = s00 + base;                              // call sample of window `base` (wave-uniform; may be negative in tile 0)
     const bool odd = (s_w & 1) != 0;                         // wave-uniform
-    const uint32_t ph1 = (uint32_t)(s_w + 2 * (int)lane) & 3u, ph2 = (ph1 + 1u) & 3u;
-    // 16-bit weight pairs (I byte, Q byte) by phase: re = +I, -Q, -I, +Q; im = +Q, +I, -Q, -I
-    auto w_re = [](uint32_t ph) { return ph == 0u ? 0x0001u : ph == 1u ? 0xFF00u : ph == 2u ? 0x00FFu : 0x0100u; };
-    auto w_im = [](uint32_t ph) { return ph == 0u ? 0x0100u : ph == 1u ? 0x0001u : ph == 2u ? 0xFF00u : 0x00FFu; };
-    const uint32_t r1 = w_re(ph1), m1 = w_im(ph1), r2 = w_re(ph2) << 16, m2 = w_im(ph2) << 16;
-    const int bre1 = kSumBias + (int)(ph1 == 0u || ph1 == 3u), bim1 = kSumBias + (int)(ph1 <= 1u);
-    const int bre2 = kSumBias + (int)(ph2 == 0u || ph2 == 3u), bim2 = kSumBias + (int)(ph2 <= 1u);
+    const uint32_t ph1 = (uint32_t)(s_w + 2 * (int)lane) & 3u;               // the second sample's phase is (ph1 + 1) & 3
+    // 16-bit weight pairs (I byte, Q byte) by phase: re = +I, -Q, -I, +Q (0x0001, 0xFF00, 0x00FF, 0x0100); im = +Q, +I, -Q, -I
+    // (0x0100, 0x0001, 0xFF00, 0x00FF) -- as 8-byte tables these are the dword weights themselves (EVEN, ODD), and one v_perm_b32
+    // picks a phase's pair (round 6: it was a chain of compares and selects per weight).  The second sample's tables are rotated by
+    // one phase and land in the upper half.  The additive constants (+1 where the weight is +1) come out of byte tables the same way.
+    const uint32_t selL = ph1 * 0x0202u + 0x0C0C0100u;                       // bytes (2 ph, 2 ph + 1, zero, zero)
+    const uint32_t selH = (selL << 16) | 0x0C0Cu;                            // bytes (zero, zero, 2 ph, 2 ph + 1)
+    const uint32_t selB = ph1 | 0x07060500u;                                 // byte 0: table entry ph; bytes 1 ... 3: kSumBias's
+    const uint32_t r1 = __builtin_amdgcn_perm(FMD_W_RE_ODD, FMD_W_RE_EVEN, selL), m1 = __builtin_amdgcn_perm(FMD_W_IM_ODD, FMD_W_IM_EVEN, selL);
+    // phase ph1 + 1: entries (1, 2, 3, 0) = 0xFF00, 0x00FF, 0x0100, 0x0001 (re), 0x0001, 0xFF00, 0x00FF, 0x0100 (im)
+    const uint32_t r2 = __builtin_amdgcn_perm(0x00010100u, 0x00FFFF00u, selH), m2 = __builtin_amdgcn_perm(0x010000FFu, 0xFF000001u, selH);
+    static_assert((kSumBias & 0xFF) == 0, "the table byte replaces the bias's low byte");
+    // re gets +1 at phases 0 and 3, im at phases 0 and 1; the second sample's tables rotated by one phase
+    const int bre1 = (int)__builtin_amdgcn_perm((uint32_t)kSumBias, 0x01000001u, selB), bim1 = (int)__builtin_amdgcn_perm((uint32_t)kSumBias, 0x00000101u, selB);
+    const int bre2 = (int)__builtin_amdgcn_perm((uint32_t)kSumBias, 0x01010000u, selB), bim2 = (int)__builtin_amdgcn_perm((uint32_t)kSumBias, 0x01000001u, selB);
     const uint32_t* __restrict__ pa = raw_w + (uint32_t)(wofs + (s_w >> 1) + (int)lane);
     auto round = [&](int b, auto full_c) {
         constexpr bool FULL = decltype(full_c)::value;
@@ -353,21 +361,39 @@ __device__ __forceinline__ void odd_pair_rounds(const uint32_t* __restrict__ raw
     int base = (int)wave * RS;
     const int s_w = s00 + D * base;                          // call sample where window `base` starts (wave-uniform)
     const bool odd = (s_w & 1) != 0;                         // wave-uniform: the pair starts in the high half of a dword
-    const int s_l = s_w + 2 * D * (int)lane;                 // ... of this lane's first window
-    const uint32_t sm1 = (uint32_t)s_l & 3u, sm2 = (uint32_t)(s_l + D) & 3u;
+    // The lane's first window starts at call sample s_l = s_w + 2 D lane.  D is odd, so everything per-lane below depends on the
+    // lane's PARITY only: s_l = s_w + 2 (lane & 1) (mod 4), and (s_l >> 1) = (s_w >> 1) + D lane has the parity of (s_w >> 1) + lane.
+    // Round 6: the set-up written for exactly that -- one sign mask and xors for the byte weights, the additive constants out of
+    // compile-time byte tables by v_perm_b32 -- instead of per-lane phase arithmetic, compares and selects: ~25 instead of ~75 vector
+    // instructions per wave, a fifth of what a wave of the downsample-5 kernel issued (profiles/r06_experiments.md 1).
     // dword 0 of the lane's span is call dword (s_l >> 1): its weights are the EVEN pair when that index is even
-    const bool podd = ((s_l >> 1) & 1) != 0;
-    const uint32_t wrA = podd ? FMD_W_RE_ODD : FMD_W_RE_EVEN, wrB = podd ? FMD_W_RE_EVEN : FMD_W_RE_ODD;   // dword u: A for even u, B for odd u
-    const uint32_t wiA = podd ? FMD_W_IM_ODD : FMD_W_IM_EVEN, wiB = podd ? FMD_W_IM_EVEN : FMD_W_IM_ODD;
-    // the half dwords: even start -> dword H (low half: window 1, high half: window 2); odd start -> dword 0 (high half,
-    // window 1) and dword D (low half, window 2)
-    const uint32_t wrH = (H & 1) ? wrB : wrA, wiH = (H & 1) ? wiB : wiA;     // weights of dword H
-    const uint32_t wrD = wrB, wiD = wiB;                                      // ... of dword D (D is odd)
-    const uint32_t r1h = odd ? (wrA & 0xFFFF0000u) : (wrH & 0x0000FFFFu), i1h = odd ? (wiA & 0xFFFF0000u) : (wiH & 0x0000FFFFu);
-    const uint32_t r2h = odd ? (wrD & 0x0000FFFFu) : (wrH & 0xFFFF0000u), i2h = odd ? (wiD & 0x0000FFFFu) : (wiH & 0xFFFF0000u);
-    const int bre1 = kSumBias + fmd_const_re((int)sm1 + D) - fmd_const_re((int)sm1), bim1 = kSumBias + fmd_const_im((int)sm1 + D) - fmd_const_im((int)sm1);
-    const int bre2 = kSumBias + fmd_const_re((int)sm2 + D) - fmd_const_re((int)sm2), bim2 = kSumBias + fmd_const_im((int)sm2 + D) - fmd_const_im((int)sm2);
-    const uint32_t* __restrict__ pa = raw_w + (uint32_t)(wofs + (s_l >> 1));
+    const uint32_t mk = (uint32_t)__builtin_amdgcn_sbfe((int)(lane ^ (uint32_t)(s_w >> 1)), 0, 1);       // all ones: an odd call dword
+    constexpr uint32_t XRE = FMD_W_RE_EVEN ^ FMD_W_RE_ODD, XIM = FMD_W_IM_EVEN ^ FMD_W_IM_ODD;
+    const uint32_t wrA = FMD_W_RE_EVEN ^ (mk & XRE), wrB = wrA ^ XRE;   // dword u: A for even u, B for odd u
+    const uint32_t wiA = FMD_W_IM_EVEN ^ (mk & XIM), wiB = wiA ^ XIM;
+    // the half dwords: even start -> dword H (low half: window 1, high half: window 2), weights A or B by H's parity; odd start ->
+    // dword 0 (high half, window 1: A) and dword D (low half, window 2: B, D is odd).  `odd` is wave-uniform: scalar masks / flips.
+    const uint32_t hm1 = odd ? 0xFFFF0000u : 0x0000FFFFu, hm2 = ~hm1;
+    const bool f1 = !odd && (H & 1) != 0, f2 = odd || (H & 1) != 0;          // the half dword's weights are the B pair
+    const uint32_t r1h = (wrA ^ (f1 ? XRE : 0u)) & hm1, i1h = (wiA ^ (f1 ? XIM : 0u)) & hm1;
+    const uint32_t r2h = (wrA ^ (f2 ? XRE : 0u)) & hm2, i2h = (wiA ^ (f2 ? XIM : 0u)) & hm2;
+    // additive constants of a window that starts at rotation phase sm: fmd_const(sm + D) - fmd_const(sm), one byte each (<= 9);
+    // window 1 starts at sm1 = s_l & 3, window 2 at (sm1 + D) & 3 -- its tables are rotated accordingly, so ONE selector serves all
+    // four: byte 0 picks the table entry, bytes 1 ... 3 the upper bytes of kSumBias
+    constexpr auto tbl = [](bool im, int k) constexpr {
+        uint32_t t = 0;
+        for (int sm = 0; sm < 4; ++sm) {
+            const int s = (sm + k) & 3;
+            t |= (uint32_t)(im ? fmd_const_im(s + D) - fmd_const_im(s) : fmd_const_re(s + D) - fmd_const_re(s)) << (8 * sm);
+        }
+        return t;
+    };
+    constexpr uint32_t TRE1 = tbl(false, 0), TIM1 = tbl(true, 0), TRE2 = tbl(false, D), TIM2 = tbl(true, D);
+    static_assert((kSumBias & 0xFF) == 0, "the table byte replaces the bias's low byte");
+    const uint32_t sel = ((((uint32_t)s_w) ^ (lane << 1)) & 3u) | 0x07060500u;
+    const int bre1 = (int)__builtin_amdgcn_perm((uint32_t)kSumBias, TRE1, sel), bim1 = (int)__builtin_amdgcn_perm((uint32_t)kSumBias, TIM1, sel);
+    const int bre2 = (int)__builtin_amdgcn_perm((uint32_t)kSumBias, TRE2, sel), bim2 = (int)__builtin_amdgcn_perm((uint32_t)kSumBias, TIM2, sel);
+    const uint32_t* __restrict__ pa = raw_w + (uint32_t)(wofs + (s_w >> 1)) + (uint32_t)D * lane;
     auto round = [&](int b, auto full_c, auto odd_c) {
         constexpr bool FULL = decltype(full_c)::value, ODD = decltype(odd_c)::value;
         const int i1 = b + 2 * (int)lane, i2 = i1 + 1;
@@ -526,16 +552,22 @@ __device__ __forceinline__ void stream_pair_rounds(const unsigned char* __restri
         if (lane > 0 && KO < rem) dl[KO] = (int16_t)disc_f32_c<DH == 1, true>(ar1, ai1, br1, bi1, k4096);
         if (KO + 1 < rem) dl[KO + 1] = (int16_t)disc_f32_c<DH == 1, true>(ar2, ai2, ar1, ai1, k4096);
     };
-    // Straight-line code for up to FMD_STREAM_MAX_ROUNDS rounds per wave (the host sizes the tiles accordingly): in a
+    // Straight-line code for up to FMD_STREAM_MAX_ROUNDS(downsample) rounds per wave (the host sizes the tiles accordingly): in a
     // loop hipcc's wait-count pass gives up at the back edge and waits for EVERY outstanding load (vmcnt(0)) once per trip,
     // which stalls the whole ring; unrolled, every round waits for exactly its own register set.
     uint32_t w[P][NDW];
 #pragma unroll
     for (int p = 0; p < P; ++p) fetch(w[p]);
-    static_assert(FMD_STREAM_MAX_ROUNDS == 12, "the unrolled rounds below");
+    constexpr int MAXR = (int)FMD_STREAM_MAX_ROUNDS(2u * DH);
+    static_assert(MAXR == 12 || MAXR == 16, "the unrolled rounds below");
 #define FMD_SR(K) round(w[(K) % P], std::integral_constant<int, (K)>{}); base += NW * RS; if (base >= last) return; fetch(w[(K) % P])
     FMD_SR(0); FMD_SR(1); FMD_SR(2); FMD_SR(3); FMD_SR(4); FMD_SR(5); FMD_SR(6); FMD_SR(7); FMD_SR(8); FMD_SR(9); FMD_SR(10);
-    round(w[11 % P], std::integral_constant<int, 11>{});
+    if constexpr (MAXR == 16) {
+        FMD_SR(11); FMD_SR(12); FMD_SR(13); FMD_SR(14);
+        round(w[15 % P], std::integral_constant<int, 15>{});
+    } else {
+        round(w[11 % P], std::integral_constant<int, 11>{});
+    }
 #undef FMD_SR
 }
 
@@ -827,6 +859,15 @@ __device__ __forceinline__ void tile_body(const FmdLaunch& L, const TileCtx& X, 
     // wave as the loop's own stores to these entries, so program order makes the patch win.
     bool any_guard = false;                                  // a guarded f64 sample in this tile (FmdF64Exc, fmd_kernels.h)
     FMD_SPECIAL_ONLY(X) if (jfirst <= 0 && tid == 0) {
+        // the launch's mailbox post (FmdLaunch::mbox): ANY block of this launch runs after the previous launch has completed;
+        // this region is entered by the first tile of every channel-call only, and channel 0's does the post
+        // (ONE relaxed 8-byte store -- sequence number in the low word, "its report buffer is not empty" in the high one: nothing to order,
+        //  so no release fence; a system-scope release writes the XCD's L2 back, once per launch: session r06c measured the two-word
+        //  form with a release 3.3 % over the bare launches, and +0.5 % on cfg-ref's plain launches)
+        if (c == 0u && L.mbox) {
+            const uint32_t busy = L.exc_prev ? ((L.exc_prev->err != 0u ? 1u : 0u) | (L.exc_prev->count != 0u ? 2u : 0u)) : 0u;
+            __hip_atomic_store(reinterpret_cast<uint64_t*>(L.mbox), (uint64_t)(L.seq - 1u) | ((uint64_t)busy << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
         const FmdChanState st = chan_state();
         int r0, i0, r1, i1w, cr, ci;
         lds_window_sum(raw_w, wofs, 0, fmd_win_end(r.D, p0, 0), r0, i0);
@@ -842,6 +883,11 @@ __device__ __forceinline__ void tile_body(const FmdLaunch& L, const TileCtx& X, 
         fmd_mul_conj(r1, i1w, r0, i0, cr, ci);
         d16[1 - jfirst] = (int16_t)fmd_fast_atan2(ci, cr);
     }
+#ifdef FMD_EXPERIMENT
+    if constexpr (STREAM) {                                  // timeline probe of the streaming kernel: the end of this wave's rounds
+        if (FMD_ABLATE(29) && lane == 0u) reinterpret_cast<uint32_t*>(smem)[(L.lp_cap * 2u + 64u) / 4u + wave] = (uint32_t)__builtin_readcyclecounter();
+    }
+#endif
     if (!FMD_ABLATE(20)) __syncthreads();                    // (probe, experiment build: what the barrier in front of the resampler pass costs)
     if constexpr (STREAM && (DH == 1 || DH == 2)) {
         // The call's LAST decimated sample: a lane's span is two windows, and when the call ends after a lane's FIRST
@@ -914,8 +960,28 @@ __device__ __forceinline__ void tile_body(const FmdLaunch& L, const TileCtx& X, 
     // instructions).
     auto resample = [&](auto fa_c) {
         constexpr int FA = decltype(fa_c)::value;
+        uint32_t q_lo = 0u, q_hi = 0u;                       // audio samples q_lo <= q < q_hi are done by the 16-byte copy below
+        if constexpr (FA < 0) {
+            // rate_out == rate_resample: the pass is a COPY of the tile's discriminator samples.  Round 6: eight samples per lane -- one
+            // 16-byte LDS read (2-byte aligned: the hardware takes it), one ALIGNED 16-byte store -- instead of one: at downsample 1,
+            // 48 k -> 48 k, the sample-per-lane copy was a quarter of the kernel's vector instructions (20 passes per tile, now 2.5):
+            // -12 % on the launch.  The samples in front of the first 16-byte boundary of the output row and behind the last one take
+            // the sample-per-lane loop (unaligned 16-byte stores measured +0.9 % at downsample 6, where the memory side is the bound).
+            typedef short fmd_s8 __attribute__((ext_vector_type(8)));
+            typedef short fmd_s8u __attribute__((ext_vector_type(8), aligned(2)));
+            const int s0 = (int)(T.eq + T.er) - jfirst;      // d16 index of the tile's audio sample 0
+            const uint32_t head = (uint32_t)((0u - (uint32_t)(uintptr_t)(outc + T.k0)) & 15u) >> 1;     // samples up to the boundary (block-uniform)
+            if (s0 >= 0 && (int)(T.eq + T.er) >= 0 && nk >= head + 8u && !FMD_ABLATE(2) && !FMD_ABLATE(21)) {
+                q_lo = head; q_hi = head + ((nk - head) & ~7u);
+#pragma clang loop unroll(disable)
+                for (uint32_t q = q_lo + 8u * tid; q < q_hi; q += 8u * kThreads)
+                    *reinterpret_cast<fmd_s8*>(outc + T.k0 + q) = *reinterpret_cast<const fmd_s8u*>(d16 + s0 + (int)q);
+            }
+        }
+        // (the samples the 16-byte copy left: q < q_lo -- fewer than 8, one lane each -- and everything from q_hi on)
+        const uint32_t q_end = tid < q_lo ? q_lo : nk;
 #pragma clang loop unroll(disable) vectorize(disable)
-        for (uint32_t q = tid; q < nk; q += kThreads) {
+        for (uint32_t q = tid < q_lo ? tid : tid - q_lo + q_hi; q < q_end; q += kThreads) {
             if (FMD_ABLATE(2)) { outc[T.k0 + q] = d16[q + 1]; continue; }       // ablation: no resampler
             if (FMD_ABLATE(21)) { outc[T.k0 + q] = (int16_t)q; continue; }      // ... and no LDS read either: the bare store
             if constexpr (FA < 0) {
@@ -1212,14 +1278,35 @@ __global__ void __launch_bounds__(kThreads) fmd_demod_tile_kernel(const FmdLaunc
 }
 
 // ---- register-streaming form: no staging, no staging barrier (see stream_pair_rounds) -------------------------------
+// (Round 6 measured this kernel with ONE wave per block -- no block barrier in front of the resampler pass, four times the dispatch
+//  granularity: +1.3 ... +5 % at downsample 4 / 2, profiles/r06_experiments.md 2; the instantiation is deleted.)
 template <int DH, int FAST>
 __global__ void __launch_bounds__(256, 8) fmd_demod_stream_kernel(const FmdLaunch L)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+#ifdef FMD_EXPERIMENT
+    // Timeline probe (ablation bit 29; tools/timeline.py), as in the tile kernel: entry, end of the rounds (= in front of the block
+    // barrier: the "staging" column of the tool is this kernel's whole load + round phase), end of the wave.
+    const bool tl_on = FMD_ABLATE(29);
+    uint64_t tl_t0 = 0;
+    if (tl_on) tl_t0 = __builtin_readcyclecounter();
+#endif
     const FastAddr A = fast_addr<FAST>(L);
     if (A.c >= L.fg.n_channels) return;
     const TileCtx X = fast_ctx<FAST>(L, A);
     tile_body<DH, true>(L, X, smem);
+#ifdef FMD_EXPERIMENT
+    if (tl_on && (threadIdx.x & 63u) == 0u && L.out_len) {
+        const uint64_t t2 = __builtin_readcyclecounter();
+        const uint32_t lin = (blockIdx.z * gridDim.y + blockIdx.y) * 8u + blockIdx.x;
+        uint32_t* rec = L.out_len + ((L.n_channels + 1023u) & ~1023u) + 8u * (4u * lin + (threadIdx.x >> 6));
+        const uint32_t t1 = reinterpret_cast<const uint32_t*>(smem)[(L.lp_cap * 2u + 64u) / 4u + (threadIdx.x >> 6)];   // left there by tile_body
+        rec[0] = (uint32_t)tl_t0; rec[1] = (uint32_t)(tl_t0 >> 32); rec[2] = t1 - (uint32_t)tl_t0; rec[3] = (uint32_t)(t2 - tl_t0);
+        rec[4] = __builtin_amdgcn_s_getreg((31 << 11) | 4);      // HW_ID
+        rec[5] = __builtin_amdgcn_s_getreg((31 << 11) | 20);     // XCC_ID
+        rec[6] = X.c; rec[7] = blockIdx.y | (blockIdx.y << 16);
+    }
+#endif
 }
 
 // Host side of the instantiations: launch_lds<DH> / launch_stream<DH> are defined here and explicitly instantiated in

@@ -11,6 +11,9 @@ template <int DH> void launch_stream(const FmdLaunch& L, dim3 g, size_t lds, hip
 size_t fmd_tile_lds_bytes(const FmdLaunch& L)
 {
     const size_t glen = (size_t)L.fa + 1u;
+#ifdef FMD_EXPERIMENT
+    if (L.stream) return ((2u * ((size_t)L.lp_cap + glen + 1u) + 15u) & ~(size_t)15u) + 16u + 96u;   // + the timeline probe's four words behind the samples (fmd_demod_stream_kernel)
+#endif
     return (L.stream ? 0u : (size_t)L.raw_cap) + ((2u * ((size_t)L.lp_cap + glen + 1u) + 15u) & ~(size_t)15u) + 16u;
 }
 

@@ -93,12 +93,22 @@ class DemodBank:
         return np.array(lens[:], dtype=np.int64)
 
     def demodulate_device(self, d_iq, nbytes, d_out, out_cap_, d_out_len=None, stream=None):
-        """Enqueue on device pointers (ints).  Returns immediately."""
+        """Enqueue on device pointers (ints).  Returns immediately.
+        STREAM LIFETIME (include/fmd.h): `stream` (a hipStream_t as an int; None = the default stream) must stay alive until this
+        handle's NEXT `demodulate_device` call or completion point (`check`, `check_prev`, `get_state`, `set_state`, a host entry)
+        has returned -- the library touches the most recent launch's stream once more there.  A stream taken from a pool that may
+        destroy it (torch's stream objects going out of scope) has to be kept referenced that long."""
         check(lib().fmd_demod_demodulate_device(self._h, d_iq, nbytes, d_out, out_cap_, d_out_len, stream))
 
     def check(self):
         """fmd_demod_check: wait for the handle's launches, surface device assertions, settle guarded f64 samples."""
         check(lib().fmd_demod_check(self._h))
+
+    def check_prev(self):
+        """fmd_demod_check_prev: the same one launch back -- waits for launch n - 1 while launch n runs, settles its f64 samples.
+        Until a launch has been settled its output buffer stays allocated and unread and its input buffer unmodified (include/fmd.h);
+        the stream of the handle's most recent launch must be alive, as for `check`."""
+        check(lib().fmd_demod_check_prev(self._h))
 
     def f64_stats(self):
         g, p = C.c_uint64(), C.c_uint64()
@@ -122,6 +132,10 @@ class DemodBank:
         a, b, c = C.c_uint32(), C.c_uint32(), C.c_uint32()
         check(lib().fmd_demod_tiling(self._h, C.byref(a), C.byref(b), C.byref(c)))
         return {"audio_per_tile": a.value, "lds_bytes": b.value, "block_threads": c.value}
+
+    def tiling_plan(self):
+        """fmd_demod_tiling_plan: 0 the caller's tile, 1 the 20 KB budget, 2 the 15.5 ... 17.3 KB window (LDS kernels)."""
+        return int(lib().fmd_demod_tiling_plan(self._h))
 
     def last_kernel(self):
         """Name of the kernel the most recent launch ran, as rocprofv3 --kernel-trace prints it ('' before the first launch)."""

@@ -47,7 +47,15 @@ class FirBank:
         check(lib().fmd_fir_filter_batch(self._h, iq.ctypes.data, iq.shape[1], out.ctypes.data, cap, lens))
         return out[:, :lens[0], :].copy()
 
+    def kernel_name(self):
+        """The kernel this bank launches, as rocprofv3 --kernel-trace prints it."""
+        buf = C.create_string_buffer(128)
+        check(lib().fmd_fir_kernel_name(self._h, buf, len(buf)))
+        return buf.value.decode()
+
     def filter_device(self, d_iq, nbytes, d_out, out_cap, stream=None):
+        """Enqueue on device pointers.  `stream` must stay alive until the handle's next `filter_device` call has returned
+        (stream lifetime rule of include/fmd.h)."""
         n = C.c_size_t(0)
         check(lib().fmd_fir_filter_device(self._h, d_iq, nbytes, d_out, out_cap, C.byref(n), stream))
         return n.value
@@ -104,6 +112,8 @@ class FirDemodBank:
         return out[:, :lens[0]].copy()
 
     def demodulate_device(self, d_iq, nbytes, d_out, out_cap, stream=None):
+        """Enqueue on device pointers.  `stream` must stay alive until the handle's next `demodulate_device` call or `check` has
+        returned (stream lifetime rule of include/fmd.h)."""
         n = C.c_size_t(0)
         check(lib().fmd_firdemod_demodulate_device(self._h, d_iq, nbytes, d_out, out_cap, C.byref(n), stream))
         return n.value

@@ -98,6 +98,7 @@ extern "C" {
     pub fn fmd_demod_demodulate_device(d: *mut fmd_demod, d_iq: *const c_void, nbytes: usize, d_out: *mut c_void, out_cap: usize, d_out_len: *mut c_void, stream: *mut c_void) -> c_int;
     pub fn fmd_demod_set_block_len(d: *mut fmd_demod, block_bytes: usize) -> c_int;
     pub fn fmd_demod_check(d: *mut fmd_demod) -> c_int;
+    pub fn fmd_demod_check_prev(d: *mut fmd_demod) -> c_int;
     pub fn fmd_demod_f64_stats(d: *const fmd_demod, guarded: *mut u64, patched: *mut u64) -> c_int;
     pub fn fmd_demod_last_out_len(d: *const fmd_demod, out_len: *mut usize) -> c_int;
     pub fn fmd_host_alloc(nbytes: usize, ptr: *mut *mut c_void) -> c_int;
@@ -110,6 +111,7 @@ extern "C" {
     pub fn fmd_device_count(count: *mut c_int) -> c_int;
     pub fn fmd_version() -> c_int;
     pub fn fmd_demod_tiling(d: *const fmd_demod, audio_per_tile: *mut u32, lds_bytes: *mut u32, block_threads: *mut u32) -> c_int;
+    pub fn fmd_demod_tiling_plan(d: *const fmd_demod) -> c_int;
     pub fn fmd_demod_last_kernel(d: *const fmd_demod, name: *mut c_char, cap: usize) -> c_int;
     pub fn fmd_demod_set_tiling(d: *mut fmd_demod, audio_per_tile: u32) -> c_int;
     pub fn fmd_synth_fill_device(device_id: c_int, d_iq: *mut c_void, n_channels: u32, nbytes: usize, sample_offset: u64, p: *const SynthParams, stream: *mut c_void) -> c_int;
@@ -134,6 +136,7 @@ extern "C" {
     pub fn fmd_firdemod_f64_stats(f: *const fmd_firdemod, guarded: *mut u64, patched: *mut u64) -> c_int;
     pub fn fmd_firdemod_tiling(f: *const fmd_firdemod, audio_per_tile: *mut u32, lds_bytes: *mut u32) -> c_int;
     pub fn fmd_firdemod_kernel_name(f: *const fmd_firdemod, name: *mut c_char, cap: usize) -> c_int;
+    pub fn fmd_fir_kernel_name(f: *const fmd_fir, name: *mut c_char, cap: usize) -> c_int;
     pub fn fmd_sink_new(config: *const DemodConfig, n_channels: u32, device_ids: *const i32, n_devices: u32, nbytes: usize, depth: u32, callback: fmd_sink_callback, user: *mut c_void, out: *mut *mut fmd_sink) -> c_int;
     pub fn fmd_sink_free(s: *mut fmd_sink);
     pub fn fmd_sink_acquire(s: *mut fmd_sink, iq: *mut *mut u8) -> c_int;
@@ -215,11 +218,24 @@ impl Demod {
         Ok(out)
     }
 
+    /// STREAM LIFETIME for callers of the raw `fmd_demod_demodulate_device` / `fmd_fir_filter_device` / `fmd_firdemod_demodulate_device`
+    /// bindings above: the `stream` of a handle's most recent device launch must stay alive until the handle's next device launch or
+    /// completion point (`check`, `check_prev`, `state`, `set_state`, a host entry) has returned (include/fmd.h) -- the safe wrappers
+    /// of this crate only use the library's own stream and are not affected.
+    ///
     /// Completion / verification point after device-side launches (`fmd_demod_check`): waits, surfaces device-side
     /// assertions and settles the guarded f64 samples against the host libm.  The host entry points used by
     /// `demodulate` do this themselves; it is here for callers that drive `fmd_demod_demodulate_device` directly.
     pub fn check(&mut self) -> Result<()> {
         check(unsafe { fmd_demod_check(self.handle) })
+    }
+
+    /// The same one launch back (`fmd_demod_check_prev`): with launches 1 ..= n enqueued on the device entry point, waits for launch
+    /// n - 1 only and settles its f64 samples while launch n runs -- the `demodulate` -> `output` cadence of `simple_fm.rs:150-156`
+    /// without serialising host and device.  Until a launch has been settled its output buffer must stay allocated and unread, its
+    /// input buffer unmodified, and the stream of the most recent launch alive (include/fmd.h).
+    pub fn check_prev(&mut self) -> Result<()> {
+        check(unsafe { fmd_demod_check_prev(self.handle) })
     }
 
     pub fn state(&mut self) -> Result<DemodState> {

@@ -147,6 +147,43 @@ def scenario_sink(D, fast, slow):
     return {"bad": bad, "state_bad": 0, "stats": stats, "expected_guarded": n * nbuf}
 
 
+def scenario_pipelined(D, fast, slow, nch):
+    """fmd_demod_check_prev: launch n is enqueued, THEN launch n - 1 is settled and read -- two launches in flight, the patch has to
+    land in the OLDER one's output buffer (and, where the f64 sample of launch n - 1 lies in the sum it carried into launch n, in
+    the state launch n read, with launch n run again).  Every launch has its own input and output buffer, as the contract asks;
+    the last launch is settled by fmd_demod_check.  Channels >= 8 and 4096-byte calls: the table-form tile / streaming kernels."""
+    import torch
+    o = oracle_lib.load()
+    N, ncalls = 8 * 512, 7
+    cfg, ocfg = mkcfg(D, fast, slow), o.config(D, fast, slow)
+    bank, obank = fmd.DemodBank(cfg, nch), o.new_bank(ocfg, nch)
+    rng = np.random.default_rng(D + 90)
+    cap = bank.out_cap(N)
+    ins, outs, exps = [], [], []
+    bad = 0
+    kernels = set()
+
+    def settle_and_compare(k):
+        got = outs[k].cpu().numpy()
+        e, l = exps[k]
+        return sum(0 if np.array_equal(got[c, :l[c]], e[c, :l[c]]) else 1 for c in range(nch))
+
+    for call in range(ncalls):
+        iq = rng.integers(0, 256, (nch, N), dtype=np.uint8)
+        exps.append(o.demodulate_batch(obank, iq))
+        ins.append(torch.from_numpy(iq).cuda())
+        outs.append(torch.zeros((nch, cap), dtype=torch.int16, device="cuda"))
+        bank.demodulate_device(ins[-1].data_ptr(), N, outs[-1].data_ptr(), cap, None, None)
+        kernels.add(bank.last_kernel())
+        bank.check_prev()                                  # launch `call - 1` is final now; launch `call` may still run
+        if call >= 1:
+            bad += settle_and_compare(call - 1)
+    bank.check()
+    bad += settle_and_compare(ncalls - 1)
+    st_bad = sum(0 if bank.get_state(c).as_dict() == o.state_of(obank[c]) else 1 for c in range(nch))
+    return {"bad": bad, "state_bad": st_bad, "stats": bank.f64_stats(), "kernels": sorted(kernels), "launches": ncalls * nch}
+
+
 if __name__ == "__main__":
     kind = sys.argv[1]
     if kind == "direct":
@@ -157,6 +194,8 @@ if __name__ == "__main__":
         res = scenario_firdemod()
     elif kind == "sink":
         res = scenario_sink(*(int(x) for x in sys.argv[2:5]))
+    elif kind == "pipelined":
+        res = scenario_pipelined(*(int(x) for x in sys.argv[2:6]))
     else:
         D, fast, slow, bl = (int(x) for x in sys.argv[2:6])
         res = scenario_stream(D, fast, slow, bl)
