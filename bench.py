@@ -46,49 +46,98 @@ HBM_PEAK_GBS = 8000.0            # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E
 KERNEL_EXPECTED = "fmd_tk::fmd_demod_tile_kernel<5, 2>"
 MIN_TIMED_S = 1.0                # repeat the K-step region until this much has been timed
 MAX_REGIONS = 4000
-PMC_SUMMARY = os.path.join("profiles", "r05_pmc_summary.json")
-BOUNDS = os.path.join("profiles", "r05_bounds.json")   # per-row pipe utilisation from the committed PMC passes (scripts/summarize_bounds.py)
+PMC_SUMMARY = os.path.join("profiles", "r06_pmc_summary.json")
+BOUNDS = os.path.join("profiles", "r06_bounds.json")   # per-row pipe utilisation from the committed PMC passes (scripts/summarize_bounds.py)
 
 
-# what the headline kernel is built from (the FIR kernels, the sink and the CLI do not enter it)
-HEADLINE_SOURCES = ("fmd_tile_body.h", "fmd_tile_lds_even.hip", "fmd_tile_launch.hip", "fmd_kernels.h", "fmd_device.h", "fmd_index.h",
-                    "fmd_host.h", "fmd_internal.h", "fmd_api.cpp")
+# What each kernel family is built from.  Every counter-derived figure this file quotes (roofline.traffic, the pipe fractions of the
+# `extra` rows) is tied to the hash of ITS family's sources as they were on the GPU box when the counters were taken: an edit of the FIR
+# kernels no longer leaves the FIR rows quoting old counters (only the headline was tied), and an edit of one family
+# does not void the others.  tests/test_isa_invariants.py checks the committed summaries against these hashes on the CPU box.
+_TILE_COMMON = ("fmd_tile_body.h", "fmd_tile_launch.hip", "fmd_kernels.h", "fmd_device.h", "fmd_index.h", "fmd_host.h", "fmd_internal.h", "fmd_api.cpp")
+KERNEL_FAMILIES = {
+    "tile_even": ("fmd_tile_lds_even.hip",) + _TILE_COMMON,      # downsample 2 ... 14 (the headline: downsample 10)
+    "tile_wide": ("fmd_tile_lds_wide.hip",) + _TILE_COMMON,      # downsample 16 ... 128 and the catch-all
+    "tile_odd": ("fmd_tile_lds_odd.hip",) + _TILE_COMMON,        # odd factors
+    "stream": ("fmd_tile_stream.hip",) + _TILE_COMMON,           # register-streaming kernels (downsample 2, 4)
+    "fir": ("fmd_fir.hip", "fmd_fir_common.h", "fmd_host.h", "fmd_internal.h"),
+    "fused": ("fmd_firdemod.hip", "fmd_fir_common.h", "fmd_device.h", "fmd_index.h", "fmd_kernels.h", "fmd_host.h", "fmd_internal.h"),
+}
+HEADLINE_FAMILY = "tile_even"
+
+
+def family_hashes():
+    """sha256 (16 hex digits) over each kernel family's sources."""
+    csrc = os.path.join(ROOT, "rtl-sdr-rs_amd", "csrc")
+    out = {}
+    for fam, files in KERNEL_FAMILIES.items():
+        h = hashlib.sha256()
+        for f in files:
+            h.update(f.encode())
+            h.update(open(os.path.join(csrc, f), "rb").read())
+        out[fam] = h.hexdigest()[:16]
+    return out
 
 
 def kernel_source_hash():
-    """sha256 over the headline kernel's sources: ties a committed PMC summary to the code it was measured on."""
-    h = hashlib.sha256()
-    csrc = os.path.join(ROOT, "rtl-sdr-rs_amd", "csrc")
-    for f in HEADLINE_SOURCES:
-        h.update(f.encode())
-        h.update(open(os.path.join(csrc, f), "rb").read())
-    return h.hexdigest()[:16]
+    """The headline kernel's family: ties a committed PMC summary to the code it was measured on."""
+    return family_hashes()[HEADLINE_FAMILY]
+
+
+def family_of_kernel(name):
+    """Kernel name (as fmd_*_last_kernel / rocprofv3 print it) -> family key."""
+    import re
+    name = name or ""
+    if "fmd_firdemod" in name:
+        return "fused"
+    if "fmd_fir_" in name:
+        return "fir"
+    if "fmd_demod_stream_kernel" in name:
+        return "stream"
+    m = re.search(r"fmd_demod_tile_kernel<(-?\d+),", name)
+    if m:
+        dh = int(m.group(1))
+        return "tile_odd" if dh < 0 else ("tile_even" if 1 <= dh <= 7 else "tile_wide")
+    return None
 
 
 def load_bounds():
-    """profiles/r05_bounds.json (scripts/summarize_bounds.py): how busy the vector / scalar / matrix pipes were per row, from the committed
-    PMC passes -- quoted only when they were taken on THESE kernel sources (same rule as the traffic figure)."""
+    """profiles/r06_bounds.json (scripts/summarize_bounds.py): how busy the vector / scalar / matrix pipes were per row, from the committed
+    PMC passes -- each row quoted only when it was taken on THESE sources of its kernel family."""
     try:
         with open(os.path.join(ROOT, BOUNDS)) as f:
             b = json.load(f)
     except (OSError, ValueError):
         return None
-    b["current"] = b.get("kernel_source_sha16") == kernel_source_hash()
+    now = family_hashes()
+    meas = b.get("family_sha16") or {}
+    b["family_current"] = {fam: meas.get(fam) == h for fam, h in now.items()}
+    b["current"] = all(b["family_current"].values())
     return b
+
+
+CO_BOUND_WITHIN = 0.03
 
 
 def bound_fields(b, key, hbm_frac, section="demod"):
     """`bound` + the pipe fractions of one row: the largest of the launch's HBM fraction and the vector / scalar / matrix pipes' issue
-    fractions under the counters (method and units: scripts/summarize_bounds.py, profiles/README.md)."""
+    fractions under the counters -- "co-bound" when the two largest are within 0.03 of each other (the model is good to a few
+    percent: scripts/summarize_bounds.py, profiles/README.md).  A row whose kernel family has been edited since the counters were
+    taken is REFUSED (no figures), not quoted as "indicative"."""
     if not b:
         return {}
     row = (b.get(section) or {}).get(key) if section == "demod" else b.get(section)
     if not row:
         return {}
-    out = {k: row[k] for k in ("valu_issue_frac", "salu_issue_frac", "mfma_busy_frac", "lds_bank_conflict_share") if row.get(k) is not None}
+    fam = family_of_kernel(row.get("kernel")) or {"config4_fir": "fir", "config4_fir_demod_fused": "fused"}.get(section)
+    if not (b.get("family_current") or {}).get(fam, False):
+        return {"bound_source": "%s: refused -- its counters were taken on other sources of the '%s' kernels; re-run scripts/gpu_round.sh" % (BOUNDS, fam)}
+    out = {k: row[k] for k in ("valu_issue_frac", "salu_issue_frac", "mfma_busy_frac", "lds_bank_conflict_share", "compute_alone_cycles_frac") if row.get(k) is not None}
     cand = {"hbm": hbm_frac, "valu": row.get("valu_issue_frac") or 0.0, "salu": row.get("salu_issue_frac") or 0.0, "mfma": row.get("mfma_busy_frac") or 0.0}
-    out["bound"] = max(cand, key=cand.get)
-    out["bound_source"] = "%s%s" % (BOUNDS, "" if b.get("current") else " (taken on EARLIER kernel sources: indicative only)")
+    order = sorted(cand, key=cand.get, reverse=True)
+    out["bound"] = "co-bound" if cand[order[0]] - cand[order[1]] <= CO_BOUND_WITHIN else order[0]
+    out["bound_top2"] = order[:2]
+    out["bound_source"] = BOUNDS
     return out
 
 
@@ -227,7 +276,12 @@ def extra_config4(fmd, torch, dev, stream, fused, bounds=None):
         bank = fmd.FirBank(taps, M, nch, device_id=dev.index)
         cap = bank.out_cap(n)
         out = torch.zeros((nch, cap, 2), dtype=torch.int32, device=dev)
-        call = lambda i: bank.filter_device(bufs[i % 3].data_ptr(), n, out.data_ptr(), cap, stream)
+        # A third of this operator's bytes are WRITTEN (int32 re, im), and one 268 MB output buffer written again by every call partly
+        # stays in the 256 MB memory-side cache.  `frac` is therefore measured with the calls rotating over FOUR output buffers (1.07 GB:
+        # every written byte goes to HBM) -- the steady state of a consumer that keeps its outputs (the honest figure);
+        # the one-buffer run is the side field `one_output_buffer`.
+        outs = [out] + [torch.zeros_like(out) for _ in range(3)]
+        call = lambda i: bank.filter_device(bufs[i % 3].data_ptr(), n, outs[i % 4].data_ptr(), cap, stream)
         out_bytes = lambda k: 8 * k
     ms, lo, hi, nout = time_calls(torch, call)
     if fused:
@@ -235,7 +289,7 @@ def extra_config4(fmd, torch, dev, stream, fused, bounds=None):
     alg = nch * n + nch * out_bytes(int(nout))
     res = {"workload": "BASELINE configs[3]: %d-tap FIR, decimate %d, %d channels x %d B/call (20 Msps x 52.4 ms)%s"
                        % (T, M, nch, n, ", fused with the discriminator and the %d -> %d Hz resampler" % (fast, slow) if fused else ""),
-           "kernel": bank.kernel_name() if fused else "fmd_fir_mfma_kernel", "ms_per_call": round(ms, 4),
+           "kernel": bank.kernel_name(), "ms_per_call": round(ms, 4),
            "ms_min_max": [round(lo, 4), round(hi, 4)],
            "iq_msamples_per_s": round(nch * (n // 2) / ms / 1e3, 1), "outputs_per_channel": int(nout),
            "algorithmic_bytes_per_launch": alg, "GBps": round(alg / ms / 1e6, 1), "frac": round(alg / ms / 1e6 / HBM_PEAK_GBS, 4)}
@@ -252,23 +306,24 @@ def extra_config4(fmd, torch, dev, stream, fused, bounds=None):
         res["taps_8bit_one_digit"] = {"kernel": bank8.kernel_name(), "ms_per_call": round(ms8, 4), "frac": round(alg / ms8 / 1e6 / HBM_PEAK_GBS, 4)}
         del bank8
     if not fused:
-        # A third of this operator's bytes are WRITTEN (int32 re, im), and one 268 MB output buffer written again by every call
-        # partly stays in the 256 MB memory-side cache.  The same calls rotating over four output buffers (1.07 GB: every written
-        # byte goes to HBM) are the steady state of a consumer that keeps the outputs; `frac` above stays the round-to-round figure.
-        outs = [out] + [torch.zeros_like(out) for _ in range(3)]
-        ms4, lo4, hi4, _ = time_calls(torch, lambda i: bank.filter_device(bufs[i % 3].data_ptr(), n, outs[i % 4].data_ptr(), cap, stream),
+        ms1, lo1, hi1, _ = time_calls(torch, lambda i: bank.filter_device(bufs[i % 3].data_ptr(), n, out.data_ptr(), cap, stream),
                                       settle=60, steps=60, regions=3)
-        res["rotating_4_output_buffers"] = {"ms_per_call": round(ms4, 4), "frac": round(alg / ms4 / 1e6 / HBM_PEAK_GBS, 4)}
+        res["output_buffers"] = 4
+        res["one_output_buffer"] = {"ms_per_call": round(ms1, 4), "frac": round(alg / ms1 / 1e6 / HBM_PEAK_GBS, 4),
+                                    "note": "the same calls writing ONE 268 MB buffer again and again: partly resident in the 256 MB memory-side cache (round 5's `frac`)"}
         res["note"] = ("33 % of the bytes are outputs; reads alone stream at ~6.7 TB/s, written bytes at ~4.9 TB/s, the matrix phase is "
-                       "hidden (-1.9 % without it): profiles/r05_experiments.md section 12")
+                       "hidden (-1.9 % without it): profiles/r05_experiments.md section 12; round 6: outputs leave the wave in lane order "
+                       "(whole lines per store instruction): profiles/r06_experiments.md")
         del outs
         # the same shape with an 8-bit filter (every |tap| <= 127): one i8 digit per tap, eight outputs per operand column -- the
         # same matrix instructions and LDS operand reads cover twice the outputs
         taps8 = rng.integers(-127, 128, T).astype(np.int16)
         bank8 = fmd.FirBank(taps8, M, nch, device_id=dev.index)
-        ms8, lo8, hi8, _ = time_calls(torch, lambda i: bank8.filter_device(bufs[i % 3].data_ptr(), n, out.data_ptr(), cap, stream),
+        outs8 = [out] + [torch.zeros_like(out) for _ in range(3)]
+        ms8, lo8, hi8, _ = time_calls(torch, lambda i: bank8.filter_device(bufs[i % 3].data_ptr(), n, outs8[i % 4].data_ptr(), cap, stream),
                                       settle=60, steps=60, regions=3)
-        res["taps_8bit_one_digit"] = {"tap_digits": bank8.tap_digits(), "ms_per_call": round(ms8, 4), "frac": round(alg / ms8 / 1e6 / HBM_PEAK_GBS, 4)}
+        del outs8
+        res["taps_8bit_one_digit"] = {"tap_digits": bank8.tap_digits(), "kernel": bank8.kernel_name(), "ms_per_call": round(ms8, 4), "frac": round(alg / ms8 / 1e6 / HBM_PEAK_GBS, 4)}
         res["tap_digits"] = bank.tap_digits()
         del bank8
     del bank, out, bufs
@@ -412,6 +467,33 @@ def extra_check_per_step(fmd, torch, bank, bufs, out, cap, stream, steps=200):
     nch = bufs[0].shape[0]
     return {"what": "demodulate_device + fmd_demod_check after every step (host wall time, %d steps)" % steps,
             "ms_per_step": round(ms, 4), "iq_msamples_per_s": round(nch * (BLOCK // 2) / ms / 1e3, 1)}
+
+
+def extra_check_pipelined(fmd, torch, bank, bufs, out, cap, stream, steps=200):
+    """The same cadence with the completion point ONE LAUNCH BACK (fmd_demod_check_prev, round 6): enqueue buffer n, settle buffer
+    n - 1 while n runs -- what `loop { demodulate(buf); output(audio) }` of simple_fm.rs:150-156 becomes when the consumer lags one
+    buffer.  Two output buffers alternate (a launch's buffer stays untouched until it is settled).  Host wall time per step."""
+    out2 = torch.zeros_like(out)
+    outs = (out, out2)
+    for i in range(20):
+        bank.demodulate_device(bufs[i % len(bufs)].data_ptr(), BLOCK, outs[i & 1].data_ptr(), cap, None, stream)
+        bank.check_prev()
+    bank.check()
+    t_enq = t_wait = 0.0
+    t0 = time.perf_counter()
+    for i in range(steps):
+        ta = time.perf_counter()
+        bank.demodulate_device(bufs[i % len(bufs)].data_ptr(), BLOCK, outs[i & 1].data_ptr(), cap, None, stream)
+        tb = time.perf_counter()
+        bank.check_prev()
+        tc = time.perf_counter()
+        t_enq += tb - ta; t_wait += tc - tb
+    bank.check()
+    ms = (time.perf_counter() - t0) / steps * 1e3
+    nch = bufs[0].shape[0]
+    return {"what": "demodulate_device(n) + fmd_demod_check_prev (settles n - 1 while n runs) every step, fmd_demod_check at the end (host wall time, %d steps)" % steps,
+            "ms_per_step": round(ms, 4), "iq_msamples_per_s": round(nch * (BLOCK // 2) / ms / 1e3, 1),
+            "host_ms_in_enqueue": round(t_enq / steps * 1e3, 4), "host_ms_in_check_prev": round(t_wait / steps * 1e3, 4)}
 
 
 def extra_sink_pcie(fmd, dev_index, nch=1024, steps=20):
@@ -903,6 +985,7 @@ def main():
             bounds = load_bounds()
             side = [("cfg_ref", lambda: extra_cfg_ref(fmd, torch, dev, stream, bufs, bounds)),
                     ("check_per_step", lambda: extra_check_per_step(fmd, torch, bank, bufs, out, cap, stream)),
+                    ("check_pipelined", lambda: extra_check_pipelined(fmd, torch, bank, bufs, out, cap, stream)),
                     ("config2_1channel", lambda: extra_config2(fmd, torch, dev, stream)),
                     ("config4_fir", lambda: extra_config4(fmd, torch, dev, stream, False, bounds)),
                     ("config4_fir_demod_fused", lambda: extra_config4(fmd, torch, dev, stream, True, bounds)),

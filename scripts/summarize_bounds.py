@@ -35,7 +35,11 @@ for l in open(os.path.join(g, tag + "_pmc_configs.jsonl")):
     r = rows.setdefault(key, {"config": d["config"], "kernel": d.get("kernel_reported"), "waves_per_launch": d["waves_per_launch"], "per_wave": {}})
     r["per_wave"].update(d["per_wave"])
     sha = d.get("kernel_source_sha16", sha)
-out = {"kernel_source_sha16": sha, "method": __doc__.split("Units", 1)[1].strip(), "demod": {}}
+# the hashes of every kernel family's sources AS MEASURED (written on the GPU box by scripts/gpu_round.sh): bench.py quotes a row only
+# while its family still hashes the same
+fam_file = os.path.join(g, tag + "_family_sha16.json")
+fam = json.load(open(fam_file)) if os.path.exists(fam_file) else {}
+out = {"kernel_source_sha16": sha, "family_sha16": fam, "method": __doc__.split("Units", 1)[1].strip(), "demod": {}}
 for key, r in rows.items():
     p, w = r["per_wave"], r["waves_per_launch"]
     if "SQ_BUSY_CYCLES" not in p or "SQ_ACTIVE_INST_VALU" not in p or "SQ_INSTS_VALU" not in p:
@@ -49,6 +53,29 @@ for key, r in rows.items():
          "valu_per_wave": p.get("SQ_INSTS_VALU"), "salu_per_wave": p.get("SQ_INSTS_SALU"),
          "lds_bank_conflict_share": round(p["SQ_LDS_BANK_CONFLICT"] / p["SQ_LDS_IDX_ACTIVE"], 3) if p.get("SQ_LDS_IDX_ACTIVE") else None}
     out["demod"][key] = o
+# ---- the compute side ALONE (scripts/gpu_pmc_alone.sh): shader clocks of the experiment build with the staging loads ablated over the
+# shader clocks of the same build unablated -- clock-independent, needs no price list, never above 1 by construction
+alone_file = os.path.join(g, tag + "_pmc_alone.jsonl")
+if os.path.exists(alone_file):
+    cyc = {}
+    for l in open(alone_file):
+        d = json.loads(l)
+        if "SQ_BUSY_CYCLES" in d.get("per_launch", {}):
+            cyc.setdefault(d["kernel"], {})[d["dbg"]] = d["per_launch"]["SQ_BUSY_CYCLES"]
+    for o in out["demod"].values():
+        c = cyc.get(o["kernel"])
+        if c and 0 in c and 16 in c and "stream_kernel" not in o["kernel"]:      # (the streaming kernel stages nothing: the ablation does not apply)
+            o["compute_alone_cycles_frac"] = round(c[16] / c[0], 3)
+# ---- calibration of the price list: the instruction-count model prices a vector instruction at the issue clocks of
+# tools/valu_weights.py's classes; a pipe cannot be more than 100 % busy, so the row that comes out highest caps the price -- every
+# row's vector fraction is scaled by the same factor so that it reads 1.00 (the weights overstate by that much: 2 % in round 5)
+top = max((o["valu_issue_frac"] for o in out["demod"].values()), default=0.0)
+scale = 1.0 / top if top > 1.0 else 1.0
+out["valu_weight_scale"] = round(scale, 4)
+if scale != 1.0:
+    for o in out["demod"].values():
+        o["valu_issue_frac_uncalibrated"] = o["valu_issue_frac"]
+        o["valu_issue_frac"] = round(o["valu_issue_frac"] * scale, 3)
 for name, sub in (("config4_fir", tag + "_pmc_fir"), ("config4_fir_demod_fused", tag + "_pmc_fd")):
     f = os.path.join(g, sub, "summary.json")
     if not os.path.exists(f):
@@ -59,7 +86,7 @@ for name, sub in (("config4_fir", tag + "_pmc_fir"), ("config4_fir_demod_fused",
     cyc = c["SQ_BUSY_CYCLES"] / N_SE
     o = {"launch_cycles_under_pmc": round(cyc), "waves_per_launch": round(c.get("SQ_WAVES", 0))}
     kname = {"config4_fir": "(anonymous namespace)::fmd_fir_mfma_kernel<6, false, 3>", "config4_fir_demod_fused": "(anonymous namespace)::fmd_firdemod_regs_kernel<6, 8, true>"}[name]
-    kw = kernel_weight(kname)
+    kw = kernel_weight(kname) * scale
     o["kernel"], o["valu_clocks_per_instruction"] = kname, round(kw, 3)
     if "SQ_INSTS_VALU" in c:
         o["valu_issue_frac"] = round(c["SQ_INSTS_VALU"] * kw / N_SIMD / cyc, 3)

@@ -3,6 +3,12 @@
 committed summaries under profiles/.  Usage: summarize_profiles.py <tag> [round-prefix, default r01]"""
 import collections, csv, glob, json, os, shutil, sys
 
+def family_sha(g, tag, fam):
+    """The hash of one kernel family's sources as they were on the GPU box of session `tag` (scripts/gpu_round.sh writes the file)."""
+    f = os.path.join(g, tag + "_family_sha16.json")
+    return json.load(open(f)).get(fam) if os.path.exists(f) else None
+
+
 def summarize_firdemod(g, tag, rnd, out):
     """Fused FIR -> discriminator -> resampler kernel (config 4): bench line + PMC passes (scripts/gpu_pmc_firdemod.sh)."""
     fd = os.path.join(g, tag + "_firdemod.json")
@@ -16,6 +22,7 @@ def summarize_firdemod(g, tag, rnd, out):
         alg = line.get("GBps", 0) * line.get("ms", 0) * 1e6
         fetch, wr = c["FETCH_SIZE"]["mean_per_launch"] * 2048, c["WRITE_SIZE"]["mean_per_launch"] * 1024
         pf = {"command": "rocprofv3 --kernel-trace --pmc <set> -- python3 tools/bench_firdemod.py (scripts/gpu_pmc_firdemod.sh; one pass per counter set)",
+              "family_sha16": {"fused": family_sha(g, tag, "fused")},
               "bench_line_same_session": line, "counters": c,
               "per_wave": {k: round(c[k]["mean_per_launch"] / w, 2) for k in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_INSTS_VMEM_RD", "SQ_INSTS_MFMA",
                                                                             "SQ_WAVE_CYCLES", "SQ_ACTIVE_INST_VALU", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_LDS_BANK_CONFLICT", "SQ_LDS_IDX_ACTIVE") if k in c},
@@ -25,7 +32,7 @@ def summarize_firdemod(g, tag, rnd, out):
 
 
 tag = sys.argv[1]
-rnd = sys.argv[2] if len(sys.argv) > 2 else "r05"
+rnd = sys.argv[2] if len(sys.argv) > 2 else "r06"
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src, pmc, out = os.path.join(root, "gpurun_out", tag), os.path.join(root, "gpurun_out", tag + "_pmc"), os.path.join(root, "profiles")
 if "--firdemod-only" in sys.argv:      # a session that re-measured only the fused FIR kernel (its source is not one of the headline's)
@@ -78,7 +85,7 @@ fetch_kb, write_kb = counters["FETCH_SIZE"]["mean_per_launch"], counters["WRITE_
 traffic = fetch_kb * 1024 * 2 + write_kb * 1024
 pm = {"command": "rocprofv3 --kernel-trace --pmc <set> -- python3 bench.py --steps 10 --warmup 2 --settle 20 --no-cpu --no-extra  (scripts/gpu_pmc.sh; "
                  "one pass per counter set; never combined with --sys-trace)",
-      "kernel": KERNEL, "kernel_source_sha16": measured_hash, "counters": counters,
+      "kernel": KERNEL, "kernel_source_sha16": measured_hash, "family_sha16": {"tile_even": measured_hash}, "counters": counters,
       "per_wave": {"valu": counters["SQ_INSTS_VALU"]["mean_per_launch"] / waves, "salu": counters["SQ_INSTS_SALU"]["mean_per_launch"] / waves,
                    "lds": counters["SQ_INSTS_LDS"]["mean_per_launch"] / waves, "vmem_rd": counters["SQ_INSTS_VMEM_RD"]["mean_per_launch"] / waves},
       "hbm_traffic": {"fetch_size_kb": fetch_kb, "write_size_kb": write_kb,
@@ -130,6 +137,7 @@ if os.path.exists(fj) and os.path.exists(fs) and not os.path.exists(os.path.join
     fetch, wr = c["FETCH_SIZE"]["mean_per_launch"] * 2048, c["WRITE_SIZE"]["mean_per_launch"] * 1024
     pf = {"command": "rocprofv3 --kernel-trace --pmc <set> -- python3 tools/bench_fir.py (scripts/gpu_pmc_fir.sh; one pass per counter set)",
           "kernel": c.get("kernel_name"), "kernel_ns_under_pmc": c.get("kernel_ns_under_pmc"), "bench_line_same_session": m,
+          "family_sha16": {"fir": family_sha(g, tag, "fir")},
           "counters": {k: v for k, v in c.items() if isinstance(v, dict) and "mean_per_launch" in v},
           "per_wave": {k: round(c[k]["mean_per_launch"] / w, 2) for k in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_INSTS_VMEM_RD", "SQ_INSTS_VMEM_WR", "SQ_INSTS_MFMA",
                                                                         "SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY") if k in c},

@@ -155,6 +155,28 @@ def test_driver_launch_line_two_ranks_on_one_box():
     assert r["config"]["torch_distributed"]["world_size"] == 2 and r["value"] > 0
 
 
+@pytest.mark.gpu
+def test_eight_ranks_on_one_box_emit_the_line_an_eight_gpu_node_will():
+    """the first real 8-GPU run (the driver's to launch) must not fail on plumbing.  The driver's launch line
+    with EIGHT ranks over gloo, all sharing this box's one GPU (small banks: 8 x 256 channels): one line, eight per-GPU rates, a
+    parity bit from every rank, world size 8, contiguous channel shards, no data-path collective."""
+    p = subprocess.run(torchrun_cmd(8, 29547, ["--backend", "gloo", "--steps", "3", "--warmup", "1", "--settle", "5", "--channels", "256",
+                                               "--min-timed-s", "0.02", "--cpu-seconds", "0.5", "--power-only"]),
+                       capture_output=True, env=clean_env(), timeout=1500)
+    assert p.returncode == 0, p.stderr.decode()[-3000:]
+    lines = [l for l in p.stdout.decode().splitlines() if l.startswith("{")]
+    assert len(lines) == 1, lines
+    r = json.loads(lines[0])
+    assert r["n_gpus"] == 8 and r["scaling"] == "weak" and r["value"] > 0
+    assert len(r["per_gpu_msamples_per_s"]) == 8 and all(v > 0 for v in r["per_gpu_msamples_per_s"])
+    assert r["config"]["torch_distributed"]["world_size"] == 8
+    assert r["config"]["parallelism"].startswith("channels sharded x8")
+    pr = r["parity"]
+    assert pr["ok"] is True and pr["ranks_checked"] == 8 and pr["ranks_ok"] == [True] * 8
+    assert [g["rank"] for g in r["extra"]["power_clock"]["per_gpu"]] == list(range(8))
+    assert r["roofline"]["kernel_is_expected"] is True
+
+
 def shape_of(x):
     """Keys and value types of a JSON line, recursively (numbers are one type): what "unchanged" means for a line."""
     if isinstance(x, dict):
@@ -200,8 +222,13 @@ def test_default_line_carries_parity_and_the_side_lines():
     assert r["roofline"]["traffic_measured_in_this_run"] is False
     ex = r["extra"]
     assert r["roofline"]["kernel_is_expected"] is True and r["parity"]["ranks_checked"] == 1
-    for k in ("cfg_ref", "check_per_step", "config2_1channel", "config4_fir", "config4_fir_demod_fused", "sink_pcie", "domain"):
+    for k in ("cfg_ref", "check_per_step", "check_pipelined", "config2_1channel", "config4_fir", "config4_fir_demod_fused", "sink_pcie", "domain"):
         assert k in ex and "error" not in ex[k], (k, ex.get(k))
+    # the completion point one launch back does not serialise host and device: within a few percent of the bare launches, and
+    # clearly below launch + check per buffer (fmd_demod_check_prev, round 6)
+    assert ex["check_pipelined"]["ms_per_step"] <= 1.06 * r["ms_per_step"] and ex["check_pipelined"]["ms_per_step"] < ex["check_per_step"]["ms_per_step"]
+    assert ex["config4_fir"]["output_buffers"] == 4 and ex["config4_fir"]["kernel"].startswith("(anonymous namespace)::fmd_fir_mfma_kernel<")
+    assert ex["config4_fir"]["one_output_buffer"]["frac"] > 0
     assert 0.3 < ex["cfg_ref"]["frac"] < 1.0 and ex["check_per_step"]["ms_per_step"] >= r["ms_per_step"] * 0.9
     assert ex["sink_pcie"]["all_status_ok"] and ex["sink_pcie"]["delivered"] >= 40
     rows = {row["downsample"]: row for row in ex["domain"]["rows"]}

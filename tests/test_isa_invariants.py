@@ -192,3 +192,25 @@ def test_committed_pmc_summary_belongs_to_these_kernel_sources():
     assert pmc.get("kernel_source_sha16") == bench.kernel_source_hash(), (
         "%s was measured on other kernel sources (%s, now %s): bench.py would report roofline.traffic = null -- re-run "
         "scripts/gpu_pmc.sh on the GPU box and scripts/summarize_profiles.py" % (bench.PMC_SUMMARY, pmc.get("kernel_source_sha16"), bench.kernel_source_hash()))
+
+
+def test_every_committed_counter_summary_belongs_to_its_kernel_family_sources():
+    """every figure bench.py quotes from counters -- the headline's traffic, the pipe fractions of the `extra` rows,
+    the FIR kernels' conflict shares -- is tied to the sources of ITS kernel family (bench.KERNEL_FAMILIES): an edit of fmd_fir.hip or
+    fmd_firdemod.hip without a re-run of scripts/gpu_round.sh is a red test here, not a row that silently quotes old counters."""
+    import bench
+    now = bench.family_hashes()
+    with open(os.path.join(ROOT, bench.BOUNDS)) as f:
+        b = json.load(f)
+    assert b.get("family_sha16") == now, "profiles bounds were measured on other kernel sources: %r, now %r" % (b.get("family_sha16"), now)
+    rnd = os.path.basename(bench.BOUNDS).split("_")[0]
+    for name, fam in (("config4_fir_pmc.json", "fir"), ("config4_firdemod_pmc.json", "fused"), ("pmc_summary.json", "tile_even")):
+        with open(os.path.join(ROOT, "profiles", "%s_%s" % (rnd, name))) as f:
+            d = json.load(f)
+        assert (d.get("family_sha16") or {}).get(fam) == now[fam], (name, d.get("family_sha16"), now[fam])
+    # and the loader refuses a stale family instead of labelling it "indicative"
+    bb = bench.load_bounds()
+    assert bb["current"] and all(bb["family_current"].values())
+    stale = dict(bb, family_current=dict(bb["family_current"], fir=False))
+    got = bench.bound_fields(stale, None, 0.7, section="config4_fir")
+    assert set(got) == {"bound_source"} and "refused" in got["bound_source"]
