@@ -180,6 +180,13 @@ int fmd_demod_check(fmd_demod *d);
  * Call fmd_demod_check after the LAST launch of a run.  (fmd_firdemod / the pipelined sink have their own completion points.) */
 int fmd_demod_check_prev(fmd_demod *d);
 
+/* EVENT ORDERING (opt-in, round 6): with on != 0 the handle records an event behind every launch and every later wait -- the next
+ * launch on another stream, fmd_demod_check / _check_prev / _get_state -- goes to that EVENT: a `stream` handed to
+ * fmd_demod_demodulate_device is never used again once that call has returned, so the stream lifetime rule above does not apply (for
+ * callers whose streams come from a pool that may destroy them).  Costs the record: +2 - 3 % per launch at the headline rates, which
+ * is why it is not the default.  Synchronises the device; call it between launches. */
+int fmd_demod_set_event_ordering(fmd_demod *d, int on);
+
 /* Diagnostics of the above: f64 samples that fell into the guard band / whose value had to be patched. */
 int fmd_demod_f64_stats(const fmd_demod *d, uint64_t *guarded, uint64_t *patched);
 

@@ -348,7 +348,7 @@ int enqueue(fmd_demod* d, const void* d_iq, size_t nbytes, void* d_out, size_t o
     } else {
         HIP_TRY(fmd_launch_generic(L, stream, &d->last_kernel));
     }
-    d->order.after(stream);
+    HIP_TRY(d->order.after(stream));
     d->seq += 1;
     {
         fmd_demod::Pending& pd = d->pend[d->seq & 1u];
@@ -453,9 +453,12 @@ namespace {
 int replay_launch(fmd_demod* d, fmd_demod::Pending& pd)
 {
     FmdKernelId used;
-    if (d->last_kernel.family == FMD_KERNEL_GENERIC) HIP_TRY(fmd_launch_generic(pd.L, pd.stream, &used));
-    else HIP_TRY(fmd_launch_tile(pd.L, pd.stream, &used));
-    HIP_TRY(hipStreamSynchronize(pd.stream));
+    // (the caller has synchronised the device; event mode: the handle's own stream -- the caller's may be gone)
+    hipStream_t rs = d->order.event_mode ? d->stream : pd.stream;
+    if (d->last_kernel.family == FMD_KERNEL_GENERIC) HIP_TRY(fmd_launch_generic(pd.L, rs, &used));
+    else HIP_TRY(fmd_launch_tile(pd.L, rs, &used));
+    HIP_TRY(hipStreamSynchronize(rs));
+    if (d->order.event_mode) HIP_TRY(hipEventRecord(d->order.ev, rs));      // the newest launch's event is now the second run's
     return FMD_OK;
 }
 
@@ -880,9 +883,13 @@ int fmd_demod_check(fmd_demod* d)
     if (d->order.have_last && d->h_head && !d->exc_override) {
         const bool both = !d->pend[(d->seq + 1u) & 1u].settled;          // launch seq - 1 was never checked: its buffer too
         for (int i = 0; i < 8; ++i) d->h_head[i] = i < 4 || both ? ~0u : 0u;
-        hipError_t e = hipMemcpyAsync(d->h_head, d->d_exc + (d->seq & 1u), 16, hipMemcpyDeviceToHost, d->order.last);
-        if (e == hipSuccess && both) e = hipMemcpyAsync(d->h_head + 4, d->d_exc + ((d->seq + 1u) & 1u), 16, hipMemcpyDeviceToHost, d->order.last);
-        if (e == hipSuccess) e = hipStreamSynchronize(d->order.last);
+        // (event mode: the handle's OWN stream waits for the launch's event and carries the copies -- the caller's stream is not touched)
+        hipStream_t cs = d->order.last;
+        hipError_t e = hipSuccess;
+        if (d->order.event_mode) { cs = d->stream; e = hipStreamWaitEvent(cs, d->order.ev, 0); }
+        if (e == hipSuccess) e = hipMemcpyAsync(d->h_head, d->d_exc + (d->seq & 1u), 16, hipMemcpyDeviceToHost, cs);
+        if (e == hipSuccess && both) e = hipMemcpyAsync(d->h_head + 4, d->d_exc + ((d->seq + 1u) & 1u), 16, hipMemcpyDeviceToHost, cs);
+        if (e == hipSuccess) e = hipStreamSynchronize(cs);
         if (e == hipSuccess && d->h_head[0] == 0u && d->h_head[1] == 0u && d->h_head[4] == 0u && d->h_head[5] == 0u) {
             d->pend[0].settled = d->pend[1].settled = true;
             return FMD_OK;
@@ -919,12 +926,12 @@ int fmd_demod_check_prev(fmd_demod* d)
             const double waited = (double)(ts.tv_sec - ts0.tv_sec) + 1e-9 * (double)(ts.tv_nsec - ts0.tv_nsec);
             if (waited >= next_query_s) {
                 next_query_s = waited + 1.0e-3;
-                const hipError_t q = hipStreamQuery(pn.stream);
+                const hipError_t q = d->order.query_last();
                 if (q == hipSuccess) {                       // the newest launch has completed too -- the post is there, or never comes
                     if ((int32_t)((uint32_t)(word = __atomic_load_n(m, __ATOMIC_ACQUIRE)) - target) < 0) return fmd_demod_check(d);
                     break;
                 }
-                if (q != hipErrorNotReady) { set_err("hipStreamQuery: %s", hipGetErrorString(q)); (void)hipGetLastError(); return FMD_ERR_HIP; }
+                if (q != hipErrorNotReady) { set_err("querying the newest launch: %s", hipGetErrorString(q)); (void)hipGetLastError(); return FMD_ERR_HIP; }
             }
         }
 #if defined(__x86_64__) || defined(__i386__)
@@ -937,6 +944,21 @@ int fmd_demod_check_prev(fmd_demod* d)
     // that produced them -- both are still the caller's to keep -- and a corrected carried sum re-runs the newest launch).
     HIP_TRY(hipDeviceSynchronize());
     return resolve_device_reports(d, nullptr, 0);
+}
+
+int fmd_demod_set_event_ordering(fmd_demod* d, int on)
+{
+    if (!d) { set_err("null argument"); return FMD_ERR_INVALID_ARG; }
+    ON_DEVICE(d->device);
+    HIP_TRY(hipDeviceSynchronize());                         // the switch happens between launches, with nothing in flight
+    {
+        const int rr = resolve_device_reports(d, nullptr, 0);
+        if (rr) return rr;
+    }
+    if (on) HIP_TRY(d->order.ensure_event());
+    d->order.event_mode = on != 0;
+    d->order.reset();
+    return FMD_OK;
 }
 
 int fmd_demod_f64_stats(const fmd_demod* d, uint64_t* guarded, uint64_t* patched)

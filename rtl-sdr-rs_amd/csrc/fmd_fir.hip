@@ -578,7 +578,7 @@ int fir_enqueue(fmd_fir* f, const void* d_iq, size_t nbytes, void* d_out, size_t
         hipLaunchKernelGGL(fmd_fir_hist_kernel, dim3((uint32_t)((th + kFirThreads - 1) / kFirThreads)), dim3(kFirThreads), 0, stream, L);
         FIR_TRY(hipGetLastError());
     }
-    f->order.after(stream);
+    (void)f->order.after(stream);
     if (f->Hw) f->cur ^= 1;
     f->pos += ns;
     if (n_each) *n_each = (size_t)n_out;

@@ -1049,7 +1049,7 @@ int fd_enqueue(fmd_firdemod* f, const void* d_iq, size_t nbytes, void* d_out, si
         default: launch<8>(L, g, lds, stream); break;
     }
     FD_TRY(hipGetLastError());
-    f->order.after(stream);
+    (void)f->order.after(stream);
     f->seq += 1;
     f->cur ^= 1;
     f->i0r = fmd_next_lpr_index_r(r, f->i0r, L.P.M, L.P.K);

@@ -61,18 +61,50 @@ struct FmdStreamOrder {
     hipStream_t last = nullptr;
     bool have_last = false;
     hipEvent_t ev = nullptr;
+    // EVENT MODE (round 6, opt-in per handle: fmd_demod_set_event_ordering): an event is recorded behind EVERY launch and every later
+    // wait -- the next launch's stream, the completion points -- goes to the EVENT; the caller's stream handle is never used again
+    // after the enqueue call has returned, so the lifetime rule above does not apply (a stream from a pool that destroys it at will
+    // is fine).  Costs the record: +2 - 3 % per launch at the headline rates (profiles/r05_experiments.md 1), which is why it is not
+    // the default.
+    bool event_mode = false;
 
+    hipError_t ensure_event()
+    {
+        return ev ? hipSuccess : hipEventCreateWithFlags(&ev, hipEventDisableTiming);
+    }
     // Call before enqueueing on `stream`.
     hipError_t before(hipStream_t stream)
     {
-        if (!have_last || stream == last) return hipSuccess;
-        if (!ev) { hipError_t e = hipEventCreateWithFlags(&ev, hipEventDisableTiming); if (e != hipSuccess) return e; }
-        hipError_t e = hipEventRecord(ev, last);           // everything submitted to the old stream so far
+        if (!have_last) return hipSuccess;
+        if (event_mode) return hipStreamWaitEvent(stream, ev, 0);      // (recorded by after(): always there once have_last is set)
+        if (stream == last) return hipSuccess;
+        hipError_t e = ensure_event();
+        if (e != hipSuccess) return e;
+        e = hipEventRecord(ev, last);                      // everything submitted to the old stream so far
         if (e == hipSuccess) e = hipStreamWaitEvent(stream, ev, 0);
         if (e != hipSuccess) { (void)hipGetLastError(); e = hipDeviceSynchronize(); }   // be safe
         return e;
     }
-    void after(hipStream_t stream) { last = stream; have_last = true; }
+    hipError_t after(hipStream_t stream)
+    {
+        last = stream; have_last = true;
+        if (!event_mode) return hipSuccess;
+        hipError_t e = ensure_event();
+        if (e == hipSuccess) e = hipEventRecord(ev, stream);
+        return e;
+    }
+    // Wait for the handle's most recent launch (completion points).
+    hipError_t wait_last()
+    {
+        if (!have_last) return hipSuccess;
+        return event_mode ? hipEventSynchronize(ev) : hipStreamSynchronize(last);
+    }
+    // hipSuccess: the most recent launch has completed; hipErrorNotReady: still running.
+    hipError_t query_last()
+    {
+        if (!have_last) return hipSuccess;
+        return event_mode ? hipEventQuery(ev) : hipStreamQuery(last);
+    }
     void reset() { have_last = false; }
     void destroy() { if (ev) (void)hipEventDestroy(ev); ev = nullptr; have_last = false; }
 };

@@ -43,7 +43,11 @@ class PinnedBuffer:
             check(lib().fmd_host_free(self._p))
             self._p = C.c_void_p()
 
-    __del__ = close
+    def __del__(self):
+        try:                                                 # (at interpreter shutdown the module globals may be gone already)
+            self.close()
+        except Exception:
+            pass
 
 
 class DemodBank:
@@ -61,7 +65,11 @@ class DemodBank:
             lib().fmd_demod_free(self._h)
             self._h = C.c_void_p()
 
-    __del__ = close
+    def __del__(self):
+        try:                                                 # (at interpreter shutdown the module globals may be gone already)
+            self.close()
+        except Exception:
+            pass
 
     def reset(self):
         check(lib().fmd_demod_reset(self._h))
@@ -109,6 +117,11 @@ class DemodBank:
         Until a launch has been settled its output buffer stays allocated and unread and its input buffer unmodified (include/fmd.h);
         the stream of the handle's most recent launch must be alive, as for `check`."""
         check(lib().fmd_demod_check_prev(self._h))
+
+    def set_event_ordering(self, on=True):
+        """fmd_demod_set_event_ordering: record an event behind every launch and wait on events only -- the streams handed to
+        `demodulate_device` need not outlive the call (+2 - 3 % per launch)."""
+        check(lib().fmd_demod_set_event_ordering(self._h, 1 if on else 0))
 
     def f64_stats(self):
         g, p = C.c_uint64(), C.c_uint64()

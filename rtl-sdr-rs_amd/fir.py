@@ -24,7 +24,11 @@ class FirBank:
             lib().fmd_fir_free(self._h)
             self._h = C.c_void_p()
 
-    __del__ = close
+    def __del__(self):
+        try:                                                 # (at interpreter shutdown the module globals may be gone already)
+            self.close()
+        except Exception:
+            pass
 
     def reset(self):
         check(lib().fmd_fir_reset(self._h))
@@ -92,7 +96,11 @@ class FirDemodBank:
             lib().fmd_firdemod_free(self._h)
             self._h = C.c_void_p()
 
-    __del__ = close
+    def __del__(self):
+        try:                                                 # (at interpreter shutdown the module globals may be gone already)
+            self.close()
+        except Exception:
+            pass
 
     def reset(self):
         check(lib().fmd_firdemod_reset(self._h))

@@ -137,7 +137,11 @@ class RtlTcpSourceC:
             self._lib.fmd_rtltcp_close(self._h)
             self._h = self._C.c_void_p()
 
-    __del__ = close
+    def __del__(self):
+        try:                                                 # (at interpreter shutdown the module globals may be gone already)
+            self.close()
+        except Exception:
+            pass
 
     def __enter__(self):
         return self

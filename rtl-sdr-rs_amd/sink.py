@@ -42,7 +42,11 @@ class Sink:
             lib().fmd_sink_free(self._h)
             self._h = C.c_void_p()
 
-    __del__ = close
+    def __del__(self):
+        try:                                                 # (at interpreter shutdown the module globals may be gone already)
+            self.close()
+        except Exception:
+            pass
 
     def _reraise(self):
         if self._pending_exc is not None:

@@ -99,6 +99,7 @@ extern "C" {
     pub fn fmd_demod_set_block_len(d: *mut fmd_demod, block_bytes: usize) -> c_int;
     pub fn fmd_demod_check(d: *mut fmd_demod) -> c_int;
     pub fn fmd_demod_check_prev(d: *mut fmd_demod) -> c_int;
+    pub fn fmd_demod_set_event_ordering(d: *mut fmd_demod, on: c_int) -> c_int;
     pub fn fmd_demod_f64_stats(d: *const fmd_demod, guarded: *mut u64, patched: *mut u64) -> c_int;
     pub fn fmd_demod_last_out_len(d: *const fmd_demod, out_len: *mut usize) -> c_int;
     pub fn fmd_host_alloc(nbytes: usize, ptr: *mut *mut c_void) -> c_int;

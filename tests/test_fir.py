@@ -135,6 +135,18 @@ def test_gpu_fir_one_digit_form_matches_oracle(fmd, oracle, T, M):
 
 
 @pytest.mark.gpu
+def test_gpu_fir_kernel_name_follows_the_form(fmd):
+    """fmd_fir_kernel_name (round 6): the name rocprofv3 --kernel-trace prints for the handle's launches -- what bench.py quotes in
+    `extra.config4_fir.kernel` instead of a constant -- follows the form the taps select."""
+    rng = np.random.default_rng(2)
+    wide = rng.integers(-2047, 2048, 127).astype(np.int16)
+    assert fmd.FirBank(wide, 8).kernel_name() == "(anonymous namespace)::fmd_fir_mfma_kernel<6, false, 3>"      # config 4: sparse two-digit form
+    assert fmd.FirBank(np.clip(wide, -127, 127), 8).kernel_name() == "(anonymous namespace)::fmd_fir_mfma_kernel<6, false, 1>"
+    assert fmd.FirBank(wide, 4).kernel_name().endswith(", false, 2>")                                           # decim < 8: dense two digits
+    assert fmd.FirBank(np.ones(4, np.int16), 128).kernel_name() == "(anonymous namespace)::fmd_fir_kernel"       # vector-pipe kernel
+
+
+@pytest.mark.gpu
 def test_gpu_fir_digits_follow_the_taps(fmd):
     assert fmd.FirBank(np.full(9, 127, np.int16), 8).tap_digits() == 1
     assert fmd.FirBank(np.array([5, -128, 3], np.int16), 8).tap_digits() == 2      # -128 is one too many for the sign-flipped rows

@@ -140,3 +140,50 @@ def test_fir_alternating_streams(fmd, oracle):
             assert ns[i] == exp.shape[0] and np.array_equal(got[c, :ns[i]], exp), (i, c)
     for h in hs:
         oracle.lib.fmo_fir_free(h)
+
+
+def test_event_ordering_lets_the_callers_streams_die(fmd, oracle):
+    """fmd_demod_set_event_ordering (round 6, ADVICE r4 / r5: the remembered stream handle): with the opt-in on, every launch goes to a
+    stream of its own that is DESTROYED right after the enqueue call -- the library must never touch it again (ordering of the next
+    launch, fmd_demod_check_prev, fmd_demod_check all go to the event recorded behind the launch).  Eight launches, each on a fresh
+    stream, the completion point one launch back after every enqueue, bit-exact against the oracle."""
+    import torch
+    hip = hip_runtime()
+    hip.hipStreamCreate.argtypes = [C.POINTER(C.c_void_p)]
+    hip.hipStreamDestroy.argtypes = [C.c_void_p]
+    nch, N = 32, 65536
+    bank = fmd.DemodBank(mkcfg(fmd, *CFG_REF), nch)
+    bank.set_event_ordering(True)
+    obank = oracle.new_bank(oracle.config(*CFG_REF), nch)
+    cap = bank.out_cap(N)
+    torch.cuda.synchronize()
+    ins, outs, exps = [], [], []
+    for call in range(8):
+        iq = fmd.synth.synth_iq(nch, N, sample_offset=call * (N // 2), seed=3)
+        exps.append(oracle.demodulate_batch(obank, iq))
+        ins.append(torch.from_numpy(iq).cuda())
+        outs.append(torch.zeros((nch, cap), dtype=torch.int16, device="cuda"))
+    torch.cuda.synchronize()
+    for call in range(8):
+        s = C.c_void_p()
+        assert hip.hipStreamCreate(C.byref(s)) == 0
+        bank.demodulate_device(ins[call].data_ptr(), N, outs[call].data_ptr(), cap, None, s)
+        assert hip.hipStreamDestroy(s) == 0                 # the caller's stream is gone before anything else happens
+        bank.check_prev()
+        if call:
+            got, (exp, lens) = outs[call - 1].cpu().numpy(), exps[call - 1]
+            assert all(np.array_equal(got[c, :lens[c]], exp[c, :lens[c]]) for c in range(nch)), call - 1
+    bank.check()
+    got, (exp, lens) = outs[7].cpu().numpy(), exps[7]
+    assert all(np.array_equal(got[c, :lens[c]], exp[c, :lens[c]]) for c in range(nch))
+    assert bank.get_state(nch - 1).as_dict() == oracle.state_of(obank[nch - 1])
+    bank.set_event_ordering(False)                          # and back: the default ordering again
+    s2 = torch.cuda.Stream()
+    iq = fmd.synth.synth_iq(nch, N, sample_offset=8 * (N // 2), seed=3)
+    exp, lens = oracle.demodulate_batch(obank, iq)
+    d_iq = torch.from_numpy(iq).cuda()
+    torch.cuda.synchronize()
+    bank.demodulate_device(d_iq.data_ptr(), N, outs[0].data_ptr(), cap, None, s2.cuda_stream)
+    bank.check()
+    got = outs[0].cpu().numpy()
+    assert all(np.array_equal(got[c, :lens[c]], exp[c, :lens[c]]) for c in range(nch))
