@@ -348,7 +348,7 @@ int enqueue(fmd_demod* d, const void* d_iq, size_t nbytes, void* d_out, size_t o
     } else {
         HIP_TRY(fmd_launch_generic(L, stream, &d->last_kernel));
     }
-    HIP_TRY(d->order.after(stream));
+    const hipError_t e_after = d->order.after(stream);       // (event mode: records the launch's event; reported below, after the bookkeeping)
     d->seq += 1;
     {
         fmd_demod::Pending& pd = d->pend[d->seq & 1u];
@@ -357,6 +357,7 @@ int enqueue(fmd_demod* d, const void* d_iq, size_t nbytes, void* d_out, size_t o
     }
     d->cur ^= 1;
     advance_classes(d, nbytes, plans);
+    HIP_TRY(e_after);
     return FMD_OK;
 }
 
