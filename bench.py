@@ -470,30 +470,39 @@ def extra_check_per_step(fmd, torch, bank, bufs, out, cap, stream, steps=200):
 
 
 def extra_check_pipelined(fmd, torch, bank, bufs, out, cap, stream, steps=200):
-    """The same cadence with the completion point ONE LAUNCH BACK (fmd_demod_check_prev, round 6): enqueue buffer n, settle buffer
-    n - 1 while n runs -- what `loop { demodulate(buf); output(audio) }` of simple_fm.rs:150-156 becomes when the consumer lags one
-    buffer.  Two output buffers alternate (a launch's buffer stays untouched until it is settled).  Host wall time per step."""
-    out2 = torch.zeros_like(out)
-    outs = (out, out2)
-    for i in range(20):
-        bank.demodulate_device(bufs[i % len(bufs)].data_ptr(), BLOCK, outs[i & 1].data_ptr(), cap, None, stream)
-        bank.check_prev()
-    bank.check()
-    t_enq = t_wait = 0.0
-    t0 = time.perf_counter()
-    for i in range(steps):
-        ta = time.perf_counter()
-        bank.demodulate_device(bufs[i % len(bufs)].data_ptr(), BLOCK, outs[i & 1].data_ptr(), cap, None, stream)
-        tb = time.perf_counter()
-        bank.check_prev()
-        tc = time.perf_counter()
-        t_enq += tb - ta; t_wait += tc - tb
-    bank.check()
-    ms = (time.perf_counter() - t0) / steps * 1e3
+    """The same cadence with the completion point TWO LAUNCHES BACK (fmd_demod_check_behind, round 6): enqueue buffer n, settle buffer
+    n - 2 while n - 1 and n run -- what `loop { demodulate(buf); output(audio) }` of simple_fm.rs:150-156 becomes when the consumer lags
+    two buffers; a whole launch stays queued behind the running one, so a late host costs nothing.  Three output buffers rotate (a
+    launch's buffer stays untouched until it is settled).  Host wall time per step; `one_launch_back`: the same with back = 1."""
+    outs = (out, torch.zeros_like(out), torch.zeros_like(out))
+
+    def run(back):
+        for i in range(20):
+            bank.demodulate_device(bufs[i % len(bufs)].data_ptr(), BLOCK, outs[i % 3].data_ptr(), cap, None, stream)
+            bank.check_behind(back)
+        bank.check()
+        t_enq = t_wait = 0.0
+        t0 = time.perf_counter()
+        for i in range(steps):
+            ta = time.perf_counter()
+            bank.demodulate_device(bufs[i % len(bufs)].data_ptr(), BLOCK, outs[i % 3].data_ptr(), cap, None, stream)
+            tb = time.perf_counter()
+            bank.check_behind(back)
+            tc = time.perf_counter()
+            t_enq += tb - ta; t_wait += tc - tb
+        bank.check()
+        ms = (time.perf_counter() - t0) / steps * 1e3
+        return ms, t_enq / steps * 1e3, t_wait / steps * 1e3
+
+    g0 = bank.f64_stats()["guarded"]
+    ms, enq, wait = run(2)
+    guarded = bank.f64_stats()["guarded"] - g0       # launches with a report are settled while the newer ones run (no drain)
+    ms1, _, _ = run(1)
     nch = bufs[0].shape[0]
-    return {"what": "demodulate_device(n) + fmd_demod_check_prev (settles n - 1 while n runs) every step, fmd_demod_check at the end (host wall time, %d steps)" % steps,
+    return {"what": "demodulate_device(n) + fmd_demod_check_behind(2) (settles n - 2 while n - 1 and n run) every step, fmd_demod_check at the end (host wall time, %d steps)" % steps,
             "ms_per_step": round(ms, 4), "iq_msamples_per_s": round(nch * (BLOCK // 2) / ms / 1e3, 1),
-            "host_ms_in_enqueue": round(t_enq / steps * 1e3, 4), "host_ms_in_check_prev": round(t_wait / steps * 1e3, 4)}
+            "host_ms_in_enqueue": round(enq, 4), "host_ms_in_check_behind": round(wait, 4), "guarded_samples_settled_in_flight": int(guarded),
+            "one_launch_back": {"ms_per_step": round(ms1, 4), "what": "the same with fmd_demod_check_prev (back = 1): one launch of look-ahead"}}
 
 
 def extra_sink_pcie(fmd, dev_index, nch=1024, steps=20):

@@ -159,25 +159,34 @@ int fmd_demod_set_block_len(fmd_demod *d, size_t block_bytes);
  * output buffer the launch wrote, which must still be allocated) or the carried partial sum is patched.
  * Outside that band the two results are provably equal.  The HOST entry points and fmd_demod_get_state do this
  * themselves before returning; after fmd_demod_demodulate_device call it before reading the output.  Only the output
- * buffers of the TWO most recent launches are ever written by a patch (they must still be allocated; round 5: the most recent
+ * buffers of the THREE most recent launches are ever written by a patch (they must still be allocated; round 5: the most recent
  * one only); a sample of an OLDER launch that turns out to need one (probability ~2^-36 per reference call) makes this function
  * return FMD_ERR_HIP instead of touching memory the caller may have reused: for the strict bit-exactness guarantee call it --
- * or fmd_demod_check_prev, which does not serialise -- for every launch. */
+ * or fmd_demod_check_behind, which does not serialise -- for every launch. */
 int fmd_demod_check(fmd_demod *d);
 
-/* The same completion point ONE LAUNCH BACK (round 6): with launches 1 ... n enqueued through fmd_demod_demodulate_device, waits
- * until launch n - 1 has completed -- not for launch n -- and settles ITS f64 samples, so that the reference's cadence
+/* The same completion point ONE or TWO LAUNCHES BACK (round 6): with launches 1 ... n enqueued through fmd_demod_demodulate_device,
+ * fmd_demod_check_behind(d, back) waits until launch n - back has completed -- not for the newer ones -- and settles ITS f64 samples,
+ * so that the reference's cadence
  *     loop { buf = read_sync(); audio = demod.demodulate(buf); output(audio); }        (simple_fm.rs:150-156)
- * runs as  enqueue(buf n); fmd_demod_check_prev(); output(audio n - 1);  with the GPU never idle between launches and the strict
- * bit-exactness guarantee intact (fmd_demod_check after every launch serialises host and device: ~9 % at the headline
- * configuration).  How: launch n cannot start before launch n - 1 has completed, so its first tile posts "n - 1 is done" together
- * with the head of n - 1's report buffer into host-mapped memory; the two most recent launches report into buffers of their own.
+ * runs as  enqueue(buf n); fmd_demod_check_behind(d, 2); output(audio n - 2);  with the GPU never idle between launches and the
+ * strict bit-exactness guarantee intact (fmd_demod_check after every launch serialises host and device: ~12 % at the headline
+ * configuration; this cadence: 1.00 - 1.01 x the bare launches, extra.check_pipelined of the bench line).  back = 2 keeps a whole
+ * launch queued behind the running one, which absorbs a late host; back = 1 keeps none; back = 0 is fmd_demod_check.  How: launch
+ * s + 1 cannot start before launch s has completed, so its first tile posts "s is done" together with whether s reported anything
+ * into host-mapped memory; everything a launch leaves behind -- its report buffer, the state it wrote, its launch record -- lives in
+ * a ring of three.  A launch that DID report guarded samples is settled while the newer ones run as well (its records are copied and
+ * its audio samples patched on the handle's own stream); only a correction of the sum it carried into the next launch, or a device
+ * assertion, waits for everything.
  * Contract: until a launch has been settled by this function or by fmd_demod_check, (a) its OUTPUT buffer stays allocated and
- * unread -- a patch goes into the buffer of the launch that produced the sample, for the last TWO launches -- and (b) its INPUT
- * buffer stays unmodified: in the one case where launch n - 1's corrected sample lies in the partial sum it carried into launch n
- * (probability ~2^-36 per reference call), launch n is run again on the corrected state, inside this call.  Returns FMD_OK at
- * once when fewer than two launches are outstanding; falls back to fmd_demod_check where no post is coming (generic kernel).
- * Call fmd_demod_check after the LAST launch of a run.  (fmd_firdemod / the pipelined sink have their own completion points.) */
+ * unread -- a patch goes into the buffer of the launch that produced the sample, for the last THREE launches -- and (b) its INPUT
+ * buffer stays unmodified: in the one case where a launch's corrected sample lies in the partial sum it carried into the next launch
+ * (probability ~2^-36 per reference call), the launches behind it are run again on the corrected state, inside this call.  Launches
+ * are settled IN ORDER (an older unsettled launch turns the call into fmd_demod_check).  Returns FMD_OK at once when fewer than
+ * back + 1 launches are outstanding; falls back to fmd_demod_check where no post is coming (generic kernel).  Call fmd_demod_check
+ * after the LAST launch of a run.  (fmd_firdemod / the pipelined sink have their own completion points.) */
+int fmd_demod_check_behind(fmd_demod *d, uint32_t back);
+/* fmd_demod_check_behind(d, 1). */
 int fmd_demod_check_prev(fmd_demod *d);
 
 /* EVENT ORDERING (opt-in, round 6): with on != 0 the handle records an event behind every launch and every later wait -- the next

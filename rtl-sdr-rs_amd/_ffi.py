@@ -73,6 +73,7 @@ PROTOTYPES = {
     "fmd_demod_set_block_len": (C.c_int, [_vp, _sz]),
     "fmd_demod_check": (C.c_int, [_vp]),
     "fmd_demod_check_prev": (C.c_int, [_vp]),
+    "fmd_demod_check_behind": (C.c_int, [_vp, C.c_uint32]),
     "fmd_demod_set_event_ordering": (C.c_int, [_vp, C.c_int]),
     "fmd_demod_f64_stats": (C.c_int, [_vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "fmd_demod_last_out_len": (C.c_int, [_vp, _szp]),

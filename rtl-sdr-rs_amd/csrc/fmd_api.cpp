@@ -80,24 +80,30 @@ struct fmd_demod {
     uint32_t dbg = 0;                     // ablation bits (FMD_DBG, experiment build)
     int n_cus = 0;                        // compute units of the device
     uint32_t allow_fast = 2;              // FMD_FAST: 0 general prologue only, 1 closed form only, 2 (default) table, else closed form (A/B)
-    FmdChanState* d_state[2] = {nullptr, nullptr};
-    int cur = 0;
-    // device error word + guarded f64 samples (fmd_kernels.h): TWO buffers, launch `seq` reports into d_exc[seq & 1] -- the
-    // records of launch n - 1 stay apart from those of launch n, which is what lets fmd_demod_check_prev settle buffer n - 1
-    // while launch n runs (round 6)
-    FmdExcBuf* d_exc = nullptr;
-    uint32_t* h_head = nullptr;           // page-locked copy of both buffers' first 16 bytes (fmd_demod_check reads them behind ONE stream synchronisation)
-    uint32_t* h_mbox = nullptr;           // host-mapped mailbox the kernels post into (FmdLaunch::mbox): one 8-byte word, low = seq known complete, high = report flags
+    // Round 6: everything a launch leaves behind lives in a RING OF THREE (kRing), indexed by the launch's sequence number: the state
+    // it wrote, its report buffer (device error word + guarded f64 samples, fmd_kernels.h), its mailbox word and its launch record.
+    // That is what lets fmd_demod_check_behind settle launch n - 2 (or n - 1) while the newer ones run: the records of the last three
+    // launches stay apart, and the state launch s wrote is still there while launches s + 1 and s + 2 are in flight (a ping-pong of
+    // two would have launch s + 2 overwrite it).
+    static constexpr uint32_t kRing = 3;
+    FmdChanState* d_state[kRing] = {nullptr, nullptr, nullptr};
+    uint32_t cur = 0;                     // index of the state the NEXT launch reads (= what the newest launch wrote)
+    FmdExcBuf* d_exc = nullptr;           // [kRing]: launch seq reports into d_exc[seq % kRing]
+    uint32_t* h_head = nullptr;           // page-locked copy of the report buffers' first 16 bytes (fmd_demod_check reads them behind ONE stream synchronisation)
+    FmdExcBuf* h_recs = nullptr;          // page-locked copy of ONE report buffer (the light settle path of fmd_demod_check_behind)
+    uint32_t* h_mbox = nullptr;           // host-mapped mailbox, kRing 8-byte words: word[s % kRing] = (s | flags << 32), posted by launch s + 1 when it starts
     uint32_t* d_mbox = nullptr;           // ... its device address
-    // what the last two launches were (index seq & 1): enough to patch their output buffers and, for the one case that needs it
-    // -- a guarded sample of launch n - 1 in the carried partial sum that launch n has already consumed -- to run launch n again
+    // what the last three launches were: enough to patch their output buffers and, for the one case that needs it -- a guarded sample
+    // of launch s in the carried partial sum that launch s + 1 has already consumed -- to run the launches behind s again
     struct Pending {
         uint32_t seq = 0;
         bool valid = false, settled = true;
         bool posts = false;               // the launch posts its predecessor's completion (tile / streaming kernels, the handle's own buffers)
+        bool generic = false;             // it ran fmd_demod_generic_kernel (how to launch it again)
+        uint32_t st_out = 0;              // index of the state buffer it wrote
         hipStream_t stream = nullptr;
         FmdLaunch L{};
-    } pend[2];
+    } pend[kRing];
     FmdExcBuf* exc_override = nullptr;    // fmd_internal_set_report_buffer (pipelined sink: one buffer per in-flight launch)
     double f64_guard = 0x1p-20;           // fixed in the shipped library; FMD_F64_GUARD_LOG2 in the experiment build (tests widen it to exercise the patch path)
     int32_t f64_skew = 0;                 // FMD_F64_SKEW, honoured by -DFMD_EXPERIMENT builds only
@@ -300,14 +306,14 @@ int enqueue(fmd_demod* d, const void* d_iq, size_t nbytes, void* d_out, size_t o
     L.lp_cap = stream_now ? d->lp_cap_s : d->lp_cap;
     L.raw_cap = d->raw_cap;
     L.st_in = d->d_state[d->cur];
-    L.st_out = d->d_state[d->cur ^ 1];
+    L.st_out = d->d_state[(d->cur + 1u) % fmd_demod::kRing];
     L.out = static_cast<int16_t*>(d_out);
     L.out_stride = out_cap;
     L.out_len = static_cast<uint32_t*>(d_out_len);
-    L.exc = d->exc_override ? d->exc_override : d->d_exc + ((d->seq + 1u) & 1u);
+    L.exc = d->exc_override ? d->exc_override : d->d_exc + (d->seq + 1u) % fmd_demod::kRing;
     L.err = &L.exc->err;
-    L.exc_prev = d->exc_override ? nullptr : d->d_exc + (d->seq & 1u);
-    L.mbox = d->exc_override ? nullptr : d->d_mbox;
+    L.exc_prev = d->exc_override ? nullptr : d->d_exc + d->seq % fmd_demod::kRing;          // the previous launch's buffer ...
+    L.mbox = d->exc_override ? nullptr : d->d_mbox + 2u * (d->seq % fmd_demod::kRing);       // ... and its mailbox word
     L.f64_guard = d->f64_guard;
     L.seq = d->seq + 1;
 #ifdef FMD_EXPERIMENT
@@ -351,11 +357,13 @@ int enqueue(fmd_demod* d, const void* d_iq, size_t nbytes, void* d_out, size_t o
     const hipError_t e_after = d->order.after(stream);       // (event mode: records the launch's event; reported below, after the bookkeeping)
     d->seq += 1;
     {
-        fmd_demod::Pending& pd = d->pend[d->seq & 1u];
+        fmd_demod::Pending& pd = d->pend[d->seq % fmd_demod::kRing];
         pd.seq = d->seq; pd.valid = true; pd.settled = false; pd.stream = stream; pd.L = L;
-        pd.posts = L.mbox != nullptr && d->last_kernel.family != FMD_KERNEL_GENERIC;
+        pd.generic = d->last_kernel.family == FMD_KERNEL_GENERIC;
+        pd.posts = L.mbox != nullptr && !pd.generic;
+        pd.st_out = (d->cur + 1u) % fmd_demod::kRing;
     }
-    d->cur ^= 1;
+    d->cur = (d->cur + 1u) % fmd_demod::kRing;
     advance_classes(d, nbytes, plans);
     HIP_TRY(e_after);
     return FMD_OK;
@@ -450,28 +458,29 @@ int fmd_internal_resolve_exc(FmdExcBuf* d_exc, int32_t R, uint32_t host_seq, uin
 
 namespace {
 
-// Run launch `pd` again (same arguments, same stream): see settle_buffer.
+// Run launch `pd` again (same arguments, same stream): see settle_launch.
 int replay_launch(fmd_demod* d, fmd_demod::Pending& pd)
 {
     FmdKernelId used;
     // (the caller has synchronised the device; event mode: the handle's own stream -- the caller's may be gone)
     hipStream_t rs = d->order.event_mode ? d->stream : pd.stream;
-    if (d->last_kernel.family == FMD_KERNEL_GENERIC) HIP_TRY(fmd_launch_generic(pd.L, rs, &used));
+    if (pd.generic) HIP_TRY(fmd_launch_generic(pd.L, rs, &used));
     else HIP_TRY(fmd_launch_tile(pd.L, rs, &used));
     HIP_TRY(hipStreamSynchronize(rs));
-    if (d->order.event_mode) HIP_TRY(hipEventRecord(d->order.ev, rs));      // the newest launch's event is now the second run's
+    if (d->order.event_mode && pd.seq == d->seq) HIP_TRY(hipEventRecord(d->order.ev, rs));   // the newest launch's event is now the second run's
     return FMD_OK;
 }
 
-// Settle the records of ONE of the handle's two report buffers (the caller has made sure the launches that wrote it have
-// completed).  newest = d->seq.  A record of the newest launch is patched as before (its output buffer -- or the caller's host
-// copy -- and the current state); a record of launch newest - 1 is patched in THAT launch's output buffer (still allocated: the
-// contract of fmd_demod_check_prev), and one in its carried partial sum -- which launch `newest` has consumed by now -- in the
-// state launch `newest` read, after which launch `newest` is RUN AGAIN: its inputs (the caller's input buffer, the state of
-// launch newest - 1 in the other half of the ping-pong) are untouched until it has been checked, so the second run is the
-// launch the reference would have made.  Anything older is reported, not touched (as before).
-int settle_buffer(fmd_demod* d, FmdExcBuf* buf, int16_t* host_out, size_t host_cap, bool* need_replay)
+// Settle the records launch `s` left in its report buffer (the device is idle: the caller synchronised).  A guarded sample whose
+// host-libm value differs from the kernel's is patched where it went: an audio sample in the output buffer launch s wrote (or, for
+// the newest launch, in the caller's host copy), a sample of the trailing group in the state launch s wrote -- and if a newer launch
+// has consumed that state meanwhile, *carried is set: the caller runs the launches behind s again (their inputs -- the callers' input
+// buffers, the state ring -- are untouched until they are settled: the contract of fmd_demod_check_behind).  Records of any other
+// launch found in the buffer belong to a launch three or more back that was never settled: reported, not touched.
+int settle_launch(fmd_demod* d, uint32_t s, int16_t* host_out, size_t host_cap, bool* carried)
 {
+    FmdExcBuf* const buf = d->d_exc + s % fmd_demod::kRing;
+    const fmd_demod::Pending& P = d->pend[s % fmd_demod::kRing];
     uint32_t head[4] = {0, 0, 0, 0};                        // err, count, guarded_total, pad
     HIP_TRY(hipMemcpy(head, buf, sizeof(head), hipMemcpyDeviceToHost));
     if (head[0] & ~FMD_DEVERR_EXC_CAP) { set_err("device-side sizing assertion failed (bits 0x%x)", head[0]); return FMD_ERR_HIP; }
@@ -483,47 +492,37 @@ int settle_buffer(fmd_demod* d, FmdExcBuf* buf, int16_t* host_out, size_t host_c
     d->f64_guarded += head[1];
     int rc = FMD_OK;
     // several guarded samples may share one audio group (block_len mode): their corrections add up
-    std::map<std::pair<uint32_t, uint64_t>, std::pair<int64_t, const FmdF64Exc*>> groups;   // (seq, out_elem) -> (delta, record)
+    std::map<uint64_t, std::pair<int64_t, const FmdF64Exc*>> groups;       // out_elem -> (delta, record)
     for (const FmdF64Exc& e : recs) {
         const int16_t want = (int16_t)host_polar_f64(e.cr, e.ci), have = (int16_t)e.d_gpu;
         if (want == have) continue;
         d->f64_patched += 1;
-        const int delta = (int)want - (int)have;
-        if (e.k >= 0) {
-            auto& g = groups[{e.seq, e.out_elem}];
-            g.first += delta; g.second = &e;
-            continue;
-        }
-        // the carried partial sum: the state launch e.seq WROTE
-        FmdChanState* st = nullptr;
-        if (e.seq == newest) st = d->d_state[d->cur];
-        else if (e.seq + 1u == newest && d->pend[newest & 1u].valid && !d->exc_override) { st = d->d_state[d->cur ^ 1]; *need_replay = true; }
-        if (!st) {
-            set_err("a guarded f64 sample of launch %u (channel %u) lies in the carried partial sum and later launches have "
-                    "already consumed it: call fmd_demod_check (or fmd_demod_check_prev) for every *_device launch", e.seq, e.channel);
+        if (e.seq != s) {
+            // Nothing ties a record of an older launch to memory that still holds that launch's audio or state: its buffers may have
+            // been reused.  Only the last three launches are ever written; for anything older the caller is told.
+            set_err("a guarded f64 sample of launch %u (channel %u) needs the host-libm value, but three or more launches have been "
+                    "enqueued since: call fmd_demod_check / fmd_demod_check_behind for every *_device launch", e.seq, e.channel);
             rc = FMD_ERR_HIP;
             continue;
         }
-        int32_t now = 0;
-        int32_t* p = &st[e.channel].now_lpr;
+        const int delta = (int)want - (int)have;
+        if (e.k >= 0) {
+            auto& g = groups[e.out_elem];
+            g.first += delta; g.second = &e;
+            continue;
+        }
+        int32_t now = 0;                                     // the carried partial sum: in the state launch s WROTE
+        int32_t* p = &d->d_state[P.st_out][e.channel].now_lpr;
         HIP_TRY(hipMemcpy(&now, p, sizeof(now), hipMemcpyDeviceToHost));
         now += delta;
         HIP_TRY(hipMemcpy(p, &now, sizeof(now), hipMemcpyHostToDevice));
+        if (s != newest) *carried = true;
     }
     for (const auto& kv : groups) {
         const FmdF64Exc& e = *kv.second.second;
         const int16_t fixed = (int16_t)((e.sum + (int)kv.second.first) / d->r.R);         // low_pass_real, simple_fm.rs:421
-        if (host_out && e.seq == newest) host_out[(size_t)e.channel * host_cap + (size_t)e.k] = fixed;
-        else if (e.seq == newest || e.seq + 1u == newest) HIP_TRY(hipMemcpy((void*)(uintptr_t)e.out_elem, &fixed, sizeof(fixed), hipMemcpyHostToDevice));
-        else {
-            // Nothing ties the address saved in an OLDER launch's record to memory that still holds that launch's audio:
-            // the caller may have reused the buffer for a later launch (a write would corrupt newer audio) or freed it.
-            // Only the last TWO launches' buffers are ever written; for anything older the caller is told.
-            set_err("a guarded f64 sample of launch %u (channel %u, audio sample %d) needs the host-libm value, but two or more "
-                    "launches have been enqueued since: call fmd_demod_check (or fmd_demod_check_prev) for every *_device launch",
-                    e.seq, e.channel, e.k);
-            rc = FMD_ERR_HIP;
-        }
+        if (host_out && s == newest) host_out[(size_t)e.channel * host_cap + (size_t)e.k] = fixed;
+        else HIP_TRY(hipMemcpy((void*)(uintptr_t)e.out_elem, &fixed, sizeof(fixed), hipMemcpyHostToDevice));
     }
     if (head[0] & FMD_DEVERR_EXC_CAP) {
         set_err("more than %u guarded f64 samples in one report buffer since the last check: some were not re-evaluated", FMD_EXC_CAP);
@@ -532,25 +531,81 @@ int settle_buffer(fmd_demod* d, FmdExcBuf* buf, int16_t* host_out, size_t host_c
     return rc;
 }
 
-// Everything the handle has enqueued has completed (the caller synchronised): settle both report buffers, the older launch's
-// first.  host_out: the caller's host copy of the NEWEST launch's output, or nullptr.
+// The LIGHT settle path of fmd_demod_check_behind: launch `s` has completed (its successor posted so) and reported records, newer
+// launches are still running.  A guarded sample is, almost always, one whose host-libm value AGREES with the kernel's (the guard band
+// only marks where two faithful atan2 implementations COULD differ) -- settling it must not cost the pipeline a drain.  So: copy the
+// records on the handle's own (non-blocking) stream, evaluate them on the host, and write the audio samples that need a patch into
+// launch s's output buffer -- nothing the running launches touch.  Only a record that corrects the CARRIED partial sum (the state a
+// newer launch has already read) or a device assertion needs everything idle: *need_heavy, with the buffer left as it was.
+int settle_launch_light(fmd_demod* d, uint32_t s, bool* need_heavy)
+{
+    *need_heavy = false;
+    FmdExcBuf* const buf = d->d_exc + s % fmd_demod::kRing;
+    FmdExcBuf* const h = d->h_recs;
+    HIP_TRY(hipMemcpyAsync(h, buf, 16, hipMemcpyDeviceToHost, d->stream));
+    HIP_TRY(hipStreamSynchronize(d->stream));
+    if (h->err != 0u || h->count > FMD_EXC_CAP) { *need_heavy = true; return FMD_OK; }
+    const uint32_t n = h->count;
+    if (n) {
+        HIP_TRY(hipMemcpyAsync(h->rec, buf->rec, n * sizeof(FmdF64Exc), hipMemcpyDeviceToHost, d->stream));
+        HIP_TRY(hipStreamSynchronize(d->stream));
+    }
+    std::map<uint64_t, std::pair<int64_t, const FmdF64Exc*>> groups;       // out_elem -> (delta, record)
+    uint64_t patched = 0;
+    for (uint32_t i = 0; i < n; ++i) {
+        const FmdF64Exc& e = h->rec[i];
+        const int16_t want = (int16_t)host_polar_f64(e.cr, e.ci), have = (int16_t)e.d_gpu;
+        if (want == have) continue;
+        if (e.seq != s || e.k < 0) { *need_heavy = true; return FMD_OK; }     // an older launch's record, or the carried sum: everything idle first
+        auto& g = groups[e.out_elem];
+        g.first += (int)want - (int)have; g.second = &e;
+        patched += 1;
+    }
+    for (const auto& kv : groups) {
+        const FmdF64Exc& e = *kv.second.second;
+        const int16_t fixed = (int16_t)((e.sum + (int)kv.second.first) / d->r.R);         // low_pass_real, simple_fm.rs:421
+        HIP_TRY(hipMemcpyAsync((void*)(uintptr_t)e.out_elem, &fixed, sizeof(fixed), hipMemcpyHostToDevice, d->stream));
+        HIP_TRY(hipStreamSynchronize(d->stream));            // (`fixed` is a stack variable)
+    }
+    HIP_TRY(hipMemsetAsync(buf, 0, 16, d->stream));
+    HIP_TRY(hipStreamSynchronize(d->stream));
+    d->f64_guarded += n;
+    d->f64_patched += patched;
+    return FMD_OK;
+}
+
+// Everything the handle has enqueued has completed (the caller synchronised): settle every launch of the ring that is not settled
+// yet, the oldest first.  host_out: the caller's host copy of the NEWEST launch's output, or nullptr.
 int resolve_device_reports(fmd_demod* d, int16_t* host_out, size_t host_cap)
 {
     if (d->exc_override)                                     // (the pipelined sink owns its report buffers and settles them itself)
         return fmd_internal_resolve_exc(d->d_exc, d->r.R, d->seq, d->seq, d->d_state[d->cur], host_out, host_cap, &d->f64_guarded, &d->f64_patched);
     const uint32_t newest = d->seq;
-    bool replay = false;
-    int rc = settle_buffer(d, d->d_exc + ((newest + 1u) & 1u), nullptr, 0, &replay);     // launch newest - 1 (and older ones of its parity)
-    if (rc == FMD_OK && replay) {
-        // launch `newest` ran on a carried sum that has just been corrected: drop what it reported and run it again
-        HIP_TRY(hipMemset(d->d_exc + (newest & 1u), 0, 16));
-        rc = replay_launch(d, d->pend[newest & 1u]);
-        if (rc == FMD_OK && host_out) { set_err("internal: replay with a host copy"); rc = FMD_ERR_HIP; }   // (host entry points settle every call: unreachable)
+    int rc = FMD_OK;
+    for (uint32_t back = fmd_demod::kRing; back-- > 0;) {
+        if (newest < back + 1u) continue;
+        const uint32_t s = newest - back;
+        fmd_demod::Pending& P = d->pend[s % fmd_demod::kRing];
+        if (!P.valid || P.seq != s || P.settled) continue;
+        bool carried = false;
+        const int r1 = settle_launch(d, s, host_out, host_cap, &carried);
+        P.settled = true;
+        if (r1 && !rc) rc = r1;
+        if (r1 == FMD_OK && carried) {
+            // the launches behind s ran on a carried sum that has just been corrected: drop what they reported and run them again,
+            // oldest first; the loop then settles them like any other launch
+            for (uint32_t t = s + 1u; t <= newest; ++t) {
+                fmd_demod::Pending& T = d->pend[t % fmd_demod::kRing];
+                if (!T.valid || T.seq != t || T.settled) { set_err("launch %u ran on a carried sum that launch %u's check has corrected, but it has been settled (delivered) already: settle launches in order", t, s); return FMD_ERR_HIP; }
+                if (host_out && t == newest) { set_err("internal: replay with a host copy"); return FMD_ERR_HIP; }   // (host entry points settle every call: unreachable)
+                HIP_TRY(hipMemset(d->d_exc + t % fmd_demod::kRing, 0, 16));
+                const int r2 = replay_launch(d, T);
+                if (r2) return r2;
+                T.settled = false;
+            }
+        }
     }
-    bool again = false;
-    const int rc2 = settle_buffer(d, d->d_exc + (newest & 1u), host_out, host_cap, &again);
-    d->pend[0].settled = d->pend[1].settled = true;
-    return rc ? rc : rc2;
+    return rc;
 }
 }  // namespace
 
@@ -716,13 +771,14 @@ int fmd_demod_new(const fmd_demod_config* config, const fmd_device_config* dev, 
     if (const char* g = fmd_knob("FMD_F64_GUARD_LOG2")) d->f64_guard = ldexp(1.0, atoi(g));   // experiment build only: the
     d->f64_skew = fmd_knob_i32("FMD_F64_SKEW", 0);                                              // shipped guard band is 2^-20, fixed
     const size_t sbytes = sizeof(FmdChanState) * (size_t)d->C;
-    for (int i = 0; i < 2; ++i) {
+    for (uint32_t i = 0; i < fmd_demod::kRing; ++i) {
         if ((e = hipMalloc(&d->d_state[i], sbytes)) != hipSuccess) return fail(e, "hipMalloc(state)");
         if ((e = hipMemset(d->d_state[i], 0, sbytes)) != hipSuccess) return fail(e, "hipMemset(state)");
     }
-    if ((e = hipMalloc(&d->d_exc, 2 * sizeof(FmdExcBuf))) != hipSuccess) return fail(e, "hipMalloc(reports)");
-    if ((e = hipMemset(d->d_exc, 0, 2 * sizeof(FmdExcBuf))) != hipSuccess) return fail(e, "hipMemset(reports)");
-    if ((e = hipHostMalloc(reinterpret_cast<void**>(&d->h_head), 32, hipHostMallocDefault)) != hipSuccess) return fail(e, "hipHostMalloc(report head)");
+    if ((e = hipMalloc(&d->d_exc, fmd_demod::kRing * sizeof(FmdExcBuf))) != hipSuccess) return fail(e, "hipMalloc(reports)");
+    if ((e = hipMemset(d->d_exc, 0, fmd_demod::kRing * sizeof(FmdExcBuf))) != hipSuccess) return fail(e, "hipMemset(reports)");
+    if ((e = hipHostMalloc(reinterpret_cast<void**>(&d->h_head), 16 * fmd_demod::kRing, hipHostMallocDefault)) != hipSuccess) return fail(e, "hipHostMalloc(report head)");
+    if ((e = hipHostMalloc(reinterpret_cast<void**>(&d->h_recs), sizeof(FmdExcBuf), hipHostMallocDefault)) != hipSuccess) return fail(e, "hipHostMalloc(report copy)");
     if ((e = hipHostMalloc(reinterpret_cast<void**>(&d->h_mbox), 64, hipHostMallocMapped)) != hipSuccess) return fail(e, "hipHostMalloc(mailbox)");
     memset(d->h_mbox, 0, 64);
     if ((e = hipHostGetDevicePointer(reinterpret_cast<void**>(&d->d_mbox), d->h_mbox, 0)) != hipSuccess) return fail(e, "hipHostGetDevicePointer(mailbox)");
@@ -737,10 +793,11 @@ void fmd_demod_free(fmd_demod* d)
     if (!d) return;
     FmdDeviceGuard guard(d->device);
     (void)hipDeviceSynchronize();
-    for (int i = 0; i < 2; ++i) if (d->d_state[i]) (void)hipFree(d->d_state[i]);
+    for (uint32_t i = 0; i < fmd_demod::kRing; ++i) if (d->d_state[i]) (void)hipFree(d->d_state[i]);
     if (d->d_exc) (void)hipFree(d->d_exc);
     if (d->h_head) (void)hipHostFree(d->h_head);
     if (d->h_mbox) (void)hipHostFree(d->h_mbox);
+    if (d->h_recs) (void)hipHostFree(d->h_recs);
     d->order.destroy();
     if (d->d_chan_class) (void)hipFree(d->d_chan_class);
     if (d->d_iq) (void)hipFree(d->d_iq);
@@ -755,12 +812,12 @@ int fmd_demod_reset(fmd_demod* d)
     ON_DEVICE(d->device);
     HIP_TRY(hipDeviceSynchronize());
     const size_t sbytes = sizeof(FmdChanState) * (size_t)d->C;
-    HIP_TRY(hipMemset(d->d_state[0], 0, sbytes));
-    HIP_TRY(hipMemset(d->d_state[1], 0, sbytes));
-    HIP_TRY(hipMemset(d->d_exc, 0, 16));
-    HIP_TRY(hipMemset(d->d_exc + 1, 0, 16));
+    for (uint32_t i = 0; i < fmd_demod::kRing; ++i) {
+        HIP_TRY(hipMemset(d->d_state[i], 0, sbytes));
+        HIP_TRY(hipMemset(d->d_exc + i, 0, 16));
+    }
     HIP_TRY(hipDeviceSynchronize());
-    d->pend[0] = fmd_demod::Pending{}; d->pend[1] = fmd_demod::Pending{};
+    for (uint32_t i = 0; i < fmd_demod::kRing; ++i) d->pend[i] = fmd_demod::Pending{};
     d->cur = 0;
     d->order.reset();
     reset_classes(d);
@@ -815,11 +872,12 @@ int fmd_demod_demodulate_batch(fmd_demod* d, const uint8_t* iq, size_t nbytes, i
                                  (size_t)kmax * sizeof(int16_t), d->C, hipMemcpyDeviceToHost, d->stream));
     }
     const bool head = d->h_head && !d->exc_override;           // the report head rides behind the output copy (see fmd_demod_check)
-    const bool prev_clean = d->pend[(d->seq + 1u) & 1u].settled;      // (a caller may mix the host and the _device entry points)
-    if (head) { d->h_head[0] = d->h_head[1] = ~0u; HIP_TRY(hipMemcpyAsync(d->h_head, d->d_exc + (d->seq & 1u), 16, hipMemcpyDeviceToHost, d->stream)); }
+    bool older_clean = true;                                  // (a caller may mix the host and the _device entry points)
+    for (uint32_t i = 0; i < fmd_demod::kRing; ++i) if (i != d->seq % fmd_demod::kRing && d->pend[i].valid && !d->pend[i].settled) older_clean = false;
+    if (head) { d->h_head[0] = d->h_head[1] = ~0u; HIP_TRY(hipMemcpyAsync(d->h_head, d->d_exc + d->seq % fmd_demod::kRing, 16, hipMemcpyDeviceToHost, d->stream)); }
     HIP_TRY(hipStreamSynchronize(d->stream));
-    if (head && prev_clean && d->h_head[0] == 0u && d->h_head[1] == 0u) { d->pend[d->seq & 1u].settled = true; return FMD_OK; }
-    if (!prev_clean) HIP_TRY(hipDeviceSynchronize());
+    if (head && older_clean && d->h_head[0] == 0u && d->h_head[1] == 0u) { d->pend[d->seq % fmd_demod::kRing].settled = true; return FMD_OK; }
+    if (!older_clean) HIP_TRY(hipDeviceSynchronize());
     return resolve_device_reports(d, out, out_cap);   // device assertions + guarded f64 samples (patched in `out`)
 }
 
@@ -878,21 +936,27 @@ int fmd_demod_check(fmd_demod* d)
     if (!d) { set_err("null argument"); return FMD_ERR_INVALID_ARG; }
     ON_DEVICE(d->device);
     // The common case -- no device assertion, no guarded f64 sample -- costs one stream synchronisation: the heads of the report
-    // buffers are copied to page-locked memory BEHIND the handle's last launch on that launch's stream (the library orders a
-    // handle's launches across streams itself, so that stream's completion is the handle's).  Anything else takes the
-    // device-wide path below.
+    // buffers of every launch that is not settled yet are copied to page-locked memory BEHIND the handle's last launch on that
+    // launch's stream (the library orders a handle's launches across streams itself, so that stream's completion is the handle's).
+    // Anything else takes the device-wide path below.
     if (d->order.have_last && d->h_head && !d->exc_override) {
-        const bool both = !d->pend[(d->seq + 1u) & 1u].settled;          // launch seq - 1 was never checked: its buffer too
-        for (int i = 0; i < 8; ++i) d->h_head[i] = i < 4 || both ? ~0u : 0u;
         // (event mode: the handle's OWN stream waits for the launch's event and carries the copies -- the caller's stream is not touched)
         hipStream_t cs = d->order.last;
         hipError_t e = hipSuccess;
         if (d->order.event_mode) { cs = d->stream; e = hipStreamWaitEvent(cs, d->order.ev, 0); }
-        if (e == hipSuccess) e = hipMemcpyAsync(d->h_head, d->d_exc + (d->seq & 1u), 16, hipMemcpyDeviceToHost, cs);
-        if (e == hipSuccess && both) e = hipMemcpyAsync(d->h_head + 4, d->d_exc + ((d->seq + 1u) & 1u), 16, hipMemcpyDeviceToHost, cs);
+        bool copied[fmd_demod::kRing] = {false, false, false};
+        for (uint32_t i = 0; i < fmd_demod::kRing && e == hipSuccess; ++i) {
+            d->h_head[4 * i] = d->h_head[4 * i + 1] = 0u;
+            if (!d->pend[i].valid || d->pend[i].settled) continue;
+            d->h_head[4 * i] = d->h_head[4 * i + 1] = ~0u;
+            e = hipMemcpyAsync(d->h_head + 4 * i, d->d_exc + i, 16, hipMemcpyDeviceToHost, cs);
+            copied[i] = true;
+        }
         if (e == hipSuccess) e = hipStreamSynchronize(cs);
-        if (e == hipSuccess && d->h_head[0] == 0u && d->h_head[1] == 0u && d->h_head[4] == 0u && d->h_head[5] == 0u) {
-            d->pend[0].settled = d->pend[1].settled = true;
+        bool clean = e == hipSuccess;
+        for (uint32_t i = 0; i < fmd_demod::kRing; ++i) clean = clean && d->h_head[4 * i] == 0u && d->h_head[4 * i + 1] == 0u;
+        if (clean) {
+            for (uint32_t i = 0; i < fmd_demod::kRing; ++i) if (copied[i]) d->pend[i].settled = true;
             return FMD_OK;
         }
         if (e != hipSuccess) (void)hipGetLastError();
@@ -901,19 +965,26 @@ int fmd_demod_check(fmd_demod* d)
     return resolve_device_reports(d, nullptr, 0);
 }
 
-int fmd_demod_check_prev(fmd_demod* d)
+int fmd_demod_check_behind(fmd_demod* d, uint32_t back)
 {
     if (!d) { set_err("null argument"); return FMD_ERR_INVALID_ARG; }
+    if (back == 0u) return fmd_demod_check(d);
+    if (back >= fmd_demod::kRing) { set_err("fmd_demod_check_behind: back must be 0, 1 or 2"); return FMD_ERR_INVALID_ARG; }
     ON_DEVICE(d->device);
-    const uint32_t newest = d->seq, target = newest - 1u;
-    fmd_demod::Pending& pn = d->pend[newest & 1u];
-    fmd_demod::Pending& pp = d->pend[target & 1u];
-    if (newest < 2u || !pp.valid || pp.seq != target || pp.settled) return FMD_OK;          // nothing older in flight
-    // Launch `newest` posts the completion of launch `target` (and the head of its report buffer) when its first tile runs:
-    // spin on the host-mapped word.  No post is coming if the newest launch is not one that posts (generic kernel, a caller-owned
-    // report buffer): then this is fmd_demod_check.
-    if (!pn.valid || pn.seq != newest || !pn.posts || !d->h_mbox) return fmd_demod_check(d);
-    const uint64_t* const m = reinterpret_cast<const uint64_t*>(d->h_mbox);
+    const uint32_t newest = d->seq;
+    if (newest < back + 1u) return FMD_OK;                   // nothing that far back yet
+    const uint32_t target = newest - back;
+    fmd_demod::Pending& pt = d->pend[target % fmd_demod::kRing];
+    if (!pt.valid || pt.seq != target || pt.settled) return FMD_OK;
+    // Launch target + 1 posts the completion of launch `target` (and whether its report buffer is empty) when its first tile runs:
+    // spin on the host-mapped word.  No post is coming if that launch is not one that posts (generic kernel, a caller-owned report
+    // buffer); and launches are settled IN ORDER (a correction of an older launch's carried sum runs the newer ones again: they must
+    // not have been delivered): with an older launch still unsettled this is fmd_demod_check.
+    const fmd_demod::Pending& pnext = d->pend[(target + 1u) % fmd_demod::kRing];
+    bool in_order = pnext.valid && pnext.seq == target + 1u && pnext.posts && d->h_mbox != nullptr;
+    for (uint32_t i = 0; i < fmd_demod::kRing; ++i) if (d->pend[i].valid && !d->pend[i].settled && (int32_t)(d->pend[i].seq - target) < 0) in_order = false;
+    if (!in_order) return fmd_demod_check(d);
+    const uint64_t* const m = reinterpret_cast<const uint64_t*>(d->h_mbox) + target % fmd_demod::kRing;
     // (the wait is a plain spin on the host-mapped word; only after a millisecond without the post does it start asking the runtime
     //  -- once per further millisecond -- whether the newest launch is still running at all: a failed launch would never post)
     uint64_t spins = 0, word;
@@ -939,13 +1010,23 @@ int fmd_demod_check_prev(fmd_demod* d)
         __builtin_ia32_pause();
 #endif
     }
-    if ((uint32_t)word == target && (word >> 32) == 0u) { pp.settled = true; return FMD_OK; }   // the common case: nothing to settle
-    // Something was reported by launch `target` (a guarded f64 sample, or a device assertion).  The rare path waits for the newest
-    // launch as well and settles both buffers, the older one first (settle_buffer: patches go into the output buffer of the launch
-    // that produced them -- both are still the caller's to keep -- and a corrected carried sum re-runs the newest launch).
+    if ((uint32_t)word == target && (word >> 32) == 0u) { pt.settled = true; return FMD_OK; }   // the common case: nothing to settle
+    // Something was reported by launch `target`: guarded f64 samples (settled without waiting for the newer launches unless one of them
+    // corrects the carried sum: settle_launch_light), or a device assertion.
+    if ((uint32_t)word == target && d->h_recs) {
+        bool need_heavy = false;
+        const int rl = settle_launch_light(d, target, &need_heavy);
+        if (rl) return rl;
+        if (!need_heavy) { pt.settled = true; return FMD_OK; }
+    }
+    // The rare path waits for the newer launches as well and settles the ring in order (settle_launch: patches go into the output
+    // buffer of the launch that produced them -- all three are still the caller's to keep -- and a corrected carried sum re-runs the
+    // launches behind it).
     HIP_TRY(hipDeviceSynchronize());
     return resolve_device_reports(d, nullptr, 0);
 }
+
+int fmd_demod_check_prev(fmd_demod* d) { return fmd_demod_check_behind(d, 1u); }
 
 int fmd_demod_set_event_ordering(fmd_demod* d, int on)
 {

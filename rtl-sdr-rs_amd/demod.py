@@ -113,10 +113,15 @@ class DemodBank:
         check(lib().fmd_demod_check(self._h))
 
     def check_prev(self):
-        """fmd_demod_check_prev: the same one launch back -- waits for launch n - 1 while launch n runs, settles its f64 samples.
-        Until a launch has been settled its output buffer stays allocated and unread and its input buffer unmodified (include/fmd.h);
-        the stream of the handle's most recent launch must be alive, as for `check`."""
+        """fmd_demod_check_prev = check_behind(1)."""
         check(lib().fmd_demod_check_prev(self._h))
+
+    def check_behind(self, back=2):
+        """fmd_demod_check_behind: the completion point `back` launches back (0: `check`; 1, 2) -- waits for launch n - back while the
+        newer ones run and settles its f64 samples.  Until a launch has been settled its output buffer stays allocated and unread and
+        its input buffer unmodified (include/fmd.h); launches are settled in order; the stream of the handle's most recent launch must
+        be alive, as for `check` (or: `set_event_ordering`)."""
+        check(lib().fmd_demod_check_behind(self._h, int(back)))
 
     def set_event_ordering(self, on=True):
         """fmd_demod_set_event_ordering: record an event behind every launch and wait on events only -- the streams handed to

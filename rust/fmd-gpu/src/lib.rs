@@ -99,6 +99,7 @@ extern "C" {
     pub fn fmd_demod_set_block_len(d: *mut fmd_demod, block_bytes: usize) -> c_int;
     pub fn fmd_demod_check(d: *mut fmd_demod) -> c_int;
     pub fn fmd_demod_check_prev(d: *mut fmd_demod) -> c_int;
+    pub fn fmd_demod_check_behind(d: *mut fmd_demod, back: u32) -> c_int;
     pub fn fmd_demod_set_event_ordering(d: *mut fmd_demod, on: c_int) -> c_int;
     pub fn fmd_demod_f64_stats(d: *const fmd_demod, guarded: *mut u64, patched: *mut u64) -> c_int;
     pub fn fmd_demod_last_out_len(d: *const fmd_demod, out_len: *mut usize) -> c_int;
@@ -237,6 +238,13 @@ impl Demod {
     /// input buffer unmodified, and the stream of the most recent launch alive (include/fmd.h).
     pub fn check_prev(&mut self) -> Result<()> {
         check(unsafe { fmd_demod_check_prev(self.handle) })
+    }
+
+    /// `fmd_demod_check_behind`: the completion point `back` launches back (0 = `check`, 1 = `check_prev`, 2 keeps a whole launch queued
+    /// behind the running one and absorbs a late host).  Launches are settled in order; the last THREE launches' output buffers must
+    /// stay allocated and unread, their input buffers unmodified, until they are settled.
+    pub fn check_behind(&mut self, back: u32) -> Result<()> {
+        check(unsafe { fmd_demod_check_behind(self.handle, back) })
     }
 
     pub fn state(&mut self) -> Result<DemodState> {

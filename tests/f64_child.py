@@ -147,7 +147,7 @@ def scenario_sink(D, fast, slow):
     return {"bad": bad, "state_bad": 0, "stats": stats, "expected_guarded": n * nbuf}
 
 
-def scenario_pipelined(D, fast, slow, nch):
+def scenario_pipelined(D, fast, slow, nch, back=1):
     """fmd_demod_check_prev: launch n is enqueued, THEN launch n - 1 is settled and read -- two launches in flight, the patch has to
     land in the OLDER one's output buffer (and, where the f64 sample of launch n - 1 lies in the sum it carried into launch n, in
     the state launch n read, with launch n run again).  Every launch has its own input and output buffer, as the contract asks;
@@ -175,11 +175,12 @@ def scenario_pipelined(D, fast, slow, nch):
         outs.append(torch.zeros((nch, cap), dtype=torch.int16, device="cuda"))
         bank.demodulate_device(ins[-1].data_ptr(), N, outs[-1].data_ptr(), cap, None, None)
         kernels.add(bank.last_kernel())
-        bank.check_prev()                                  # launch `call - 1` is final now; launch `call` may still run
-        if call >= 1:
-            bad += settle_and_compare(call - 1)
+        bank.check_behind(back)                            # launch `call - back` is final now; the newer ones may still run
+        if call >= back:
+            bad += settle_and_compare(call - back)
     bank.check()
-    bad += settle_and_compare(ncalls - 1)
+    for k in range(max(0, ncalls - back), ncalls):
+        bad += settle_and_compare(k)
     st_bad = sum(0 if bank.get_state(c).as_dict() == o.state_of(obank[c]) else 1 for c in range(nch))
     return {"bad": bad, "state_bad": st_bad, "stats": bank.f64_stats(), "kernels": sorted(kernels), "launches": ncalls * nch}
 
@@ -195,7 +196,7 @@ if __name__ == "__main__":
     elif kind == "sink":
         res = scenario_sink(*(int(x) for x in sys.argv[2:5]))
     elif kind == "pipelined":
-        res = scenario_pipelined(*(int(x) for x in sys.argv[2:6]))
+        res = scenario_pipelined(*(int(x) for x in sys.argv[2:7]))
     else:
         D, fast, slow, bl = (int(x) for x in sys.argv[2:6])
         res = scenario_stream(D, fast, slow, bl)

@@ -8,7 +8,7 @@ for f in glob.glob(sys.argv[1] + "/**/*kernel_trace.csv", recursive=True):
 rows.sort()
 out = {}
 med = lambda v: sorted(v)[len(v) // 2]
-for k, name in enumerate(("warm-up", "bare", "check_prev", "check")):
+for k, name in enumerate(("warm-up", "bare", "check_behind_2", "check_prev", "check")):
     seg = rows[300 * k:300 * (k + 1)]
     if len(seg) < 300:
         break
@@ -20,5 +20,6 @@ for k, name in enumerate(("warm-up", "bare", "check_prev", "check")):
                  "gap_us_mean": round(sum(gap) / len(gap) / 1e3, 2), "gap_us_max": round(max(gap) / 1e3, 2),
                  "gaps_over_20us": len(big), "their_sum_us": round(sum(big) / 1e3, 1),
                  "period_us_median": round(med([seg[i + 1][0] - seg[i][0] for i in range(len(seg) - 1)]) / 1e3, 2),
-                 "span_us_per_launch": round((seg[-1][1] - seg[0][0]) / len(seg) / 1e3, 2)}
+                 "span_us_per_launch": round((seg[-1][1] - seg[0][0]) / len(seg) / 1e3, 2),
+                 "first_60_kernel_us": [round(x / 1e3) for x in dur[:60]], "first_60_gap_us": [round(x / 1e3) for x in gap[:60]]}
 print(json.dumps(out))
