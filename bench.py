@@ -495,11 +495,11 @@ def extra_check_pipelined(fmd, torch, bank, bufs, out, cap, stream, steps=200):
         return ms, t_enq / steps * 1e3, t_wait / steps * 1e3
 
     g0 = bank.f64_stats()["guarded"]
-    ms, enq, wait = run(2)
+    ms, enq, wait = sorted(run(2) for _ in range(3))[1]          # median of three runs of `steps` steps: one host hiccup of a millisecond is 3 % of a run
     guarded = bank.f64_stats()["guarded"] - g0       # launches with a report are settled while the newer ones run (no drain)
-    ms1, _, _ = run(1)
+    ms1, _, _ = sorted(run(1) for _ in range(3))[1]
     nch = bufs[0].shape[0]
-    return {"what": "demodulate_device(n) + fmd_demod_check_behind(2) (settles n - 2 while n - 1 and n run) every step, fmd_demod_check at the end (host wall time, %d steps)" % steps,
+    return {"what": "demodulate_device(n) + fmd_demod_check_behind(2) (settles n - 2 while n - 1 and n run) every step, fmd_demod_check at the end (host wall time, median of 3 runs of %d steps)" % steps,
             "ms_per_step": round(ms, 4), "iq_msamples_per_s": round(nch * (BLOCK // 2) / ms / 1e3, 1),
             "host_ms_in_enqueue": round(enq, 4), "host_ms_in_check_behind": round(wait, 4), "guarded_samples_settled_in_flight": int(guarded),
             "one_launch_back": {"ms_per_step": round(ms1, 4), "what": "the same with fmd_demod_check_prev (back = 1): one launch of look-ahead"}}

@@ -170,7 +170,7 @@ int fmd_demod_check(fmd_demod *d);
  * so that the reference's cadence
  *     loop { buf = read_sync(); audio = demod.demodulate(buf); output(audio); }        (simple_fm.rs:150-156)
  * runs as  enqueue(buf n); fmd_demod_check_behind(d, 2); output(audio n - 2);  with the GPU never idle between launches and the
- * strict bit-exactness guarantee intact (fmd_demod_check after every launch serialises host and device: ~12 % at the headline
+ * strict bit-exactness guarantee intact (fmd_demod_check after every launch serialises host and device: ~8 % at the headline
  * configuration; this cadence: 1.00 - 1.01 x the bare launches, extra.check_pipelined of the bench line).  back = 2 keeps a whole
  * launch queued behind the running one, which absorbs a late host; back = 1 keeps none; back = 0 is fmd_demod_check.  How: launch
  * s + 1 cannot start before launch s has completed, so its first tile posts "s is done" together with whether s reported anything

@@ -86,6 +86,7 @@ struct fmd_demod {
     // launches stay apart, and the state launch s wrote is still there while launches s + 1 and s + 2 are in flight (a ping-pong of
     // two would have launch s + 2 overwrite it).
     static constexpr uint32_t kRing = 3;
+    static constexpr uint32_t kFlagWord = 8;          // h_mbox[kFlagWord + s % kRing]: launch s has written into its report buffer (FmdLaunch::hflag)
     FmdChanState* d_state[kRing] = {nullptr, nullptr, nullptr};
     uint32_t cur = 0;                     // index of the state the NEXT launch reads (= what the newest launch wrote)
     FmdExcBuf* d_exc = nullptr;           // [kRing]: launch seq reports into d_exc[seq % kRing]
@@ -314,6 +315,7 @@ int enqueue(fmd_demod* d, const void* d_iq, size_t nbytes, void* d_out, size_t o
     L.err = &L.exc->err;
     L.exc_prev = d->exc_override ? nullptr : d->d_exc + d->seq % fmd_demod::kRing;          // the previous launch's buffer ...
     L.mbox = d->exc_override ? nullptr : d->d_mbox + 2u * (d->seq % fmd_demod::kRing);       // ... and its mailbox word
+    L.hflag = d->exc_override || !d->d_mbox ? nullptr : d->d_mbox + fmd_demod::kFlagWord + (d->seq + 1u) % fmd_demod::kRing;    // this launch's "has reported" word
     L.f64_guard = d->f64_guard;
     L.seq = d->seq + 1;
 #ifdef FMD_EXPERIMENT
@@ -477,6 +479,12 @@ int replay_launch(fmd_demod* d, fmd_demod::Pending& pd)
 // has consumed that state meanwhile, *carried is set: the caller runs the launches behind s again (their inputs -- the callers' input
 // buffers, the state ring -- are untouched until they are settled: the contract of fmd_demod_check_behind).  Records of any other
 // launch found in the buffer belong to a launch three or more back that was never settled: reported, not touched.
+// The report buffer of ring slot s % kRing has just been cleared (everything that could write it is idle or belongs to other slots).
+static inline void clear_report_flag(fmd_demod* d, uint32_t s)
+{
+    if (d->h_mbox) __atomic_store_n(d->h_mbox + fmd_demod::kFlagWord + s % fmd_demod::kRing, 0u, __ATOMIC_RELAXED);
+}
+
 int settle_launch(fmd_demod* d, uint32_t s, int16_t* host_out, size_t host_cap, bool* carried)
 {
     FmdExcBuf* const buf = d->d_exc + s % fmd_demod::kRing;
@@ -489,6 +497,7 @@ int settle_launch(fmd_demod* d, uint32_t s, int16_t* host_out, size_t host_cap, 
     std::vector<FmdF64Exc> recs(n);
     HIP_TRY(hipMemcpy(recs.data(), buf->rec, n * sizeof(FmdF64Exc), hipMemcpyDeviceToHost));
     HIP_TRY(hipMemset(buf, 0, 16));
+    clear_report_flag(d, s);
     d->f64_guarded += head[1];
     int rc = FMD_OK;
     // several guarded samples may share one audio group (block_len mode): their corrections add up
@@ -542,12 +551,13 @@ int settle_launch_light(fmd_demod* d, uint32_t s, bool* need_heavy)
     *need_heavy = false;
     FmdExcBuf* const buf = d->d_exc + s % fmd_demod::kRing;
     FmdExcBuf* const h = d->h_recs;
-    HIP_TRY(hipMemcpyAsync(h, buf, 16, hipMemcpyDeviceToHost, d->stream));
+    constexpr uint32_t kFirst = 8;                          // the head and the first few records travel in one copy
+    HIP_TRY(hipMemcpyAsync(h, buf, offsetof(FmdExcBuf, rec) + kFirst * sizeof(FmdF64Exc), hipMemcpyDeviceToHost, d->stream));
     HIP_TRY(hipStreamSynchronize(d->stream));
     if (h->err != 0u || h->count > FMD_EXC_CAP) { *need_heavy = true; return FMD_OK; }
     const uint32_t n = h->count;
-    if (n) {
-        HIP_TRY(hipMemcpyAsync(h->rec, buf->rec, n * sizeof(FmdF64Exc), hipMemcpyDeviceToHost, d->stream));
+    if (n > kFirst) {
+        HIP_TRY(hipMemcpyAsync(h->rec + kFirst, buf->rec + kFirst, (n - kFirst) * sizeof(FmdF64Exc), hipMemcpyDeviceToHost, d->stream));
         HIP_TRY(hipStreamSynchronize(d->stream));
     }
     std::map<uint64_t, std::pair<int64_t, const FmdF64Exc*>> groups;       // out_elem -> (delta, record)
@@ -569,6 +579,7 @@ int settle_launch_light(fmd_demod* d, uint32_t s, bool* need_heavy)
     }
     HIP_TRY(hipMemsetAsync(buf, 0, 16, d->stream));
     HIP_TRY(hipStreamSynchronize(d->stream));
+    clear_report_flag(d, s);
     d->f64_guarded += n;
     d->f64_patched += patched;
     return FMD_OK;
@@ -599,6 +610,7 @@ int resolve_device_reports(fmd_demod* d, int16_t* host_out, size_t host_cap)
                 if (!T.valid || T.seq != t || T.settled) { set_err("launch %u ran on a carried sum that launch %u's check has corrected, but it has been settled (delivered) already: settle launches in order", t, s); return FMD_ERR_HIP; }
                 if (host_out && t == newest) { set_err("internal: replay with a host copy"); return FMD_ERR_HIP; }   // (host entry points settle every call: unreachable)
                 HIP_TRY(hipMemset(d->d_exc + t % fmd_demod::kRing, 0, 16));
+                clear_report_flag(d, t);
                 const int r2 = replay_launch(d, T);
                 if (r2) return r2;
                 T.settled = false;
@@ -815,6 +827,7 @@ int fmd_demod_reset(fmd_demod* d)
     for (uint32_t i = 0; i < fmd_demod::kRing; ++i) {
         HIP_TRY(hipMemset(d->d_state[i], 0, sbytes));
         HIP_TRY(hipMemset(d->d_exc + i, 0, 16));
+        clear_report_flag(d, i);
     }
     HIP_TRY(hipDeviceSynchronize());
     for (uint32_t i = 0; i < fmd_demod::kRing; ++i) d->pend[i] = fmd_demod::Pending{};
@@ -935,31 +948,37 @@ int fmd_demod_check(fmd_demod* d)
 {
     if (!d) { set_err("null argument"); return FMD_ERR_INVALID_ARG; }
     ON_DEVICE(d->device);
-    // The common case -- no device assertion, no guarded f64 sample -- costs one stream synchronisation: the heads of the report
-    // buffers of every launch that is not settled yet are copied to page-locked memory BEHIND the handle's last launch on that
-    // launch's stream (the library orders a handle's launches across streams itself, so that stream's completion is the handle's).
-    // Anything else takes the device-wide path below.
-    if (d->order.have_last && d->h_head && !d->exc_override) {
-        // (event mode: the handle's OWN stream waits for the launch's event and carries the copies -- the caller's stream is not touched)
-        hipStream_t cs = d->order.last;
-        hipError_t e = hipSuccess;
-        if (d->order.event_mode) { cs = d->stream; e = hipStreamWaitEvent(cs, d->order.ev, 0); }
-        bool copied[fmd_demod::kRing] = {false, false, false};
-        for (uint32_t i = 0; i < fmd_demod::kRing && e == hipSuccess; ++i) {
-            d->h_head[4 * i] = d->h_head[4 * i + 1] = 0u;
-            if (!d->pend[i].valid || d->pend[i].settled) continue;
-            d->h_head[4 * i] = d->h_head[4 * i + 1] = ~0u;
-            e = hipMemcpyAsync(d->h_head + 4 * i, d->d_exc + i, 16, hipMemcpyDeviceToHost, cs);
-            copied[i] = true;
+    // The common case -- no device assertion, no guarded f64 sample -- costs one synchronisation with the handle's most recent launch
+    // (the library orders a handle's launches across streams itself, so that launch's completion is the handle's; event mode: its
+    // event, the caller's stream is not touched) and three reads of host memory: a launch that writes a record or an error bit into
+    // its report buffer also sets its host-mapped word (FmdLaunch::hflag), so nothing is copied unless something was reported
+    // (rounds 2 - 5 copied the buffer's head behind the launch: +4.4 us per call, profiles/r06_experiments.md 11).
+    if (d->order.have_last && d->h_mbox && !d->exc_override) {
+        const hipError_t e = d->order.wait_last();
+        if (e == hipSuccess) {
+            auto flag = [&](uint32_t i) { return __atomic_load_n(d->h_mbox + fmd_demod::kFlagWord + i % fmd_demod::kRing, __ATOMIC_ACQUIRE); };
+            // a launch that DID report: its records are evaluated here, oldest launch first (settle_launch_light -- the usual guarded
+            // sample agrees with the host's value and costs two small copies); anything else takes the device-wide path below
+            bool heavy = false;
+            const uint32_t newest = d->seq;
+            for (uint32_t back = fmd_demod::kRing; back-- > 0 && !heavy;) {
+                if (newest < back + 1u) continue;
+                const uint32_t s = newest - back;
+                fmd_demod::Pending& P = d->pend[s % fmd_demod::kRing];
+                if (!P.valid || P.seq != s || P.settled) continue;
+                if (flag(s) != 0u) {
+                    if (!d->h_recs) { heavy = true; break; }
+                    const int rl = settle_launch_light(d, s, &heavy);
+                    if (rl) return rl;
+                    if (heavy) break;
+                }
+                P.settled = true;
+            }
+            for (uint32_t i = 0; i < fmd_demod::kRing; ++i) heavy = heavy || flag(i) != 0u;       // (a sticky error bit, a slot without a launch record)
+            if (!heavy) return FMD_OK;
+        } else {
+            (void)hipGetLastError();
         }
-        if (e == hipSuccess) e = hipStreamSynchronize(cs);
-        bool clean = e == hipSuccess;
-        for (uint32_t i = 0; i < fmd_demod::kRing; ++i) clean = clean && d->h_head[4 * i] == 0u && d->h_head[4 * i + 1] == 0u;
-        if (clean) {
-            for (uint32_t i = 0; i < fmd_demod::kRing; ++i) if (copied[i]) d->pend[i].settled = true;
-            return FMD_OK;
-        }
-        if (e != hipSuccess) (void)hipGetLastError();
     }
     HIP_TRY(hipDeviceSynchronize());
     return resolve_device_reports(d, nullptr, 0);

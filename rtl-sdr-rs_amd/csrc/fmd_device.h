@@ -89,7 +89,14 @@ struct FmdExcArgs {
     const int16_t* d16;
     int16_t* out_c;          // &out[c][0]
     FmdExcBuf* exc;
+    uint32_t* hflag;         // FmdLaunch::hflag
 };
+
+// "This launch has written into its report buffer": the host-mapped word fmd_demod_check reads (rare paths only).
+__device__ __forceinline__ void fmd_flag_report(uint32_t* hflag)
+{
+    if (hflag) __hip_atomic_store(hflag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);      // (a plain store: every writer writes 1, the host clears it when the slot is idle)
+}
 
 [[maybe_unused]] static __device__ __noinline__ void exc_emit(FmdExcArgs a, int j, int cr, int ci)
 {
@@ -110,6 +117,7 @@ struct FmdExcArgs {
     atomicAdd(&a.exc->guarded_total, 1u);
     const uint32_t slot = atomicAdd(&a.exc->count, 1u);
     if (slot < FMD_EXC_CAP) a.exc->rec[slot] = e; else atomicOr(&a.exc->err, FMD_DEVERR_EXC_CAP);
+    fmd_flag_report(a.hflag);
 }
 
 __device__ __forceinline__ FmdExcArgs exc_args(const FmdLaunch& L, uint32_t c, uint32_t i0r, uint32_t K, int now_lpr_in,
@@ -118,7 +126,7 @@ __device__ __forceinline__ FmdExcArgs exc_args(const FmdLaunch& L, uint32_t c, u
     FmdExcArgs a;
     a.sr = L.r.sr; a.fr = L.r.fr; a.i0r = i0r; a.K = K; a.c = c; a.seq = L.seq;
     a.now_lpr_in = now_lpr_in; a.jfirst = jfirst; a.d16 = d16;
-    a.out_c = L.out + (uint64_t)c * L.out_stride; a.exc = L.exc;
+    a.out_c = L.out + (uint64_t)c * L.out_stride; a.exc = L.exc; a.hflag = L.hflag;
     return a;
 }
 

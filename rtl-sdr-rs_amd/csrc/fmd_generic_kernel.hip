@@ -62,7 +62,7 @@ __global__ void __launch_bounds__(FMD_BLOCK_THREADS) fmd_demod_generic_kernel(co
     const uint64_t a0 = gLo & ~15ull;
     const uint32_t nchunks = (uint32_t)((gHi - a0 + 15) >> 4);
     if ((uint32_t)cnt > L.lp_cap || nchunks * 16u > L.raw_cap) {
-        if (tid == 0) atomicOr(L.err, (uint32_t)cnt > L.lp_cap ? FMD_DEVERR_LP_CAP : FMD_DEVERR_RAW_CAP);
+        if (tid == 0) { atomicOr(L.err, (uint32_t)cnt > L.lp_cap ? FMD_DEVERR_LP_CAP : FMD_DEVERR_RAW_CAP); fmd_flag_report(L.hflag); }
         return;
     }
     const uint64_t gend = (uint64_t)(uintptr_t)L.iq + L.total_bytes;

@@ -150,6 +150,8 @@ struct FmdLaunch {
     // without an event or a copy between the two kernels (an event behind every launch costs 2 - 3 % per launch, round 5).
     const FmdExcBuf* exc_prev; // the predecessor's report buffer, or nullptr
     uint32_t* mbox;           // host-mapped, 8-byte aligned: low word = seq of the launch known complete, high word = 1 | 2 if its report buffer holds an error / records; or nullptr
+    uint32_t* hflag;          // host-mapped word of THIS launch's ring slot, or nullptr: set (a system-scope store of 1, on the rare paths only) whenever the launch writes a
+                              // record or an error bit into `exc` -- fmd_demod_check reads it after its stream synchronisation instead of copying the buffer's head
     double    f64_guard;      // half-width of the guard band around integers (see above)
     uint32_t  seq;            // launch sequence number (FmdF64Exc::seq)
     int32_t   f64_skew;       // -DFMD_EXPERIMENT builds only: added to the kernel's value of guarded samples (patch-path test)

@@ -1062,7 +1062,7 @@ __device__ __forceinline__ void tile_body(const FmdLaunch& L, const TileCtx& X, 
 __device__ __forceinline__ bool tile_fits(const FmdLaunch& L, const TileCtx& X, uint32_t tid)
 {
     if ((uint32_t)X.cnt > L.lp_cap || X.nchunks * 16u > L.raw_cap) {
-        if (tid == 0) atomicOr(L.err, (uint32_t)X.cnt > L.lp_cap ? FMD_DEVERR_LP_CAP : FMD_DEVERR_RAW_CAP);
+        if (tid == 0) { atomicOr(L.err, (uint32_t)X.cnt > L.lp_cap ? FMD_DEVERR_LP_CAP : FMD_DEVERR_RAW_CAP); fmd_flag_report(L.hflag); }
         return false;
     }
     return true;
