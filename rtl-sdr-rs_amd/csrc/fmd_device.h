@@ -220,7 +220,12 @@ __device__ __forceinline__ uint32_t f2u(float f) { return __builtin_bit_cast(uin
 // NOWRAP: the caller guarantees |s| < 2^19 (downsample <= 3: 2 (128 * 3)^2 = 294 912), where `(4096 * s) as i32` cannot wrap.
 // k4096: 4096.0f; straight-line callers (the register-streaming rounds) pass it in a register they keep for the whole
 // function -- hipcc otherwise re-materialises it with a v_mov in front of every v_bfi.
-template <bool NOWRAP = false, bool LO16 = false>
+// WRAP1: downsample 4 exactly.  There |lp| <= 512, so s = +-(|x| - |y|) lies in [-2^19, 2^19] and `(4096 * s) as i32` wraps for ONE value,
+// s = +2^19 (a = b = (512, 512): the saturated constant input), which becomes -2^19; -2^19 * 4096 = -2^31 still fits.  The general form
+// below spends four adds on the wrap; here clamp(s - (2^19 - 1)) is exactly 1 at that value and 0 everywhere else (s is an integer), and
+// one fma takes 2^20 off: two instructions (tests/test_disc_f32_model.py::test_single_point_wrap_at_downsample_4,
+// tests/test_gpu_parity.py::test_diagonal_full_scale).
+template <bool NOWRAP = false, bool LO16 = false, bool WRAP1 = false>
 __device__ __forceinline__ int disc_f32_xy(float xf, float yf, float k4096 = 4096.0f)
 {
     const float den = __builtin_fabsf(xf) + __builtin_fabsf(yf);
@@ -228,7 +233,8 @@ __device__ __forceinline__ int disc_f32_xy(float xf, float yf, float k4096 = 409
     const uint32_t sx = f2u(xf) & 0x80000000u;
     const float s = u2f(f2u(t) ^ sx);
     const float big = 13194139533312.0f;                                 // 1.5 * 2^43
-    const float sp = NOWRAP ? s : s - (((s + 0.5f) + big) - big);        // s mod 2^20, signed
+    const float sp = NOWRAP ? s : WRAP1 ? __builtin_fmaf(clamp01(s - 524287.0f), -1048576.0f, s)
+                                        : s - (((s + 0.5f) + big) - big);  // s mod 2^20, signed
     // (0, 0): den = 0 -> rcp = inf, m * inf = 0 * inf = NaN, and NaN runs through the rounding / the subtract (whatever the
     // clamped fma makes of it) / the sign xors to the final conversion, where v_cvt_i32_f32 turns it into 0 -- exactly
     // fast_atan2's `(0, 0) -> 0` (:388).  Three instructions fewer than guarding the reciprocal and multiplying by a
@@ -270,7 +276,7 @@ __device__ __forceinline__ int disc_f32(uint32_t a, uint32_t b)
 // The same with the samples' components already in f32 (exact integers): c = a * conj(b) by four fmas -- every product
 // is below 2^22 and every sum below 2^23 for downsample <= 16, so nothing rounds -- instead of pack, swap, conjugate, two
 // dot products and two conversions.
-template <bool NOWRAP = false, bool LO16 = false>
+template <bool NOWRAP = false, bool LO16 = false, bool WRAP1 = false>
 __device__ __forceinline__ int disc_f32_c(float ar, float ai, float br, float bi, float k4096 = 4096.0f)
 {
     // A product such as 0 * -5 is -0, and (-0) + (-0) stays -0; fast_atan2 takes its signs from x < 0 / y < 0, where zero
@@ -285,7 +291,7 @@ __device__ __forceinline__ int disc_f32_c(float ar, float ai, float br, float bi
     //  1 % slower than the six-instruction form: not adopted.)
     const float xf = __builtin_fmaf(ai, bi, __builtin_fmaf(ar, br, 0.0f));       // ar*br + ai*bi
     const float yf = __builtin_fmaf(ai, br, __builtin_fmaf(-ar, bi, 0.0f));      // ai*br - ar*bi
-    return disc_f32_xy<NOWRAP, LO16>(xf, yf, k4096);
+    return disc_f32_xy<NOWRAP, LO16, WRAP1>(xf, yf, k4096);
 }
 
 // Decimated samples travel packed: re in the low, im in the high 16 bits (|lp| <= 128 * D <= 16384).

@@ -13,7 +13,10 @@
  * this kernel, profiles/r06_experiments.md 3): 16 instead of 12 rounds -- fewer ramps, barriers and resampler tails per byte -- is 1.0 ... 2.1 %
  * faster at downsample 2 and -0.8 ... +3.4 % at downsample 4 (where the planner's larger tile is not always the better one): 16 at
  * downsample 2 only. */
-#define FMD_STREAM_MAX_ROUNDS(D) ((D) == 2u ? 16u : 12u)
+// Rounds per wave of the register-streaming kernels (straight-line code; the host sizes the tiles accordingly).  Downsample 4: 8 --
+// ONE-SHOT waves, every load of a wave's rounds issued up front (round 6: -2 ... -5 % against 12 rounds with 8 loads in flight and
+// refills, profiles/r06_experiments.md 12); downsample 2: 16 with 8 in flight (all 16 up front: +7 %; 8 one-shot: +12 %).
+#define FMD_STREAM_MAX_ROUNDS(D) ((D) == 2u ? 16u : 8u)
 #define FMD_TILE_MAX_LOADS 8      /* 16-byte chunks per thread the tile kernel can stage */
 
 // Device-side error bits (FmdLaunch::err), all "cannot happen" conditions.

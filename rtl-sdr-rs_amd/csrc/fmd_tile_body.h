@@ -483,20 +483,22 @@ __device__ __forceinline__ void stream_load(const unsigned char* __restrict__ p,
 
 template <int DH>
 __device__ __forceinline__ void stream_pair_rounds(const unsigned char* __restrict__ chan, uint32_t nbytes, int16_t* __restrict__ d16,
-                                                   int jfirst, uint32_t hp, int cnt, uint32_t lane, uint32_t wave)
+                                                   int jfirst, uint32_t hp, int cnt, uint32_t lane, uint32_t wave, [[maybe_unused]] uint32_t dbg)
 {
     constexpr int NDW = 2 * DH;
-#ifdef FMD_STREAM_P
-    constexpr int P = FMD_STREAM_P;                          // (variant builds: rounds in flight per wave)
-#else
     // rounds in flight per wave (register budget: 64 VGPRs; the kernel runs downsample 2 and 4 -- 2 / 4 dwords per lane and round, 32 / 46
     // VGPRs at 8 rounds: session r05bk, 3 / 4 / 5 / 6 / 8 rounds: +0.9 ... 0 / 0 / -0.3 ... -1.0 / -0.3 ... -1.2 / -0.4 ... -1.7 %)
-    constexpr int P = NDW <= 4 ? 8 : (NDW <= 6 ? 4 : (NDW <= 10 ? 3 : 2));
-#endif
-    constexpr int32_t STRIDE = 4 * DH * NW * RS;             // bytes from one round of a wave to its next
+    constexpr int P0 = NDW <= 4 ? 8 : (NDW <= 6 ? 4 : (NDW <= 10 ? 3 : 2));
+    // ONE-SHOT waves (round 6, downsample 4): no more rounds per wave than register sets -- every load of the wave is issued up front,
+    // nothing is refilled, the wave is short-lived like a block of the LDS-DMA kernels (what tools/membench shows for plain reads:
+    // one-shot tiles 6.3 - 7.0 TB/s, a grid-stride stream 5.3 - 5.6)
+    constexpr bool ONESHOT = (int)FMD_STREAM_MAX_ROUNDS(2u * DH) <= P0;
+    constexpr int P = ONESHOT ? (int)FMD_STREAM_MAX_ROUNDS(2u * DH) : P0;
     wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)wave);
     const int last = cnt - 1;
+    constexpr int RSTEP = NW * RS;
     int base = (int)wave * RS;
+    constexpr int32_t STRIDE = 4 * DH * RSTEP;               // bytes from one round of a wave to its next
     if (base >= last) return;
     const int jw = jfirst + base;
     const bool o1 = ((((DH & 1) ? ((uint32_t)jw ^ hp) : hp)) & 1u) != 0u, o2 = o1 != ((DH & 1) != 0);   // wave-uniform (see tile_body)
@@ -516,7 +518,7 @@ __device__ __forceinline__ void stream_pair_rounds(const unsigned char* __restri
         int32_t o;                                           // clamp(off, 0, lim) as ONE instruction (hipcc: min, compare, VCC select)
         asm("v_med3_i32 %0, %1, 0, %2" : "=v"(o) : "v"(off), "s"(lim));
         stream_load<NDW>(chan + (uint32_t)o, w);
-        off += STRIDE; fbase += NW * RS;
+        off += STRIDE; fbase += RSTEP;
     };
     // Per lane: where its two samples of round 0 go, and how many samples are left from there.  Round k is then a compile-time
     // offset (the rounds are unrolled) and ONE compare against a literal per store instead of index arithmetic per round.
@@ -528,7 +530,16 @@ __device__ __forceinline__ void stream_pair_rounds(const unsigned char* __restri
     asm volatile("" : "+v"(bre), "+v"(bim1), "+v"(bim2), "+v"(k4096));
     const int rem = cnt - base - 2 * (int)lane;              // sample i1 of round k is inside the tile iff k * NW * RS < rem
     auto round = [&](const uint32_t (&w)[NDW], auto kc) {
-        constexpr int KO = decltype(kc)::value * NW * RS;
+        constexpr int KO = decltype(kc)::value * RSTEP;
+#ifdef FMD_EXPERIMENT
+        if ((dbg >> 24) & 1u) {                                  // ablation (experiment build): the loads and one store per round, no arithmetic -- the kernel's skeleton
+            uint32_t x = w[0];
+#pragma unroll
+            for (int u = 1; u < NDW; ++u) x ^= w[u];
+            if (KO < rem) dl[KO] = (int16_t)x;
+            return;
+        }
+#endif
         int re1 = bre, im1 = bim1, re2 = bre, im2 = bim2;
         uint32_t dead1 = 0, dead2 = 0;
 #pragma unroll
@@ -549,8 +560,8 @@ __device__ __forceinline__ void stream_pair_rounds(const unsigned char* __restri
         const float br1 = u2f(wave_shr1_dead(dead1, f2u(ar2))), bi1 = u2f(wave_shr1_dead(dead2, f2u(ai2)));   // second window of lane l - 1
         // (the discriminators sit INSIDE the predicated stores: two separately masked instruction streams, the form hipcc
         //  built by itself while the conversion at their end was a plain cast it could sink -- and the faster one)
-        if (lane > 0 && KO < rem) dl[KO] = (int16_t)disc_f32_c<DH == 1, true>(ar1, ai1, br1, bi1, k4096);
-        if (KO + 1 < rem) dl[KO + 1] = (int16_t)disc_f32_c<DH == 1, true>(ar2, ai2, ar1, ai1, k4096);
+        if (lane > 0 && KO < rem) dl[KO] = (int16_t)disc_f32_c<DH == 1, true, DH == 2>(ar1, ai1, br1, bi1, k4096);
+        if (KO + 1 < rem) dl[KO + 1] = (int16_t)disc_f32_c<DH == 1, true, DH == 2>(ar2, ai2, ar1, ai1, k4096);
     };
     // Straight-line code for up to FMD_STREAM_MAX_ROUNDS(downsample) rounds per wave (the host sizes the tiles accordingly): in a
     // loop hipcc's wait-count pass gives up at the back edge and waits for EVERY outstanding load (vmcnt(0)) once per trip,
@@ -559,8 +570,17 @@ __device__ __forceinline__ void stream_pair_rounds(const unsigned char* __restri
 #pragma unroll
     for (int p = 0; p < P; ++p) fetch(w[p]);
     constexpr int MAXR = (int)FMD_STREAM_MAX_ROUNDS(2u * DH);
+    if constexpr (ONESHOT) {
+        static_assert(P == MAXR && MAXR <= 16, "one-shot form");
+#define FMD_SR1(K) if constexpr ((K) < MAXR) { round(w[(K) % P], std::integral_constant<int, (K)>{}); \
+                       if constexpr ((K) + 1 < MAXR) { base += RSTEP; if (base >= last) return; } }
+        FMD_SR1(0) FMD_SR1(1) FMD_SR1(2) FMD_SR1(3) FMD_SR1(4) FMD_SR1(5) FMD_SR1(6) FMD_SR1(7)
+        FMD_SR1(8) FMD_SR1(9) FMD_SR1(10) FMD_SR1(11) FMD_SR1(12) FMD_SR1(13) FMD_SR1(14) FMD_SR1(15)
+#undef FMD_SR1
+        return;
+    } else {
     static_assert(MAXR == 12 || MAXR == 16, "the unrolled rounds below");
-#define FMD_SR(K) round(w[(K) % P], std::integral_constant<int, (K)>{}); base += NW * RS; if (base >= last) return; fetch(w[(K) % P])
+#define FMD_SR(K) round(w[(K) % P], std::integral_constant<int, (K)>{}); base += RSTEP; if (base >= last) return; fetch(w[(K) % P])
     FMD_SR(0); FMD_SR(1); FMD_SR(2); FMD_SR(3); FMD_SR(4); FMD_SR(5); FMD_SR(6); FMD_SR(7); FMD_SR(8); FMD_SR(9); FMD_SR(10);
     if constexpr (MAXR == 16) {
         FMD_SR(11); FMD_SR(12); FMD_SR(13); FMD_SR(14);
@@ -569,6 +589,7 @@ __device__ __forceinline__ void stream_pair_rounds(const unsigned char* __restri
         round(w[11 % P], std::integral_constant<int, 11>{});
     }
 #undef FMD_SR
+    }
 }
 
 // Everything after the tile's bytes are visible in LDS.  Contains one __syncthreads().
@@ -630,7 +651,7 @@ __device__ __forceinline__ void tile_body(const FmdLaunch& L, const TileCtx& X, 
     if constexpr (STREAM) {
         // (the host only selects this kernel for an even downsample at an even boxcar phase: whole-dword windows)
         if constexpr (DH == 1 || DH == 2)
-            stream_pair_rounds<DH>(reinterpret_cast<const unsigned char*>((uintptr_t)X.gbase), 2u * L.ns, d16, jfirst, hp, cnt, lane, wave);
+            stream_pair_rounds<DH>(reinterpret_cast<const unsigned char*>((uintptr_t)X.gbase), 2u * L.ns, d16, jfirst, hp, cnt, lane, wave, L.dbg);
     } else if (fastwin && (DH != 4 || dh4_aligned)) {
         // Whole-dword windows, f32 discriminator (downsample 2 ... 10).  Lane l takes the ADJACENT windows i = base + 2l
         // and i + 1: the second window's predecessor is the lane's own first one, and only the first one's comes from
@@ -694,8 +715,8 @@ __device__ __forceinline__ void tile_body(const FmdLaunch& L, const TileCtx& X, 
             const float br1 = u2f(wave_shr1_dead(dead1, f2u(ar2))), bi1 = u2f(wave_shr1_dead(dead2, f2u(ai2)));   // second window of lane l - 1
             // (:362); DH == 1 is downsample 2: no i32 wrap to emulate.  The discriminators sit INSIDE the predicated stores
             // (see stream_pair_rounds)
-            if (lane > 0 && (FULL || i1 < cnt)) d16[i1] = (int16_t)disc_f32_c<DH == 1, true>(ar1, ai1, br1, bi1);
-            if (FULL || i2 < cnt) d16[i2] = (int16_t)disc_f32_c<DH == 1, true>(ar2, ai2, ar1, ai1);
+            if (lane > 0 && (FULL || i1 < cnt)) d16[i1] = (int16_t)disc_f32_c<DH == 1, true, DH == 2>(ar1, ai1, br1, bi1);
+            if (FULL || i2 < cnt) d16[i2] = (int16_t)disc_f32_c<DH == 1, true, DH == 2>(ar2, ai2, ar1, ai1);
         };
         int base = (int)wave * RS;
         const int full_to = cnt - 128;                       // (the bound as ONE scalar: `base + 128 <= cnt` cost an add per round)

@@ -31,8 +31,9 @@ def fast_atan2_ref(y, x):
     return np.where((x == 0) & (y == 0), 0, res)
 
 
-def disc_f32_model(x, y, rcp_ulps):
-    """disc_f32 after the two dot products, in float32; rcp = correctly rounded 1/d nudged by rcp_ulps ulps."""
+def disc_f32_model(x, y, rcp_ulps, wrap1=False):
+    """disc_f32 after the two dot products, in float32; rcp = correctly rounded 1/d nudged by rcp_ulps ulps.
+    wrap1: the single-point form of the i32 wrap the kernels use at downsample 4 (disc_f32_xy<.., WRAP1>)."""
     xf, yf = x.astype(F), y.astype(F)
     den = np.abs(xf) + np.abs(yf)
     t = np.abs(xf) - np.abs(yf)
@@ -40,6 +41,9 @@ def disc_f32_model(x, y, rcp_ulps):
     s = (t.view(np.uint32) ^ sx).view(F)
     big = F(13194139533312.0)
     sp = s - (((s + F(0.5)) + big) - big)
+    if wrap1:
+        t1 = np.clip(s - F(524287.0), F(0), F(1))               # v_sub_f32 with the clamp modifier: exact, s is an integer
+        sp = (t1.astype(np.float64) * -1048576.0 + s.astype(np.float64)).astype(F)      # one fma: exact product and sum, one rounding (of an integer < 2^24)
     d = den + F(2.0 ** -30)
     rc = (1.0 / d.astype(np.float64)).astype(F)
     for _ in range(abs(rcp_ulps)):
@@ -121,6 +125,25 @@ def test_f32_discriminator_is_exact(rcp_ulps):
     assert bad.size == 0, [(int(x[i]), int(y[i]), int(ref[i]), int(got[i])) for i in bad[:8]]
     # the wrap is really exercised, and so is the +1 correction
     assert np.count_nonzero(np.abs(np.abs(x) - np.abs(y)) >= 2**19) > 100000
+
+
+@pytest.mark.parametrize("rcp_ulps", [-2, 0, 2])
+def test_single_point_wrap_at_downsample_4(rcp_ulps):
+    """disc_f32_xy<.., WRAP1>: with |lp| <= 512 the product of `(4096 * s) as i32` wraps for s = +2^19 alone (a = b = (512, 512)); the
+    kernels' two-instruction form is checked on every input class of `cases` at that limit plus the whole neighbourhood of the wrap point."""
+    x, y = cases(512)
+    ext = np.arange(2**19 - 40, 2**19 + 1)
+    x = np.concatenate([x, ext, -ext, ext - 7, -(ext - 7)]); y = np.concatenate([y, np.zeros(2 * ext.size, np.int64), np.full(ext.size, 7), np.full(ext.size, -7)])
+    s = np.where(x >= 0, x - np.abs(y), x + np.abs(y))
+    assert s.max() == 2**19 and s.min() == -2**19 and np.count_nonzero(s == 2**19) >= 1      # the domain: [-2^19, 2^19]
+    ref = fast_atan2_ref(y, x)
+    got = disc_f32_model(x, y, rcp_ulps, wrap1=True)
+    bad = np.nonzero(ref != got)[0]
+    assert bad.size == 0, [(int(x[i]), int(y[i]), int(ref[i]), int(got[i])) for i in bad[:8]]
+    assert fast_atan2_ref(np.array([0]), np.array([2**19]))[0] == 8192                         # the reference's own value at the wrap point (:397)
+    # one step outside the domain (downsample 5) the single-point form must fail: it is tied to the factor
+    x5, y5 = cases(640)
+    assert np.count_nonzero(disc_f32_model(x5, y5, 0, wrap1=True) != fast_atan2_ref(y5, x5)) > 0
 
 
 def test_f32_discriminator_limit_is_where_the_kernel_stops():

@@ -136,16 +136,17 @@ def test_fuzz_several_reference_calls_per_launch(fmd, oracle):
 
 def test_fuzz_streaming_kernel(fmd, oracle):
     """Downsample 2 and 4 with >= 8 channels run the register-streaming kernel (fmd_demod_stream_kernel: global memory ->
-    registers, no LDS staging, tiles of ~1000 audio samples): random rates, 8 ... 40 channels, calls from a fraction of a
+    registers, no LDS staging, tiles of 400 ... 1000 audio samples): random rates, 8 ... 40 channels, calls from a fraction of a
     tile to several tiles (and one reference-sized buffer), random / full-scale / near-silent / synthetic data, boxcar
     phases 0 and 2, the clamped spans at both ends of a call, state after every call."""
     n_cases = max(6, int(os.environ.get("FMD_FUZZ_CASES", "40")) // 3)
     rng = np.random.default_rng(int(os.environ.get("FMD_FUZZ_SEED", "20260101")) + 11)
     if not os.environ.get("FMD_LIB"):
         # the kernel under test is the one that runs: a bank of >= 8 channels reports the streaming kernel's tiling (larger
-        # tiles, LDS for the discriminator samples only), a small bank the LDS-DMA kernel's
+        # tiles -- 8 one-shot rounds per wave at downsample 4 since round 6 --, LDS for the discriminator samples only), a small
+        # bank the LDS-DMA kernel's
         small, large = fmd.DemodBank(mkcfg(fmd, 4, 256000, 48000), 2).tiling(), fmd.DemodBank(mkcfg(fmd, 4, 256000, 48000), 8).tiling()
-        assert large["audio_per_tile"] > 2 * small["audio_per_tile"] and large["lds_bytes"] < small["lds_bytes"], (small, large)
+        assert large["audio_per_tile"] > 1.5 * small["audio_per_tile"] and large["lds_bytes"] < small["lds_bytes"] / 2, (small, large)
     for case in range(n_cases):
         D = int(rng.choice([2, 4]))
         slow = int(rng.choice(RATES))

@@ -165,6 +165,30 @@ def test_axis_aligned_full_scale(fmd, oracle, D, fast, slow):
     check_stream(fmd, oracle, D, fast, slow, blocks, n_channels=nch)
 
 
+@pytest.mark.parametrize("D,fast,slow", [(2, 500000, 32000), (3, 400000, 48000), (4, 256000, 48000), (4, 200000, 32000), (5, 250000, 44100),
+                                         CFG_REF, (8, 250000, 44100), CFG_24, (16, 150000, 32000)])
+def test_diagonal_full_scale(fmd, oracle, D, fast, slow):
+    """Decimated samples on the DIAGONALS at full scale, (+-F, +-F) in random order with the axes mixed in: a = b = (128 D, 128 D) gives
+    x = 2 (128 D)^2, y = 0 -- at downsample 4 exactly 2^19, the ONE product for which `(4096 * s) as i32` (:397) wraps at that factor
+    (s = +2^19 -> -2^31; every other s lies in [-520192, 2^19)), which the reference turns into 8192 where the angle is 0; from
+    downsample 5 on the wrap is two-sided.  The kernels' single-point form of the wrap at downsample 4 (fmd_device.h) stands on this."""
+    rng = np.random.default_rng(4000 + D)
+    nch = 5
+    seg = 8 * D
+    vals = [(128, 128), (-127, -127), (128, -127), (-127, 128), (128, 0), (0, 128), (-127, 0), (0, -127), (0, 0)]
+    blocks = []
+    for i in range(3):
+        nseg = int(rng.integers(30, 80))
+        blk = np.empty((nch, nseg * seg), np.uint8)
+        for c in range(nch):
+            picks = rng.integers(0, 4 if c == 1 else len(vals), nseg)             # channel 1: diagonals only
+            if c == 2:
+                picks[:] = 0                                                      # channel 2: the saturated constant -- every product is the wrap point
+            blk[c] = np.concatenate([np.tile(axis_pattern(*vals[k]), seg // 8) for k in picks])
+        blocks.append(blk)
+    check_stream(fmd, oracle, D, fast, slow, blocks, n_channels=nch)
+
+
 @pytest.mark.parametrize("kt", [1, 2, 7, 64, 300])
 def test_tiling_invariance(fmd, oracle, kt):
     rng = np.random.default_rng(kt)
