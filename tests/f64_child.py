@@ -157,6 +157,8 @@ def scenario_pipelined(D, fast, slow, nch, back=1):
     N, ncalls = 8 * 512, 7
     cfg, ocfg = mkcfg(D, fast, slow), o.config(D, fast, slow)
     bank, obank = fmd.DemodBank(cfg, nch), o.new_bank(ocfg, nch)
+    if os.environ.get("FMD_TEST_EVENT_ORDERING"):
+        bank.set_event_ordering(True)                        # every wait goes to the launch's event (the report flags are read behind it)
     rng = np.random.default_rng(D + 90)
     cap = bank.out_cap(N)
     ins, outs, exps = [], [], []

@@ -18,8 +18,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 EXP = os.path.join(ROOT, "rtl-sdr-rs_amd", "libfmd_hip_exp.so")
 
 
-def run_child(args, guard_log2=None, skew=None):
+def run_child(args, guard_log2=None, skew=None, extra_env=None):
     env = dict(os.environ, PYTHONPATH=ROOT)
+    env.update(extra_env or {})
     if guard_log2 is not None or skew is not None:
         # both knobs exist in the -DFMD_EXPERIMENT build only: the shipped library's guard band is 2^-20, fixed
         assert os.path.exists(EXP), "build() makes libfmd_hip_exp.so (make -C rtl-sdr-rs_amd/csrc exp)"
@@ -106,3 +107,17 @@ def test_check_behind_patches_the_older_launches_in_flight(D, fast, slow, nch, b
 def test_check_behind_on_the_shipped_library_is_quiet_and_exact(back):
     r = run_child(["pipelined", 6, 170000, 32000, 64, back])
     assert r["bad"] == 0 and r["state_bad"] == 0 and r["stats"]["patched"] == 0
+
+
+@pytest.mark.parametrize("back", [0, 1, 2])
+def test_completion_points_under_event_ordering(back):
+    """fmd_demod_set_event_ordering: every wait of the completion points goes to the event behind the launch -- fmd_demod_check reads
+    the launches' report flags behind it (round 6: no head copy), fmd_demod_check_behind spins on the mailbox and falls back to the event.
+    Every f64 sample guarded: once agreeing with the host (the light settle path), once wrong on the device (patches in the older launches'
+    buffers, the carried sum through the replay chain); back = 0 is fmd_demod_check after every launch."""
+    ev = {"FMD_TEST_EVENT_ORDERING": "1"}
+    r = run_child(["pipelined", 6, 170000, 32000, 16, back], guard_log2=-1, extra_env=ev)
+    assert r["bad"] == 0 and r["state_bad"] == 0 and r["stats"]["patched"] == 0 and r["stats"]["guarded"] > 0
+    r = run_child(["pipelined", 2, 500000, 8000, 16, back], guard_log2=-1, skew=13, extra_env=ev)
+    assert r["bad"] == 0 and r["state_bad"] == 0 and r["stats"]["guarded"] > 0 and r["stats"]["patched"] >= r["stats"]["guarded"] // 3, r
+
